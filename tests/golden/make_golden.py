@@ -1,0 +1,254 @@
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference compiled into oracle/_ref by
+oracle/build_ref.py, and torch CPU):
+
+    OMP_THREAD_LIMIT=8 python tests/golden/make_golden.py
+
+Sources of truth:
+  * query / key SimHash: the literal torch-CPU restatement of models/attnserver.py:264-270
+    and :159-168 (the reference computes these with torch ops, not in its C++ libraries);
+  * tables, retrieve, sparse attention: the reference's compiled C++ (library/lsh/lsh.cc,
+    library/sparse_attention/sparse_attention.cc) driven through its own pybind11 API.
+Inputs are regenerated from seeds by tests/synth.py (integer-only, platform independent);
+only OUTPUTS are stored (np.savez_compressed).  Sorting uses torch.sort(stable=True) so the
+bucket-internal order -- unspecified in the reference (models/attnserver.py:187 uses an
+unstable sort) -- is reproducible with numpy's stable argsort.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import synth  # noqa: E402
+from oracle.build_ref import load_ref, ref_uses_bf16_family  # noqa: E402
+
+
+# ----------------------------------------------------------------- torch restatements
+
+def torch_qhash(q: torch.Tensor, hash_func: torch.Tensor, K: int, L: int) -> torch.Tensor:
+    """models/attnserver.py:264-270, verbatim on CPU tensors."""
+    binary_pack = torch.Tensor([int(2 ** i) for i in range(K)]).to(dtype=torch.float16)
+    norm_q = q.reshape(-1, q.shape[-1])
+    norm_q = norm_q / norm_q.norm(p=2, dim=-1, keepdim=True)
+    q_hashcode = torch.matmul(norm_q, hash_func).gt(0)
+    q_hashcode = q_hashcode.reshape(-1, K).to(torch.float16)
+    q_hashcode = torch.mv(q_hashcode, binary_pack).int()
+    return q_hashcode.reshape(-1, L)
+
+
+def torch_khash(offload_key: torch.Tensor, hash_func: torch.Tensor, K: int, L: int) -> torch.Tensor:
+    """models/attnserver.py:159-168 (one chunk), offload_key bf16 [Hkv, n, D] -> int16 [Hkv, L, n]."""
+    Hkv = offload_key.shape[0]
+    binary_pack = torch.Tensor([int(2 ** i) for i in range(K)]).to(dtype=torch.float16)
+    hash_code = torch.matmul(offload_key, hash_func)
+    hash_code = hash_code > 0
+    hash_code = hash_code.reshape(-1, K).to(torch.float16)
+    hash_code = torch.mv(hash_code, binary_pack)
+    hash_code = hash_code.reshape(Hkv, -1, L)
+    return hash_code.transpose(1, 2).contiguous().to(torch.int16)
+
+
+# ----------------------------------------------------------------- case builders
+
+def case_inputs(seed, B, H, Hkv, n, D, K, L):
+    """Synthetic single-layer inputs shared by the generator and the tests."""
+    keys, kns, vals = [], [], []
+    for b in range(B):
+        k, kn = synth.centred_keys(seed + 10 * b, Hkv, n, D)
+        keys.append(k)
+        kns.append(kn)
+        vals.append(synth.normal_bf16_bits(seed + 10 * b + 1, (Hkv, n, D)))
+    W = synth.normal_bf16_bits(seed + 7, (D, K * L))
+    q = synth.normal_f32(seed + 3, (B * H, D))
+    # heavy hitters: pull each query toward one key of its kv group so a few
+    # tokens have cos ~ 0.9 and the importance weights span several orders of magnitude
+    G = H // Hkv
+    tgt = synth.randint(seed + 4, 0, n, (B * H,))
+    for h in range(B * H):
+        b, g = h // H, (h % H) // G
+        q[h] = 0.5 * q[h] + 3.0 * synth.bf16_bits_to_f32(keys[b][g, tgt[h]])
+    qb = synth.f32_to_bf16_bits(q)
+    return np.stack(keys), np.stack(kns), np.stack(vals), W, qb
+
+
+def run_pipeline(name, seed, B, H, Hkv, n, M, D, K, L, ref_lsh, ref_attn, out):
+    keys, kns, vals, W, qb = case_inputs(seed, B, H, Hkv, n, D, K, L)
+    Wt = synth.to_torch_bf16(W)
+    # --- SimHash (torch restatement)
+    qcodes = torch_qhash(synth.to_torch_bf16(qb), Wt, K, L).contiguous()
+    kcodes = torch.stack([torch_khash(synth.to_torch_bf16(keys[b]), Wt, K, L) for b in range(B)])
+    # --- tables + retrieve (compiled reference)
+    lsh = ref_lsh.LSH()
+    lsh.alloc(K, L, 1, H, Hkv, B, M)
+    for b in range(B):
+        sc, si = kcodes[b].sort(stable=True)
+        lsh.fill(0, b, sc.contiguous(), si.int().contiguous())
+    results = torch.zeros((B * H, M), dtype=torch.int32)
+    nnz = torch.zeros((B * H,), dtype=torch.int32)
+    lsh.batch_retrieve(0, qcodes, results, nnz)
+    mask = lsh.get_mask().clone().reshape(B * H, M)
+    # --- sparse attention (compiled reference, bf16 query as models/attnserver.py:300)
+    srv = ref_attn.SparseAttentionServer()
+    srv.alloc(1, H, Hkv, D, B, M)
+    for b in range(B):
+        srv.fill(0, b, synth.to_torch_bf16(keys[b]), synth.to_torch_bf16(vals[b]),
+                 torch.from_numpy(kns[b]))
+    q_t = synth.to_torch_bf16(qb)
+    qn = q_t.float().norm(p=2, dim=-1)
+    output = torch.zeros((B * H, D), dtype=torch.bfloat16)
+    mve = torch.zeros((2, B * H), dtype=torch.float32)
+    srv.attention_wrapper(0, K, L, output, mve, q_t, qn, results, nnz)
+    probs = srv.get_score().reshape(B * H, M)
+    nz = nnz.numpy()
+    out[name] = dict(
+        meta=np.array([seed, B, H, Hkv, n, M, D, K, L], np.int64),
+        qcodes=qcodes.numpy().astype(np.int32),
+        kcodes_sha=np.frombuffer(hashlib.sha256(kcodes.numpy().tobytes()).digest(), np.uint8),
+        kcodes_head0_table0=kcodes[0, 0, 0].numpy().copy(),
+        nnz=nz.copy(),
+        results_ref_order=np.concatenate([results[h, :nz[h]].numpy() for h in range(B * H)]),
+        mask_hist=np.stack([np.bincount(mask[h].numpy().astype(np.int64), minlength=3)
+                            for h in range(B * H)]),
+        qnorm=qn.numpy().copy(),
+        out_bits=output.view(torch.int16).numpy().view(np.uint16).copy(),
+        mve=mve.numpy().copy(),
+        probs=np.concatenate([probs[h, :nz[h]].numpy() for h in range(B * H)]),
+    )
+    print(f"{name}: nnz mean {nz.mean():.1f} min {nz.min()} max {nz.max()}")
+
+
+def run_qhash_only(name, seed, R, D, K, L, out):
+    qb = synth.normal_bf16_bits(seed, (R, D))
+    W = synth.normal_bf16_bits(seed + 7, (D, K * L))
+    codes = torch_qhash(synth.to_torch_bf16(qb), synth.to_torch_bf16(W), K, L)
+    out[name] = dict(meta=np.array([seed, R, D, K, L], np.int64), qcodes=codes.numpy().astype(np.int32))
+    print(f"{name}: done")
+
+
+def run_lsh_edge(name, seed, ref_lsh, out):
+    """Hand-built queries on random tables: an empty-result head, a head that selects a known
+    token, heads sharing a kv group, re-query on the same tables (mask reset, lsh/test.py:59-76)."""
+    K, L, H, Hkv, B, n, M = 8, 24, 4, 2, 2, 200, 264
+    NB = 1 << K
+    codes = synth.randint(seed, 0, NB, (B, Hkv, L, n)).astype(np.int16)
+    lsh = ref_lsh.LSH()
+    lsh.alloc(K, L, 2, H, Hkv, B, M)
+    kc = torch.from_numpy(codes)
+    for b in range(B):
+        sc, si = kc[b].sort(stable=True)
+        lsh.fill(1, b, sc.contiguous(), si.int().contiguous())
+    G = H // Hkv
+    q = synth.randint(seed + 1, 0, NB, (B * H, L)).astype(np.int32)
+    q[1] = codes[0, 1 // G, :, 5]          # head 1 copies token 5's codes: count == L
+    q[2, :] = codes[0, 2 // G, :, 17]      # head 2: token 17 ...
+    q[2, 1:] = (q[2, 1:] + 1) % NB         # ... but only table 0 is guaranteed to collide
+    for l in range(L):                     # head 3 probes an EMPTY bucket in every table: nnz == 0
+        present = np.zeros(NB, bool)
+        present[codes[0, 3 // G, l]] = True
+        q[3, l] = int(np.flatnonzero(~present)[0])
+    runs = []
+    for rep in range(2):
+        qq = torch.from_numpy(q if rep == 0 else ((q + 3) % NB).astype(np.int32)).contiguous()
+        results = torch.zeros((B * H, M), dtype=torch.int32)
+        nnz = torch.zeros((B * H,), dtype=torch.int32)
+        lsh.batch_retrieve(1, qq, results, nnz)
+        nz = nnz.numpy()
+        runs.append((nz.copy(),
+                     np.concatenate([np.sort(results[h, :nz[h]].numpy()) for h in range(B * H)])))
+    out[name] = dict(meta=np.array([seed, K, L, H, Hkv, B, n, M], np.int64), q=q,
+                     nnz0=runs[0][0], sorted0=runs[0][1], nnz1=runs[1][0], sorted1=runs[1][1])
+    print(f"{name}: nnz {runs[0][0].tolist()} / {runs[1][0].tolist()}")
+
+
+def run_attn_edge(name, seed, ref_attn, out):
+    """attention_wrapper on explicit index lists: nnz = 0, 1, 15, 16, 17, 33 and a long head;
+    random `ind` = prefix of a permutation like library/sparse_attention/test_sparse.py:52-55."""
+    K, L, H, Hkv, B, n, M, D = 10, 150, 8, 2, 1, 512, 640, 128
+    keys, kns, vals, W, qb = case_inputs(seed, B, H, Hkv, n, D, K, L)
+    nnz_list = [0, 1, 15, 16, 17, 33, 200, 511]
+    ind = np.zeros((B * H, M), np.int32)
+    for h, z in enumerate(nnz_list):
+        perm = np.argsort(synth.u64(seed + 50 + h, n), kind="stable").astype(np.int32)
+        ind[h, :z] = perm[:z]
+    srv = ref_attn.SparseAttentionServer()
+    srv.alloc(1, H, Hkv, D, B, M)
+    srv.fill(0, 0, synth.to_torch_bf16(keys[0]), synth.to_torch_bf16(vals[0]),
+             torch.from_numpy(kns[0]))
+    q_t = synth.to_torch_bf16(qb)
+    qn = q_t.float().norm(p=2, dim=-1)
+    output = torch.zeros((B * H, D), dtype=torch.bfloat16)
+    mve = torch.zeros((2, B * H), dtype=torch.float32)
+    nnz = torch.tensor(nnz_list, dtype=torch.int32)
+    srv.attention_wrapper(0, K, L, output, mve, q_t, qn, torch.from_numpy(ind), nnz)
+    probs = srv.get_score().reshape(B * H, M)
+    out[name] = dict(meta=np.array([seed, K, L, H, Hkv, B, n, M, D], np.int64),
+                     nnz=np.array(nnz_list, np.int32), qnorm=qn.numpy().copy(),
+                     out_bits=output.view(torch.int16).numpy().view(np.uint16).copy(),
+                     mve=mve.numpy().copy(),
+                     probs=np.concatenate([probs[h, :z].numpy() for h, z in enumerate(nnz_list)]))
+    print(f"{name}: lse {mve[1].tolist()}")
+
+
+def cfg1_codes(seed, Hkv, L, n, NB):
+    return synth.randint(seed, 0, NB, (Hkv, L, n)).astype(np.int16)
+
+
+def run_cfg1_retrieve_sha(name, seed, ref_lsh, out):
+    """BASELINE cfg-1-shaped single layer (B=1, H=32, Hkv=8, n=97932, M=98304, K10 L150) with
+    uniformly random codes (as library/lsh/test.py:30,36); only SHA-256 of the sorted selected
+    ids + nnz is stored so the big case is pinned without a big file."""
+    K, L, H, Hkv, B, n, M = 10, 150, 32, 8, 1, 97932, 98304
+    NB = 1 << K
+    codes = cfg1_codes(seed, Hkv, L, n, NB)
+    order = np.argsort(codes, axis=-1, kind="stable").astype(np.int32)
+    sc = np.take_along_axis(codes, order, axis=-1)
+    lsh = ref_lsh.LSH()
+    lsh.alloc(K, L, 1, H, Hkv, B, M)
+    lsh.fill(0, 0, torch.from_numpy(sc), torch.from_numpy(order))
+    q = synth.randint(seed + 1, 0, NB, (B * H, L)).astype(np.int32)
+    results = torch.zeros((B * H, M), dtype=torch.int32)
+    nnz = torch.zeros((B * H,), dtype=torch.int32)
+    lsh.batch_retrieve(0, torch.from_numpy(q), results, nnz)
+    nz = nnz.numpy()
+    hsh = hashlib.sha256()
+    hsh.update(nz.tobytes())
+    for h in range(B * H):
+        hsh.update(np.sort(results[h, :nz[h]].numpy()).tobytes())
+    out[name] = dict(meta=np.array([seed, K, L, H, Hkv, B, n, M], np.int64), nnz=nz.copy(),
+                     sha256=np.frombuffer(hsh.digest(), np.uint8))
+    print(f"{name}: nnz mean {nz.mean():.1f}")
+
+
+def main():
+    ref_lsh, ref_attn = load_ref()
+    assert ref_uses_bf16_family(), "fixtures are generated with the __AVX512BF16__ build"
+    cases: dict = {}
+    run_qhash_only("qhash_r1_k10_l150", 11, 1, 128, 10, 150, cases)
+    run_qhash_only("qhash_r32_k10_l150", 12, 32, 128, 10, 150, cases)
+    run_qhash_only("qhash_r64_k11_l300", 13, 64, 128, 11, 300, cases)
+    run_qhash_only("qhash_r40_k8_l50", 14, 40, 128, 8, 50, cases)
+    run_qhash_only("qhash_r256_k10_l170", 15, 256, 128, 10, 170, cases)
+    run_lsh_edge("lsh_edge", 21, ref_lsh, cases)
+    run_attn_edge("attn_edge", 31, ref_attn, cases)
+    run_pipeline("lsh_small", 41, 2, 4, 2, 256, 300, 128, 4, 8, ref_lsh, ref_attn, cases)
+    run_pipeline("cfg0", 42, 1, 1, 1, 4096, 4288, 128, 10, 150, ref_lsh, ref_attn, cases)
+    run_pipeline("gqa_32h", 43, 1, 32, 8, 4096, 4288, 128, 10, 150, ref_lsh, ref_attn, cases)
+    run_pipeline("b2_k8_l60", 44, 2, 8, 2, 1500, 1600, 128, 8, 60, ref_lsh, ref_attn, cases)
+    run_cfg1_retrieve_sha("cfg1_retrieve_sha", 51, ref_lsh, cases)
+    for name, d in cases.items():
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print("wrote", len(cases), "fixtures to", HERE)
+
+
+if __name__ == "__main__":
+    main()
