@@ -1,0 +1,368 @@
+"""bench.py -- decode throughput of the LSH-sampled sparse attention path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1]
+
+A "step" is one decode token of the hot path: for every sparse layer of the model shape
+(30 of Llama-3.1-8B's 32), q SimHash -> L table probes + collision-count dedupe -> gathered
+sparse KV attention with importance-sampling correction (models/attnserver.py:264-300), on
+synthetic Q/K/V already resident in HBM.  Loop shape as examples/bench.py:47-56 (32 warm-up +
+128 timed steps by default).  One process per GPU; for N > 1 the driver launches this file under
+torch.distributed.run and every rank serves its own batch of requests (weak scaling, no
+collective inside the path; RCCL only for the barrier and the max-over-ranks time).
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying
+  roofline      the dominant kernel (attn_partial_kernel): algorithmic bytes per launch /
+                average dispatch duration from HIP events bound to the dispatches;
+  cpu_baseline  the reference's own AVX512 path (oracle/_ref, kind "reference") or the oracle
+                port (kind "port") timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs: the model shape fixes layers/H/Hkv/D; P is the prompt
+# length, n = P - 68 offloaded tokens, M the allocated rows.
+CONFIGS = {
+    # plumbing config: library/lsh + library/sparse_attention, 1 head, seq 4096
+    "cfg0": dict(model="synthetic-1head", layers=1, dense=(), H=1, Hkv=1, D=128, B=1, P=4096 + 68,
+                 M=4288, K=10, L=150),
+    "cfg1": dict(model="Llama-3.1-8B", layers=32, dense=(0, 16), H=32, Hkv=8, D=128, B=1, P=98000,
+                 M=98304, K=10, L=150),
+    "cfg2": dict(model="Llama-3.1-8B", layers=32, dense=(0, 16), H=32, Hkv=8, D=128, B=8, P=32768,
+                 M=32960, K=10, L=170),
+    # per-GPU share of cfg 3 (B=64 over 8 GPUs) -- the N-GPU weak-scaling unit
+    "cfg3": dict(model="Llama-3.1-8B", layers=32, dense=(0, 16), H=32, Hkv=8, D=128, B=8, P=32768,
+                 M=32960, K=10, L=150),
+    # per-GPU share of cfg 4 (70B TP=8: 1 kv head + 8 q heads per GPU)
+    "cfg4": dict(model="Llama-3.1-70B/TP8-shard", layers=80, dense=(0, 16, 32, 48, 64), H=8, Hkv=1,
+                 D=128, B=1, P=131072, M=131264, K=11, L=300),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--config", default="cfg1", choices=sorted(CONFIGS))
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=48)
+    ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--table-build", default="sort", choices=["sort", "counting"])
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------- CPU baseline worker
+
+def cpu_worker(path: str) -> None:
+    """Runs in a subprocess with OMP_* set by the parent: times batch_retrieve +
+    attention_wrapper of ONE sparse layer (same data as the GPU's first sparse layer)."""
+    z = np.load(path)
+    meta = {k: int(v) for k, v in zip(z["meta_keys"], z["meta_vals"])}
+    B, H, Hkv, D, M, K, L, n, steps = (meta[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "n", "steps"))
+    cores = len(os.sched_getaffinity(0))
+    BH = B * H
+    sorted_codes = torch.from_numpy(z["sorted_codes"])        # [B, Hkv, L, n] int16
+    sorted_ids = torch.from_numpy(z["sorted_ids"])            # int32
+    k = torch.from_numpy(z["k"]).view(torch.bfloat16)         # [B, Hkv, n, D]
+    v = torch.from_numpy(z["v"]).view(torch.bfloat16)
+    kn = torch.from_numpy(z["kn"])
+    qs = torch.from_numpy(z["q"]).view(torch.bfloat16)        # [NQ, BH, D]
+    codes = torch.from_numpy(z["qcodes"])                     # [NQ, BH, L] int32
+    kind = "port"
+    sys.path.insert(0, ROOT)
+    from oracle import build_ref
+
+    if build_ref.ref_available():
+        ref_lsh, ref_attn = build_ref.load_ref()
+        lsh, srv = ref_lsh.LSH(), ref_attn.SparseAttentionServer()
+        kind = "reference"
+    else:
+        import oracle
+
+        lsh, srv = oracle.LSH(nthreads=cores), oracle.SparseAttentionServer(nthreads=cores)
+    lsh.alloc(K, L, 1, H, Hkv, B, M)
+    srv.alloc(1, H, Hkv, D, B, M)
+    for b in range(B):
+        lsh.fill(0, b, sorted_codes[b].contiguous(), sorted_ids[b].contiguous())
+        srv.fill(0, b, k[b].contiguous(), v[b].contiguous(), kn[b].contiguous())
+    results = torch.zeros((BH, M), dtype=torch.int32)
+    nnz = torch.zeros((BH,), dtype=torch.int32)
+    out = torch.zeros((BH, D), dtype=torch.bfloat16)
+    mve = torch.zeros((2, BH), dtype=torch.float32)
+    NQ = qs.shape[0]
+    t_ret = t_att = 0.0
+    warm = max(2, steps // 8)
+    outs = []
+    for i in range(warm + steps):
+        q = qs[i % NQ].contiguous()
+        qn = q.float().norm(p=2, dim=-1)
+        c = codes[i % NQ].contiguous()
+        t0 = time.perf_counter()
+        lsh.batch_retrieve(0, c, results, nnz)
+        t1 = time.perf_counter()
+        srv.attention_wrapper(0, K, L, out, mve, q, qn, results, nnz)
+        t2 = time.perf_counter()
+        if i >= warm:
+            t_ret += t1 - t0
+            t_att += t2 - t1
+        if i < NQ:
+            outs.append((nnz.clone(), out.clone(), mve.clone()))
+    res = dict(kind=kind, cores=cores, t_retrieve_us=t_ret / steps * 1e6, t_attention_us=t_att / steps * 1e6,
+               steps=steps, nnz0=outs[0][0].tolist(),
+               out0=outs[0][1].float().flatten().tolist(), lse0=outs[0][2][1].tolist())
+    print("CPU_BASELINE_JSON " + json.dumps(res))
+
+
+def run_cpu_baseline(cfg, server, qs, steps):
+    """Dump the first sparse layer (tables, KV, queries) and time the CPU path on it."""
+    import magicpig_amd._lib as L
+
+    B, H, Hkv, D, M, K, Lt = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L"))
+    n = cfg["P"] - 68
+    layer = 0
+    bounds, table = server.lsh_retriever.get_tables(layer)
+    ids = table[:, :, :n].reshape(B, Hkv, Lt, n).contiguous()
+    # recover the sorted codes from the CSR bounds: code of position p = #buckets with start <= p ...
+    # simpler and exact: re-hash the stored (centred) keys and gather by the stored ids
+    kc = server.attn_server.get_key_cache(layer)[:, :, :n].contiguous()           # [B,Hkv,n,D]
+    vc = server.attn_server.get_value_cache(layer)[:, :, :n].contiguous()
+    kn = server.attn_server.get_key_norm(layer)[:, :, :n].contiguous()
+    codes = torch.stack([server.hasher.keys(kc[b]) for b in range(B)])            # [B,Hkv,L,n] int16
+    sorted_codes = torch.gather(codes, -1, ids.long())
+    NQ = qs.shape[0]
+    BH = B * H
+    qcodes = torch.stack([server.hasher.query(qs[i, layer].reshape(BH, D))[0] for i in range(NQ)])
+    path = os.path.join(tempfile.gettempdir(), f"mp_cpu_baseline_{os.getpid()}.npz")
+    keys = ["B", "H", "Hkv", "D", "M", "K", "L", "n", "steps"]
+    np.savez(path, meta_keys=np.array(keys), meta_vals=np.array([B, H, Hkv, D, M, K, Lt, n, steps]),
+             sorted_codes=sorted_codes.cpu().numpy(), sorted_ids=ids.cpu().numpy(),
+             k=kc.cpu().view(torch.int16).numpy(), v=vc.cpu().view(torch.int16).numpy(),
+             kn=kn.cpu().numpy(), q=qs[:, layer].reshape(NQ, BH, D).cpu().view(torch.int16).numpy(),
+             qcodes=qcodes.cpu().numpy())
+    cores = len(os.sched_getaffinity(0))
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_THREAD_LIMIT=str(cores),
+               OMP_PROC_BIND="close", MKL_NUM_THREADS=str(cores))
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path],
+                           env=env, capture_output=True, text=True, timeout=900)
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    for line in r.stdout.splitlines():
+        if line.startswith("CPU_BASELINE_JSON "):
+            return json.loads(line[len("CPU_BASELINE_JSON "):])
+    raise RuntimeError("cpu baseline worker failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
+
+
+# ---------------------------------------------------------------------------- main
+
+def main():
+    args = parse()
+    if args.cpu_baseline_worker:
+        cpu_worker(args.cpu_baseline_worker)
+        return
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import magicpig_amd as mp
+    import magicpig_amd._lib as L
+
+    cfg = CONFIGS[args.config]
+    B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
+    sparse_layers = [i for i in range(cfg["layers"]) if i not in cfg["dense"]]
+    NL = len(sparse_layers)
+    BH = B * H
+    n = P - 68
+
+    # identical hyperplanes on every rank (attnserver_dist.py:279 broadcasts them; here seeded)
+    server = mp.LSHSparseAttnServer(NL, H, Hkv, D, K=K, L=Lt, batch_size=B, max_length=M,
+                                    dense_layers=(), device=str(dev), seed=7,
+                                    table_build=args.table_build)
+    t_setup = time.time()
+    for li in range(NL):
+        for b in range(B):
+            gen = torch.Generator(device=dev).manual_seed(1000 * (rank + 1) + 37 * li + b)
+            kc = torch.randn((P, Hkv, D), device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+            vc = torch.randn((P, Hkv, D), device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+            server.fill(li, b, kc, vc, P)
+            server.build_table(li, b, P)
+            del kc, vc
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    NQ = 16
+    gen = torch.Generator(device=dev).manual_seed(2000 + rank)
+    qs = torch.randn((NQ, NL, B, H, 1, D), device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+    q_static = qs[0].clone()
+
+    def step():
+        for li in range(NL):
+            server.decode(q_static[li], li)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # stats pass (untimed): nnz and candidate counts actually observed on step 0
+    nnz_obs, cand_obs = [], []
+    for li in range(NL):
+        server.decode(q_static[li], li)
+        nnz_obs.append(server.nnz.clone())
+        if li < 4:
+            codes, _ = server.hasher.query(q_static[li].reshape(BH, D))
+            bounds, _ = server.lsh_retriever.get_tables(li)
+            g = torch.arange(BH, device=dev) // (H // Hkv)
+            be = bounds[g[:, None], torch.arange(Lt, device=dev)[None, :], codes.long()]   # [BH, L, 2]
+            cand_obs.append((be[..., 1] - be[..., 0]).sum(-1))
+    torch.cuda.synchronize()
+    nnz_all = torch.stack(nnz_obs).float()
+    nnz_mean = float(nnz_all.mean())
+    cand_mean = float(torch.stack(cand_obs).float().mean())
+
+    server.collect_nnz = False      # no statistics copies inside the timed region
+    graph = None
+    if not args.no_graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+
+    def run_steps(k0, count):
+        for i in range(count):
+            q_static.copy_(qs[(k0 + i) % NQ])    # this step's queries (produced by the QKV GEMM in a model)
+            if graph is not None:
+                graph.replay()
+            else:
+                step()
+
+    run_steps(0, args.warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    run_steps(args.warmup, args.steps)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    tokens_per_s = world * B * args.steps / dt
+    us_per_layer = ms_per_step * 1e3 / NL
+
+    # ---- roofline leg: per-dispatch HIP events on the dominant kernel, same workload, eager
+    prof_steps = min(args.steps, 16)
+    cap = prof_steps * NL
+    L.check(L.lib().mp_attn_profile_begin(server.attn_server._h, cap))
+    nnz_sum = 0.0
+    for i in range(prof_steps):
+        q_static.copy_(qs[i % NQ])
+        step()
+    buf = (C.c_float * cap)()
+    got = C.c_int(0)
+    L.check(L.lib().mp_attn_profile_end(server.attn_server._h, buf, cap, C.byref(got)))
+    torch.cuda.synchronize()
+    k_ms = np.array(buf[:got.value], dtype=np.float64)
+    k_us = float(k_ms.mean() * 1e3)
+    # algorithmic bytes of ONE attn_partial_kernel launch (DESIGN.md "Algorithmic bytes"):
+    #   per selected token: K row + V row (2*D*2) + key norm (4) + id (4);  per head: q (2*D) + partial
+    bytes_attn = nnz_mean * BH * (4 * D + 8) + BH * (2 * D) + (nnz_mean * BH / 256 + BH) * (D * 4 + 8)
+    achieved = bytes_attn / (k_us * 1e-6) / 1e9
+    # whole-layer algorithmic bytes, SURVEY.md 8(d)
+    bytes_layer = BH * (8 * Lt + 4 * cand_mean + 4 * nnz_mean + nnz_mean * (4 * D + 4) + 4 * nnz_mean
+                        + 2 * D + 8) + 2 * D * K * Lt + BH * (2 * D + 4 * Lt)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("config") == args.config:
+                traffic = tj.get("attn_partial_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "decode tokens/sec (LSH sparse-attention path), " + cfg["model"] +
+                  f" P={P} K{K}L{Lt}",
+        "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {cfg['model']} B={B} P={P} K={K} L={Lt}, "
+                               f"{NL} sparse layers/step, H={H} Hkv={Hkv} D={D}, KV+tables resident in HBM",
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world} (requests sharded)",
+                   "launch": "eager" if graph is None else "hipGraph"},
+        "sparse_attn_us_per_layer": us_per_layer,
+        "observed": {"nnz_per_head": nnz_mean, "candidates_per_head": cand_mean,
+                     "selected_fraction": nnz_mean / n, "setup_s": t_setup},
+        "roofline": {"bound": "hbm", "kernel": "attn_partial_kernel", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "bytes_per_launch": bytes_attn, "avg_launch_us": k_us,
+                     "launches_timed": int(got.value),
+                     "layer_bytes": bytes_layer, "layer_frac": bytes_layer / (us_per_layer * 1e-6) / 1e9 / HBM_PEAK_GBS},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cb = run_cpu_baseline(cfg, server, qs, args.cpu_steps)
+            t_layer = cb["t_retrieve_us"] + cb["t_attention_us"]
+            out["cpu_baseline"] = {
+                "value": B / (NL * t_layer * 1e-6), "unit": "tokens/s", "cores": cb["cores"],
+                "kind": cb["kind"],
+                "sample": f"1 of {NL} sparse layers x {cb['steps']} decode steps, same tables/KV/queries as "
+                          f"the GPU's first sparse layer; tokens/s = B / ({NL} x t_layer)",
+                "t_retrieve_us": cb["t_retrieve_us"], "t_attention_us": cb["t_attention_us"]}
+            # cross-check of the GPU result against the CPU path on the full-size layer
+            q_static.copy_(qs[0])
+            server.collect_nnz = True
+            o, lse = server.decode(q_static[0], 0)
+            torch.cuda.synchronize()
+            same_nnz = server.nnz.cpu().tolist() == cb["nnz0"]
+            dmax = float((o.float().flatten().cpu() - torch.tensor(cb["out0"])).abs().max())
+            out["cpu_baseline"]["gpu_matches"] = {"nnz_equal": same_nnz, "max_abs_out_diff": dmax}
+            out["speedup_vs_cpu"] = tokens_per_s / out["cpu_baseline"]["value"]
+        except Exception as e:  # the GPU number must still be reported
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
+                                   "sample": f"failed: {e!r}"[:300]}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

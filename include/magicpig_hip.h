@@ -1,0 +1,169 @@
+/*
+ * magicpig_hip.h -- C ABI of the MI355X-native (gfx950) implementation of MagicPIG's
+ * LSH-sampled sparse decode attention.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  Each entry point
+ * names the reference interface it replaces (paths relative to the MagicPIG repository).
+ * The reference exposes this path as two pybind11 classes (library/lsh/lsh.cc:316-326,
+ * library/sparse_attention/sparse_attention.cc:1243-1263) plus four lines of torch
+ * (models/attnserver.py:264-270); INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions
+ *   - every function returns MP_OK (0) or an MP_ERR_* code; mp_last_error() gives the text
+ *     (an ADDITION over the reference, which has no error reporting at all: lsh.cc asserts
+ *     are compiled out by -DNDEBUG and wrong shapes corrupt memory);
+ *   - `mem` says where caller buffers live: MP_MEM_HOST buffers are staged through HBM
+ *     (drop-in for the reference's CPU-tensor callers, models/attnserver.py:59-66);
+ *     MP_MEM_DEVICE buffers are used in place (fast path: codes, results and nnz never
+ *     leave HBM);
+ *   - `stream` is a hipStream_t (NULL = default stream); work is enqueued asynchronously for
+ *     MP_MEM_DEVICE arguments, synchronously completed for MP_MEM_HOST arguments;
+ *   - all state (tables, KV, norms, scratch) lives in HBM of the device that was current at
+ *     alloc time and is owned by the handle, as the reference objects own theirs
+ *     (lsh.cc:29-42, sparse_attention.cc:529-544);
+ *   - bf16 travels as uint16_t; h = b*H + head is the request-major query-head index,
+ *     g = h / (H/Hkv) its kv-head unit (lsh.cc:251, sparse_attention.cc:773);
+ *   - one call at a time per handle (the reference's scratch is per object too,
+ *     sparse_attention.cc:577).
+ */
+#ifndef MAGICPIG_HIP_H
+#define MAGICPIG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_OK 0
+#define MP_ERR_INVALID 1     /* bad argument (shape, range, null pointer) */
+#define MP_ERR_STATE 2       /* handle not allocated / already allocated */
+#define MP_ERR_HIP 3         /* HIP runtime error, text in mp_last_error() */
+#define MP_ERR_NOMEM 4       /* hipMalloc failed */
+#define MP_ERR_UNSUPPORTED 5 /* configuration outside the built kernels (e.g. head_dim) */
+#define MP_ERR_DATA 6        /* device-side validation failed (unsorted codes, id out of range) */
+
+#define MP_MEM_HOST 0
+#define MP_MEM_DEVICE 1
+
+#define MP_DTYPE_BF16 0
+#define MP_DTYPE_F32 1
+
+typedef struct mp_lsh mp_lsh_t;         /* replaces class LSH                    (library/lsh/lsh.h:14-43) */
+typedef struct mp_attn mp_attn_t;       /* replaces class SparseAttentionServer  (library/sparse_attention/sparse_attention.h:14-52) */
+typedef struct mp_simhash mp_simhash_t; /* replaces hash_func + binary_pack      (models/attnserver.py:55-57) */
+typedef void* mp_stream_t;              /* hipStream_t */
+
+/* ---------------------------------------------------------------- library */
+int mp_version(void);
+const char* mp_last_error(void);
+/* name of the gfx target the kernels were compiled for ("gfx950") */
+const char* mp_arch(void);
+
+/* ---------------------------------------------------------------- query / key SimHash
+ * Replaces models/attnserver.py:55-57 (hash_func [D, K*L] bf16, binary_pack) and :264-270
+ * (q / ||q|| -> matmul -> gt(0) -> K-bit pack).  MFMA kernel, codes bit-exact. */
+int mp_simhash_create(mp_simhash_t** out);
+int mp_simhash_destroy(mp_simhash_t* s);
+/* hash_func: bf16 [D, K*L] row-major, exactly the tensor of attnserver.py:55. */
+int mp_simhash_set_planes(mp_simhash_t* s, int D, int K, int L, const uint16_t* hash_func,
+                          int mem, mp_stream_t stream);
+/* q: bf16 [R, D]; codes: int32 [R, L] (== q_hashcode, attnserver.py:270);
+ * qnorm: f32 [R] or NULL (== pinned_query.float().norm(p=2, dim=-1), attnserver.py:300). */
+int mp_simhash_query(mp_simhash_t* s, const uint16_t* q, int R, int32_t* codes, float* qnorm,
+                     int mem, mp_stream_t stream);
+/* keys: bf16 [Hkv, n, D] (centred keys); codes: int16 [Hkv, L, n] (== hash_code_buffer[:, :, :n],
+ * attnserver.py:159-168: no normalisation, transposed, int16). */
+int mp_simhash_keys(mp_simhash_t* s, const uint16_t* keys, int Hkv, int64_t n, int16_t* codes,
+                    int mem, mp_stream_t stream);
+
+/* ---------------------------------------------------------------- LSH tables + retrieve */
+int mp_lsh_create(mp_lsh_t** out);                    /* LSH::LSH()            lsh.cc:25-27 */
+int mp_lsh_destroy(mp_lsh_t* h);                      /* LSH::~LSH()           lsh.cc:29-42 */
+/* LSH::alloc, lsh.cc:44-91 (same argument order). */
+int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_heads,
+                 int num_key_value_heads, int batch_size, int max_length);
+/* LSH::fill, lsh.cc:143-201.  sorted_codes int16 [Hkv, L, n], sorted_ids int32 [Hkv, L, n].
+ * Unlike the reference the slot need not be cleared first (rows are re-zeroed on device). */
+int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted_codes,
+                const int32_t* sorted_ids, int64_t n, int mem, mp_stream_t stream);
+/* Working replacement of the reference's half-written LSH::fastfill (lsh.cc:93-142): builds
+ * the tables on device from UNSORTED codes int16 [Hkv, L, n] (counting sort; ascending token
+ * ids inside every bucket). */
+int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes, int64_t n,
+                 int mem, mp_stream_t stream);
+/* LSH::batch_retrieve, lsh.cc:210-288.  query int32 [B*H, L]; results int32 [B*H, M] (first
+ * nnz[h] entries valid, ASCENDING token ids; the rest untouched); nnz int32 [B*H]. */
+int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32_t* results,
+                          int32_t* nnz, int mem, mp_stream_t stream);
+int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream);    /* LSH::clear            lsh.cc:293-306 */
+/* LSH::get_mask, lsh.cc:308-314: int8 [B, H, M] collision counters min(count, 2) of the LAST
+ * batch_retrieve call (recomputed on demand; the hot path keeps only bitmaps in LDS). */
+int mp_lsh_get_mask(mp_lsh_t* h, int8_t* mask, int mem, mp_stream_t stream);
+/* debug views (the reference declares get_table*, lsh.h:24-26, but never defines them):
+ * bounds int32 [B*Hkv, L, NB, 2] = (start, end) interleaved; table int32 [B*Hkv, L, M]. */
+int mp_lsh_get_tables(mp_lsh_t* h, int layer_id, void** bounds_dev, void** table_dev);
+
+/* ---------------------------------------------------------------- sparse attention */
+int mp_attn_create(mp_attn_t** out);                  /* sparse_attention.cc:519-527 */
+int mp_attn_destroy(mp_attn_t* h);                    /* sparse_attention.cc:529-544 */
+/* SparseAttentionServer::alloc, sparse_attention.cc:546-583 (same argument order). */
+int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads,
+                  int num_key_value_heads, int head_dim, int batch_size, int max_length);
+/* SparseAttentionServer::fill, sparse_attention.cc:601-627.  k, v bf16 [Hkv, n, D];
+ * kn f32 [Hkv, n]. */
+int mp_attn_fill(mp_attn_t* h, int layer_id, int request_id, const uint16_t* k,
+                 const uint16_t* v, const float* kn, int64_t n, int mem, mp_stream_t stream);
+/* SparseAttentionServer::attention_wrapper (and attention / scheduled_attention / *_bf16:
+ * one function on the GPU), sparse_attention.cc:629-986, 1039-1211.
+ *   output bf16 [B*H, D]; max_value_expsum f32 [2, B*H] (row 0 = max*log2e, row 1 = base-2
+ *   LSE); query [B*H, D] of `query_dtype` (MP_DTYPE_BF16 as the __AVX512BF16__ build reads
+ *   it, or MP_DTYPE_F32); query_norm f32 [B*H]; ind int32 [B*H, M]; nnz int32 [B*H]. */
+int mp_attn_sparse(mp_attn_t* h, int layer_id, int K, int L, uint16_t* output,
+                   float* max_value_expsum, const void* query, int query_dtype,
+                   const float* query_norm, const int32_t* ind, const int32_t* nnz, int mem,
+                   mp_stream_t stream);
+/* SparseAttentionServer::full_attention, sparse_attention.cc:988-1037: dense attention over
+ * rows [0, nnz[h]) (K == 0 baseline).  query f32 or bf16 [B*H, D]. */
+int mp_attn_full(mp_attn_t* h, int layer_id, uint16_t* output, float* max_value_expsum,
+                 const void* query, int query_dtype, const int32_t* nnz, int mem,
+                 mp_stream_t stream);
+int mp_attn_clear(mp_attn_t* h, mp_stream_t stream);  /* sparse_attention.cc:586-598 */
+/* get_key_cache / get_value_cache / get_key_norm, sparse_attention.cc:1213-1233: device
+ * pointers into the handle's storage.  K and V rows are INTERLEAVED per token in HBM
+ * ([B*Hkv, M, 2, D]); *row_stride_elems = 2*D, the V pointer is the K pointer + D elements. */
+int mp_attn_get_kv(mp_attn_t* h, int layer_id, void** key_dev, void** value_dev,
+                   int64_t* row_stride_elems);
+int mp_attn_get_key_norm(mp_attn_t* h, int layer_id, void** kn_dev);
+/* get_score, sparse_attention.cc:1235-1241: probabilities of the last sparse/full call,
+ * f32 [B, H, M], first nnz entries per head in `ind` order.  Normalised on demand. */
+int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream);
+
+/* Measurement hooks (no reference counterpart): time each launch of the dominant kernel of
+ * mp_attn_sparse / mp_attn_full / mp_decode_sparse_layer with HIP events bound to the dispatch
+ * on its launch stream.  begin() arms up to max_launches records; end() returns the durations
+ * in milliseconds (ms_out[cap]) of the launches made in between. */
+int mp_attn_profile_begin(mp_attn_t* h, int max_launches);
+int mp_attn_profile_end(mp_attn_t* h, float* ms_out, int cap, int* n_out);
+
+/* ---------------------------------------------------------------- one decode step of one layer
+ * The device-resident equivalent of LSHSparseAttnServer.decode lines 264-300
+ * (models/attnserver.py): q-hash -> batch_retrieve -> attention_wrapper with codes, results
+ * and nnz kept in HBM.  q bf16 [B*H, D] device; output bf16 [B*H, D] device;
+ * max_value_expsum f32 [2, B*H] device.  nnz_out (optional, device int32 [B*H]) receives the
+ * per-head selected-token counts for statistics. */
+int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int layer_id,
+                           const uint16_t* q, uint16_t* output, float* max_value_expsum,
+                           int32_t* nnz_out, mp_stream_t stream);
+
+/* ---------------------------------------------------------------- LSE merge
+ * Replaces flashinfer.merge_state as called at models/attnserver.py:308 (base-2 LSEs):
+ * v = (2^sa va + 2^sb vb) / 2^s, s = log2(2^sa + 2^sb).  va, vb, v bf16 [R, D]; sa, sb, s f32 [R]
+ * (s may be NULL).  Device pointers only. */
+int mp_merge_state(const uint16_t* va, const float* sa, const uint16_t* vb, const float* sb,
+                   int R, int D, uint16_t* v, float* s, mp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGICPIG_HIP_H */

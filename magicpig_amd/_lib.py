@@ -1,0 +1,146 @@
+"""ctypes loader of the gfx950 C-ABI library (include/magicpig_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails, this module raises.
+torch is imported first on purpose: the torch ROCm wheel bundles its own libamdhip64.so.7, and
+loading it first makes this library bind to the SAME HIP runtime instance (same SONAME), so
+torch tensors, torch streams and our kernels share one device context.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmagicpig_hip.so")
+
+MP_OK = 0
+MEM_HOST, MEM_DEVICE = 0, 1
+DTYPE_BF16, DTYPE_F32 = 0, 1
+
+_ERR_NAMES = {1: "MP_ERR_INVALID", 2: "MP_ERR_STATE", 3: "MP_ERR_HIP", 4: "MP_ERR_NOMEM",
+              5: "MP_ERR_UNSUPPORTED", 6: "MP_ERR_DATA"}
+
+
+class MagicPigError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{_ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m magicpig_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    L = C.CDLL(LIB_PATH)
+    i32, i64, p = C.c_int, C.c_int64, C.c_void_p
+    pp = C.POINTER(C.c_void_p)
+    sig = {
+        "mp_version": ([], i32),
+        "mp_last_error": ([], C.c_char_p),
+        "mp_arch": ([], C.c_char_p),
+        "mp_simhash_create": ([pp], i32),
+        "mp_simhash_destroy": ([p], i32),
+        "mp_simhash_set_planes": ([p, i32, i32, i32, p, i32, p], i32),
+        "mp_simhash_query": ([p, p, i32, p, p, i32, p], i32),
+        "mp_simhash_keys": ([p, p, i32, i64, p, i32, p], i32),
+        "mp_simhash_debug_acc": ([p, p], i32),
+        "mp_lsh_create": ([pp], i32),
+        "mp_lsh_destroy": ([p], i32),
+        "mp_lsh_alloc": ([p, i32, i32, i32, i32, i32, i32, i32], i32),
+        "mp_lsh_fill": ([p, i32, i32, p, p, i64, i32, p], i32),
+        "mp_lsh_build": ([p, i32, i32, p, i64, i32, p], i32),
+        "mp_lsh_batch_retrieve": ([p, i32, p, p, p, i32, p], i32),
+        "mp_lsh_clear": ([p, p], i32),
+        "mp_lsh_get_mask": ([p, p, i32, p], i32),
+        "mp_lsh_get_tables": ([p, i32, pp, pp], i32),
+        "mp_attn_create": ([pp], i32),
+        "mp_attn_destroy": ([p], i32),
+        "mp_attn_alloc": ([p, i32, i32, i32, i32, i32, i32], i32),
+        "mp_attn_fill": ([p, i32, i32, p, p, p, i64, i32, p], i32),
+        "mp_attn_sparse": ([p, i32, i32, i32, p, p, p, i32, p, p, p, i32, p], i32),
+        "mp_attn_full": ([p, i32, p, p, p, i32, p, i32, p], i32),
+        "mp_attn_clear": ([p, p], i32),
+        "mp_attn_profile_begin": ([p, i32], i32),
+        "mp_attn_profile_end": ([p, p, i32, C.POINTER(i32)], i32),
+        "mp_attn_get_kv": ([p, i32, pp, pp, C.POINTER(i64)], i32),
+        "mp_attn_get_key_norm": ([p, i32, pp], i32),
+        "mp_attn_get_score": ([p, pp, p], i32),
+        "mp_decode_sparse_layer": ([p, p, p, i32, p, p, p, p, p], i32),
+        "mp_merge_state": ([p, p, p, p, i32, i32, p, p, p], i32),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = the library does not export the ABI
+        fn.argtypes = args
+        fn.restype = res
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != MP_OK:
+        raise MagicPigError(rc, lib().mp_last_error().decode("utf-8", "replace"))
+
+
+# ---------------------------------------------------------------- tensor plumbing
+
+def mem_kind(t: torch.Tensor) -> int:
+    return MEM_DEVICE if t.is_cuda else MEM_HOST
+
+
+def ptr(t) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(None)
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream(ref: torch.Tensor | None = None) -> C.c_void_p:
+    """hipStream_t of torch's current stream (so torch events / graphs see our launches)."""
+    if torch.cuda.is_available():
+        dev = ref.device if (ref is not None and ref.is_cuda) else None
+        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return C.c_void_p(None)
+
+
+def expect(t: torch.Tensor, dtype, shape, name: str) -> torch.Tensor:
+    """The reference casts raw data_ptr() with no checks; we check instead."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        if t.numel() != int(torch.Size(shape).numel()):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def same_memory(*tensors) -> int:
+    kinds = {mem_kind(t) for t in tensors if t is not None}
+    if len(kinds) != 1:
+        raise ValueError("all tensors of one call must live on the same side (all CPU or all on the GPU)")
+    return kinds.pop()
+
+
+class DeviceView:
+    """Zero-copy torch view of handle-owned HBM through __cuda_array_interface__."""
+
+    def __init__(self, address: int, shape, typestr: str, strides=None):
+        self.__cuda_array_interface__ = {
+            "shape": tuple(int(s) for s in shape), "typestr": typestr, "data": (int(address), False),
+            "version": 3, "strides": None if strides is None else tuple(int(s) for s in strides),
+        }
+
+
+def device_tensor(address: int, shape, typestr: str, strides_bytes=None, device=None) -> torch.Tensor:
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    return torch.as_tensor(DeviceView(address, shape, typestr, strides_bytes), device=dev)

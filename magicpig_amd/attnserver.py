@@ -1,0 +1,138 @@
+"""`LSHSparseAttnServer` -- device-resident counterpart of the reference's attention server
+(models/attnserver.py:7-333) restricted to the LSH-sampled sparse path:
+
+    fill        (:112-175)  split sink / local / offload, centre keys, key norms, key SimHash,
+                            offloaded K/V/|k| -> HBM store
+    build_table (:178-193)  per-table sort of the key codes -> CSR tables in HBM
+    decode      (:264-300)  q SimHash -> batch_retrieve -> attention_wrapper, all in HBM
+    clear       (:314-331)
+
+The exact static-window attention and LSE merge that surround it in the reference (FlashInfer
+calls, :275-296, 302-308) are SURVEY.md 8(f) "next" rows; `merge` exposes the LSE merge kernel.
+Everything runs on one device; there is no PCIe hop and no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .lsh import LSH
+from .simhash import SimHash
+from .sparse_attention import SparseAttentionServer
+
+
+class LSHSparseAttnServer:
+    def __init__(self, num_layers: int, num_attention_heads: int, num_key_value_heads: int,
+                 head_dim: int, K: int = 10, L: int = 150, batch_size: int = 1,
+                 num_sink_tokens: int = 4, num_local_tokens: int = 64, max_length: int = 8192,
+                 dense_layers=(0, 16, 32, 48, 64), device: str = "cuda:0",
+                 dtype=torch.bfloat16, hash_func: torch.Tensor | None = None, seed: int = 7,
+                 table_build: str = "sort"):
+        """Mirrors models/attnserver.py:9-57 (the LlamaConfig is replaced by its four numbers).
+        hash_func: bf16 [head_dim, K*L]; the reference draws it unseeded (:55), here it is
+        seeded or supplied (e.g. broadcast from rank 0, attnserver_dist.py:279)."""
+        assert dtype == torch.bfloat16
+        self.K, self.L = K, L
+        self.num_layers = num_layers
+        self.batch_size = batch_size
+        self.num_attention_heads = num_attention_heads
+        self.num_key_value_heads = num_key_value_heads
+        self.head_dim = head_dim
+        self.max_length = max_length
+        self.dense_layers = tuple(dense_layers)
+        self.num_sink_tokens = num_sink_tokens
+        self.num_local_tokens = num_local_tokens
+        self.device = torch.device(device)
+        self.table_build = table_build
+        if hash_func is None:
+            gen = torch.Generator(device="cpu").manual_seed(seed)
+            hash_func = torch.randn((head_dim, K * L), generator=gen, dtype=torch.float32).to(dtype)
+        self.hash_func = hash_func.to(self.device).contiguous()
+        with torch.cuda.device(self.device):
+            self.hasher = SimHash(self.hash_func, K, L)
+            self.attn_server = SparseAttentionServer()
+            self.attn_server.alloc(num_layers, num_attention_heads, num_key_value_heads, head_dim,
+                                   batch_size, max_length)
+            self.lsh_retriever = LSH()
+            self.lsh_retriever.alloc(K, L, num_layers, num_attention_heads, num_key_value_heads,
+                                     batch_size, max_length)
+        BH = batch_size * num_attention_heads
+        self.avg_k = [torch.zeros(batch_size, num_key_value_heads, 1, head_dim, device=self.device,
+                                  dtype=dtype) for _ in range(num_layers)]
+        self.hash_code_buffer = None
+        self.output = torch.zeros((BH, head_dim), dtype=torch.bfloat16, device=self.device)
+        self.max_value_expsum = torch.zeros((2, BH), dtype=torch.float32, device=self.device)
+        self.nnz = torch.zeros((BH,), dtype=torch.int32, device=self.device)
+        self.collect_nnz = True     # copy the per-head selected counts into self.nnz every decode
+
+    # ------------------------------------------------------------------ prefill side
+    def fill(self, layer_idx: int, request_id: int, key_cache: torch.Tensor,
+             value_cache: torch.Tensor, seq_len: int) -> None:
+        """models/attnserver.py:112-175, sparse-layer branch.  key_cache / value_cache:
+        bf16 [seq_len, Hkv, D] on the device."""
+        s, l = self.num_sink_tokens, self.num_local_tokens
+        offload_key = key_cache[s:seq_len - l].transpose(0, 1).contiguous()
+        offload_value = value_cache[s:seq_len - l].transpose(0, 1).contiguous()
+        avg_k = offload_key.mean(dim=1, keepdim=True)
+        offload_key = offload_key - avg_k
+        kn = offload_key.norm(p=2, dim=-1).float()
+        self.avg_k[layer_idx][request_id] = avg_k
+        # key SimHash (:159-168) -> int16 [Hkv, L, n] on device
+        self.hash_code_buffer = self.hasher.keys(offload_key)
+        self.attn_server.fill(layer_idx, request_id, offload_key, offload_value, kn)
+
+    def build_table(self, layer_idx: int, request_id: int, seq_len: int) -> None:
+        """models/attnserver.py:178-193: sort the codes of every (kv head, table) row, then
+        LSH::fill.  table_build='sort' follows the reference (torch.sort on the device);
+        'counting' uses the device counting sort (LSH.fastfill)."""
+        codes = self.hash_code_buffer
+        if self.table_build == "counting":
+            self.lsh_retriever.fastfill(layer_idx, request_id, codes)
+        else:
+            sorted_values, sorted_indices = codes.sort(dim=-1)
+            self.lsh_retriever.fill(layer_idx, request_id, sorted_values.contiguous(),
+                                    sorted_indices.int().contiguous())
+        self.hash_code_buffer = None
+
+    # ------------------------------------------------------------------ decode side
+    def decode(self, query_states: torch.Tensor, layer_idx: int):
+        """models/attnserver.py:264-300 on one device: returns (cpu_hidden_states bf16 [B, H, D],
+        cpu_lse f32 [B, H]) -- the two operands the reference hands to flashinfer.merge_state
+        (:305-308) -- for the offloaded part of the context."""
+        BH = self.batch_size * self.num_attention_heads
+        q = query_states.reshape(BH, self.head_dim)
+        L.expect(q, torch.bfloat16, (BH, self.head_dim), "query_states")
+        L.check(L.lib().mp_decode_sparse_layer(
+            self.hasher._h, self.lsh_retriever._h, self.attn_server._h, layer_idx, L.ptr(q),
+            L.ptr(self.output), L.ptr(self.max_value_expsum),
+            L.ptr(self.nnz if self.collect_nnz else None), L.current_stream(q)))
+        out = self.output.view(self.batch_size, self.num_attention_heads, self.head_dim)
+        lse = self.max_value_expsum[1].view(self.batch_size, self.num_attention_heads)
+        return out, lse
+
+    @staticmethod
+    def merge(gpu_hidden_states, gpu_lse, cpu_hidden_states, cpu_lse):
+        """flashinfer.merge_state as used at models/attnserver.py:308 (base-2 LSEs)."""
+        D = gpu_hidden_states.shape[-1]
+        va = gpu_hidden_states.reshape(-1, D).contiguous()
+        vb = cpu_hidden_states.reshape(-1, D).contiguous()
+        sa = gpu_lse.reshape(-1).float().contiguous()
+        sb = cpu_lse.reshape(-1).float().contiguous()
+        R = va.shape[0]
+        v = torch.empty_like(va)
+        s = torch.empty_like(sa)
+        L.check(L.lib().mp_merge_state(L.ptr(va), L.ptr(sa), L.ptr(vb), L.ptr(sb), R, D, L.ptr(v),
+                                       L.ptr(s), L.current_stream(va)))
+        return v.view_as(gpu_hidden_states), s.view_as(gpu_lse)
+
+    def clear(self) -> None:
+        """models/attnserver.py:314-331."""
+        self.nnz.zero_()
+        self.max_value_expsum.zero_()
+        self.output.zero_()
+        for i in range(self.num_layers):
+            self.avg_k[i].zero_()
+        self.lsh_retriever.clear()
+        self.attn_server.clear()

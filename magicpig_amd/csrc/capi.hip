@@ -1,0 +1,723 @@
+// capi.hip -- the C ABI declared in include/magicpig_hip.h: handle state in HBM + launches.
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace mp {
+
+// ---- kernels' host launchers (simhash.hip, lsh.hip, attention.hip)
+int simhash_padded_cols(int K, int L);
+int simhash_supported(int D, int K);
+hipError_t launch_simhash_prepare(const uint16_t*, int, int, int, uint16_t*, float*, hipStream_t);
+hipError_t launch_simhash_query(const uint16_t*, const uint16_t*, const float*, int, int, int, int,
+                                int32_t*, float*, float*, hipStream_t);
+hipError_t launch_simhash_keys(const uint16_t*, const uint16_t*, const float*, int64_t, int, int,
+                               int, int16_t*, hipStream_t);
+size_t retrieve_lds_bytes(int64_t M, int L);
+hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int2*,
+                           int32_t*, int*, hipStream_t);
+hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int2*, int32_t*, int*,
+                            hipStream_t);
+hipError_t launch_lsh_retrieve(const int2*, const int32_t*, const int32_t*, int32_t*, int32_t*, int,
+                               int, int, int, int64_t, hipStream_t);
+hipError_t launch_lsh_mask(const int2*, const int32_t*, const int32_t*, int8_t*, int, int, int, int,
+                           int64_t, hipStream_t);
+int64_t attn_max_slices(int BH, int64_t M);
+int attn_supported_head_dim(int D);
+hipError_t launch_attn_partial(int, bool, bool, const uint16_t*, const float*, const void*,
+                               const float*, const int32_t*, const int32_t*, float*, float2*,
+                               float*, int, int, int64_t, int, int, int, hipStream_t, hipEvent_t,
+                               hipEvent_t);
+hipError_t launch_attn_merge(int, const float*, const float2*, const int32_t*, int, int64_t,
+                             uint16_t*, float*, float2*, hipStream_t);
+hipError_t launch_attn_normalize(float*, const int32_t*, const float2*, int, int64_t, hipStream_t);
+hipError_t launch_attn_fill(const uint16_t*, const uint16_t*, const float*, int, int64_t, int,
+                            int64_t, uint16_t*, float*, hipStream_t);
+hipError_t launch_merge_state(const uint16_t*, const float*, const uint16_t*, const float*, int,
+                              int, uint16_t*, float*, hipStream_t);
+
+// ---- error text (thread local)
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+// ---- small RAII device buffer for staging host arguments
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T>
+    T* as() { return reinterpret_cast<T*>(p); }
+};
+
+// Stage `bytes` of a caller buffer into HBM when it lives on the host; device buffers pass through.
+static int stage_in(const void* src, size_t bytes, int mem, DevBuf& buf, const void** out) {
+    if (mem == MP_MEM_DEVICE) {
+        *out = src;
+        return MP_OK;
+    }
+    MP_HIP_CHECK(buf.alloc(bytes));
+    MP_HIP_CHECK(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice));
+    *out = buf.p;
+    return MP_OK;
+}
+
+static int alloc_zero(void** p, size_t bytes) {
+    MP_HIP_CHECK(hipMalloc(p, bytes ? bytes : 1));
+    MP_HIP_CHECK(hipMemset(*p, 0, bytes));
+    return MP_OK;
+}
+
+}  // namespace mp
+
+using namespace mp;
+
+// =================================================================== handle state
+
+struct mp_simhash {
+    int D = 0, K = 0, L = 0, KLpad = 0;
+    uint16_t* Wt = nullptr;   // [KLpad][D]
+    float* wnorm = nullptr;   // [KLpad]
+    float* dbg_acc = nullptr; // optional debug sink (set by mp_simhash_debug_acc)
+};
+
+struct mp_lsh {
+    bool allocated = false;
+    int K = 0, L = 0, NB = 0, layers = 0, H = 0, Hkv = 0, B = 0, G = 0;
+    int64_t M = 0;
+    std::vector<int2*> bounds;     // per layer [B*Hkv][L][NB]
+    std::vector<int32_t*> table;   // per layer [B*Hkv][L][M]
+    int32_t* last_query = nullptr; // [BH][L] staging copy of host-side query codes
+    const int32_t* lastq = nullptr;// device codes of the last retrieve (for get_mask): last_query,
+                                   // `codes`, or the caller's own device buffer (valid until it changes)
+    int last_layer = -1;
+    int* err = nullptr;            // device-side validation flag
+    // device-resident step buffers of the fused decode path
+    int32_t* codes = nullptr;      // [BH][L]
+    int32_t* results = nullptr;    // [BH][M]
+    int32_t* nnz = nullptr;        // [BH]
+    float* qnorm = nullptr;        // [BH]
+};
+
+struct mp_attn {
+    bool allocated = false;
+    int layers = 0, H = 0, Hkv = 0, D = 0, B = 0, G = 0;
+    int64_t M = 0;
+    std::vector<uint16_t*> kv;     // per layer [B*Hkv][M][2][D]
+    std::vector<float*> kn;        // per layer [B*Hkv][M]
+    float* score = nullptr;        // [BH][M] logits -> probabilities on demand
+    float* part_o = nullptr;       // [max_slices][D]
+    float2* part_ml = nullptr;     // [max_slices]
+    float2* head_mz = nullptr;     // [BH] (max logit, Z) of the last call
+    int32_t* last_nnz = nullptr;   // [BH] staging copy of host-side nnz
+    const int32_t* lastz = nullptr;// device nnz of the last call (for get_score): last_nnz or the
+                                   // caller's own device buffer (valid until it changes)
+    int score_state = 0;           // 0 none, 1 logits, 2 probabilities
+    int grid = 1024;               // persistent grid of the partial kernel
+    // optional per-dispatch timing of the dominant kernel (mp_attn_profile_*)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;   // (begin, end) pairs
+    size_t prof_used = 0;
+};
+
+extern "C" {
+
+int mp_version(void) { return 1; }
+const char* mp_last_error(void) { return g_err.c_str(); }
+const char* mp_arch(void) { return "gfx950"; }
+
+// =================================================================== SimHash
+
+int mp_simhash_create(mp_simhash_t** out) {
+    MP_REQUIRE(out != nullptr, MP_ERR_INVALID, "mp_simhash_create: null out");
+    *out = new (std::nothrow) mp_simhash();
+    MP_REQUIRE(*out != nullptr, MP_ERR_NOMEM, "mp_simhash_create: out of host memory");
+    return MP_OK;
+}
+
+int mp_simhash_destroy(mp_simhash_t* s) {
+    if (!s) return MP_OK;
+    if (s->Wt) (void)hipFree(s->Wt);
+    if (s->wnorm) (void)hipFree(s->wnorm);
+    delete s;
+    return MP_OK;
+}
+
+int mp_simhash_set_planes(mp_simhash_t* s, int D, int K, int L, const uint16_t* hash_func, int mem,
+                          mp_stream_t stream) {
+    MP_REQUIRE(s && hash_func, MP_ERR_INVALID, "mp_simhash_set_planes: null argument");
+    MP_REQUIRE(L >= 1 && L < 65536, MP_ERR_INVALID, "mp_simhash_set_planes: L out of range");
+    MP_REQUIRE(simhash_supported(D, K), MP_ERR_UNSUPPORTED,
+               "mp_simhash_set_planes: need head_dim % 16 == 0, head_dim <= 256, 1 <= K <= 15");
+    hipStream_t st = (hipStream_t)stream;
+    if (s->Wt) { (void)hipFree(s->Wt); s->Wt = nullptr; }
+    if (s->wnorm) { (void)hipFree(s->wnorm); s->wnorm = nullptr; }
+    s->D = D; s->K = K; s->L = L;
+    s->KLpad = simhash_padded_cols(K, L);
+    MP_HIP_CHECK(hipMalloc((void**)&s->Wt, (size_t)s->KLpad * D * 2));
+    MP_HIP_CHECK(hipMalloc((void**)&s->wnorm, (size_t)s->KLpad * 4));
+    DevBuf tmp;
+    const void* W = nullptr;
+    int rc = stage_in(hash_func, (size_t)D * K * L * 2, mem, tmp, &W);
+    if (rc) return rc;
+    MP_HIP_CHECK(launch_simhash_prepare((const uint16_t*)W, D, K, L, s->Wt, s->wnorm, st));
+    MP_HIP_CHECK(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
+// test hook (not in the public header): route raw MFMA accumulators of the next query calls to
+// a device buffer f32 [R][K*L] so the guard band can be validated against an exact reference.
+int mp_simhash_debug_acc(mp_simhash_t* s, float* dev_buf) {
+    MP_REQUIRE(s, MP_ERR_INVALID, "mp_simhash_debug_acc: null handle");
+    s->dbg_acc = dev_buf;
+    return MP_OK;
+}
+
+int mp_simhash_query(mp_simhash_t* s, const uint16_t* q, int R, int32_t* codes, float* qnorm,
+                     int mem, mp_stream_t stream) {
+    MP_REQUIRE(s && s->Wt, MP_ERR_STATE, "mp_simhash_query: planes not set");
+    MP_REQUIRE(q && codes && R >= 1, MP_ERR_INVALID, "mp_simhash_query: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (mem == MP_MEM_DEVICE) {
+        MP_HIP_CHECK(launch_simhash_query(q, s->Wt, s->wnorm, R, s->D, s->K, s->L, codes, qnorm,
+                                          s->dbg_acc, st));
+        return MP_OK;
+    }
+    DevBuf dq, dc, dn;
+    MP_HIP_CHECK(dq.alloc((size_t)R * s->D * 2));
+    MP_HIP_CHECK(dc.alloc((size_t)R * s->L * 4));
+    MP_HIP_CHECK(dn.alloc((size_t)R * 4));
+    MP_HIP_CHECK(hipMemcpy(dq.p, q, (size_t)R * s->D * 2, hipMemcpyHostToDevice));
+    MP_HIP_CHECK(launch_simhash_query(dq.as<uint16_t>(), s->Wt, s->wnorm, R, s->D, s->K, s->L,
+                                      dc.as<int32_t>(), dn.as<float>(), s->dbg_acc, st));
+    MP_HIP_CHECK(hipStreamSynchronize(st));
+    MP_HIP_CHECK(hipMemcpy(codes, dc.p, (size_t)R * s->L * 4, hipMemcpyDeviceToHost));
+    if (qnorm) MP_HIP_CHECK(hipMemcpy(qnorm, dn.p, (size_t)R * 4, hipMemcpyDeviceToHost));
+    return MP_OK;
+}
+
+int mp_simhash_keys(mp_simhash_t* s, const uint16_t* keys, int Hkv, int64_t n, int16_t* codes,
+                    int mem, mp_stream_t stream) {
+    MP_REQUIRE(s && s->Wt, MP_ERR_STATE, "mp_simhash_keys: planes not set");
+    MP_REQUIRE(keys && codes && Hkv >= 1 && n >= 1, MP_ERR_INVALID, "mp_simhash_keys: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf dk, dc;
+    const uint16_t* kd = keys;
+    int16_t* cd = codes;
+    const size_t kb = (size_t)Hkv * n * s->D * 2, cb = (size_t)Hkv * s->L * n * 2;
+    if (mem == MP_MEM_HOST) {
+        MP_HIP_CHECK(dk.alloc(kb));
+        MP_HIP_CHECK(dc.alloc(cb));
+        MP_HIP_CHECK(hipMemcpy(dk.p, keys, kb, hipMemcpyHostToDevice));
+        kd = dk.as<uint16_t>();
+        cd = dc.as<int16_t>();
+    }
+    for (int i = 0; i < Hkv; ++i)
+        MP_HIP_CHECK(launch_simhash_keys(kd + (size_t)i * n * s->D, s->Wt, s->wnorm, n, s->D, s->K,
+                                         s->L, cd + (size_t)i * s->L * n, st));
+    if (mem == MP_MEM_HOST) {
+        MP_HIP_CHECK(hipStreamSynchronize(st));
+        MP_HIP_CHECK(hipMemcpy(codes, dc.p, cb, hipMemcpyDeviceToHost));
+    }
+    return MP_OK;
+}
+
+// =================================================================== LSH
+
+int mp_lsh_create(mp_lsh_t** out) {
+    MP_REQUIRE(out != nullptr, MP_ERR_INVALID, "mp_lsh_create: null out");
+    *out = new (std::nothrow) mp_lsh();
+    MP_REQUIRE(*out != nullptr, MP_ERR_NOMEM, "mp_lsh_create: out of host memory");
+    return MP_OK;
+}
+
+static void lsh_free(mp_lsh_t* h) {
+    for (auto p : h->bounds) if (p) (void)hipFree(p);
+    for (auto p : h->table) if (p) (void)hipFree(p);
+    h->bounds.clear();
+    h->table.clear();
+    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->last_query = nullptr; h->err = nullptr; h->codes = nullptr; h->results = nullptr;
+    h->nnz = nullptr; h->qnorm = nullptr;
+    h->allocated = false;
+}
+
+int mp_lsh_destroy(mp_lsh_t* h) {
+    if (!h) return MP_OK;
+    lsh_free(h);
+    delete h;
+    return MP_OK;
+}
+
+int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_heads,
+                 int num_key_value_heads, int batch_size, int max_length) {
+    MP_REQUIRE(h, MP_ERR_INVALID, "mp_lsh_alloc: null handle");
+    MP_REQUIRE(!h->allocated, MP_ERR_STATE, "mp_lsh_alloc: already allocated");
+    MP_REQUIRE(K >= 1 && K <= 15, MP_ERR_INVALID, "mp_lsh_alloc: K must be in [1, 15] (int16 codes)");
+    MP_REQUIRE(L >= 1 && L < 65536, MP_ERR_INVALID, "mp_lsh_alloc: L out of range");
+    MP_REQUIRE(num_layers >= 1 && batch_size >= 1 && num_key_value_heads >= 1 &&
+                   num_attention_heads >= num_key_value_heads &&
+                   num_attention_heads % num_key_value_heads == 0,
+               MP_ERR_INVALID, "mp_lsh_alloc: bad head/layer/batch counts");
+    MP_REQUIRE(max_length >= 1 && max_length <= (1 << 22), MP_ERR_INVALID,
+               "mp_lsh_alloc: max_length must be in [1, 2^22]");
+    MP_REQUIRE(retrieve_lds_bytes(max_length, L) <= 160 * 1024, MP_ERR_UNSUPPORTED,
+               "mp_lsh_alloc: collision bitmaps for max_length do not fit the 160 KiB LDS");
+    h->K = K; h->L = L; h->NB = 1 << K; h->layers = num_layers;
+    h->H = num_attention_heads; h->Hkv = num_key_value_heads; h->B = batch_size;
+    h->G = h->H / h->Hkv; h->M = max_length;
+    const size_t groups = (size_t)h->B * h->Hkv, BH = (size_t)h->B * h->H;
+    int rc = MP_OK;
+    for (int i = 0; i < num_layers && rc == MP_OK; ++i) {
+        void* b = nullptr; void* t = nullptr;
+        rc = alloc_zero(&b, groups * L * h->NB * sizeof(int2));
+        if (rc == MP_OK) rc = alloc_zero(&t, groups * L * (size_t)h->M * 4);
+        h->bounds.push_back((int2*)b);
+        h->table.push_back((int32_t*)t);
+    }
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->last_query, BH * L * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->err, 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->codes, BH * L * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->results, BH * (size_t)h->M * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->nnz, BH * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->qnorm, BH * 4);
+    if (rc != MP_OK) { lsh_free(h); return rc; }
+    h->allocated = true;
+    return MP_OK;
+}
+
+static int lsh_check_slot(mp_lsh_t* h, int layer_id, int request_id, int64_t n, const char* who) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, std::string(who) + ": not allocated");
+    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, std::string(who) + ": layer_id out of range");
+    MP_REQUIRE(request_id >= 0 && request_id < h->B, MP_ERR_INVALID, std::string(who) + ": request_id out of range");
+    MP_REQUIRE(n >= 0 && n <= h->M, MP_ERR_INVALID, std::string(who) + ": sequence longer than max_length");
+    return MP_OK;
+}
+
+static int lsh_read_err(mp_lsh_t* h, hipStream_t st, const char* who) {
+    int flag = 0;
+    MP_HIP_CHECK(hipMemcpyAsync(&flag, h->err, 4, hipMemcpyDeviceToHost, st));
+    MP_HIP_CHECK(hipStreamSynchronize(st));
+    if (flag) {
+        MP_HIP_CHECK(hipMemsetAsync(h->err, 0, 4, st));
+        return fail(MP_ERR_DATA, std::string(who) + ": device-side validation failed (codes not sorted / "
+                                                    "out of [0, 2^K) or token id out of [0, max_length))");
+    }
+    return MP_OK;
+}
+
+int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted_codes,
+                const int32_t* sorted_ids, int64_t n, int mem, mp_stream_t stream) {
+    int rc = lsh_check_slot(h, layer_id, request_id, n, "mp_lsh_fill");
+    if (rc) return rc;
+    MP_REQUIRE(sorted_codes && sorted_ids, MP_ERR_INVALID, "mp_lsh_fill: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = h->Hkv * h->L;
+    DevBuf dc, di;
+    const void *c = nullptr, *i = nullptr;
+    rc = stage_in(sorted_codes, (size_t)rows * n * 2, mem, dc, &c);
+    if (rc) return rc;
+    rc = stage_in(sorted_ids, (size_t)rows * n * 4, mem, di, &i);
+    if (rc) return rc;
+    int2* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB;
+    int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
+    MP_HIP_CHECK(launch_lsh_fill((const int16_t*)c, (const int32_t*)i, rows, n, h->NB, h->M, b, t,
+                                 h->err, st));
+    return lsh_read_err(h, st, "mp_lsh_fill");
+}
+
+int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes, int64_t n,
+                 int mem, mp_stream_t stream) {
+    int rc = lsh_check_slot(h, layer_id, request_id, n, "mp_lsh_build");
+    if (rc) return rc;
+    MP_REQUIRE(codes, MP_ERR_INVALID, "mp_lsh_build: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = h->Hkv * h->L;
+    DevBuf dc;
+    const void* c = nullptr;
+    rc = stage_in(codes, (size_t)rows * n * 2, mem, dc, &c);
+    if (rc) return rc;
+    int2* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB;
+    int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
+    MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, b, t, h->err, st));
+    return lsh_read_err(h, st, "mp_lsh_build");
+}
+
+int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32_t* results,
+                          int32_t* nnz, int mem, mp_stream_t stream) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_lsh_batch_retrieve: not allocated");
+    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_lsh_batch_retrieve: layer_id out of range");
+    MP_REQUIRE(query && results && nnz, MP_ERR_INVALID, "mp_lsh_batch_retrieve: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int BH = h->B * h->H;
+    const size_t qb = (size_t)BH * h->L * 4;
+    if (mem == MP_MEM_DEVICE) {
+        h->lastq = query;
+        h->last_layer = layer_id;
+        MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], query, results,
+                                         nnz, BH, h->G, h->L, h->NB, h->M, st));
+        return MP_OK;
+    }
+    // host callers (models/attnserver.py:299 passes pinned CPU tensors): stage through the
+    // handle's step buffers; only the first nnz[h] entries of each row are copied back.
+    MP_HIP_CHECK(hipMemcpy(h->last_query, query, qb, hipMemcpyHostToDevice));
+    h->lastq = h->last_query;
+    h->last_layer = layer_id;
+    MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], h->last_query,
+                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, st));
+    MP_HIP_CHECK(hipStreamSynchronize(st));
+    MP_HIP_CHECK(hipMemcpy(nnz, h->nnz, (size_t)BH * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < BH; ++i)
+        if (nnz[i] > 0)
+            MP_HIP_CHECK(hipMemcpy(results + (size_t)i * h->M, h->results + (size_t)i * h->M,
+                                   (size_t)nnz[i] * 4, hipMemcpyDeviceToHost));
+    return MP_OK;
+}
+
+int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_lsh_clear: not allocated");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t groups = (size_t)h->B * h->Hkv;
+    for (int i = 0; i < h->layers; ++i) {
+        MP_HIP_CHECK(hipMemsetAsync(h->bounds[i], 0, groups * h->L * h->NB * sizeof(int2), st));
+        MP_HIP_CHECK(hipMemsetAsync(h->table[i], 0, groups * h->L * (size_t)h->M * 4, st));
+    }
+    h->last_layer = -1;
+    return MP_OK;
+}
+
+int mp_lsh_get_mask(mp_lsh_t* h, int8_t* mask, int mem, mp_stream_t stream) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_lsh_get_mask: not allocated");
+    MP_REQUIRE(mask, MP_ERR_INVALID, "mp_lsh_get_mask: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int BH = h->B * h->H;
+    const size_t bytes = (size_t)BH * h->M;
+    if (h->last_layer < 0) {  // no retrieve since alloc/clear: the reference's mask is all zero
+        if (mem == MP_MEM_DEVICE) MP_HIP_CHECK(hipMemsetAsync(mask, 0, bytes, st));
+        else memset(mask, 0, bytes);
+        return MP_OK;
+    }
+    DevBuf tmp;
+    int8_t* d = mask;
+    if (mem == MP_MEM_HOST) {
+        MP_HIP_CHECK(tmp.alloc(bytes));
+        d = tmp.as<int8_t>();
+    }
+    MP_HIP_CHECK(launch_lsh_mask(h->bounds[h->last_layer], h->table[h->last_layer], h->lastq,
+                                 d, BH, h->G, h->L, h->NB, h->M, st));
+    if (mem == MP_MEM_HOST) {
+        MP_HIP_CHECK(hipStreamSynchronize(st));
+        MP_HIP_CHECK(hipMemcpy(mask, d, bytes, hipMemcpyDeviceToHost));
+    }
+    return MP_OK;
+}
+
+int mp_lsh_get_tables(mp_lsh_t* h, int layer_id, void** bounds_dev, void** table_dev) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_lsh_get_tables: not allocated");
+    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_lsh_get_tables: layer_id out of range");
+    if (bounds_dev) *bounds_dev = h->bounds[layer_id];
+    if (table_dev) *table_dev = h->table[layer_id];
+    return MP_OK;
+}
+
+// =================================================================== sparse attention
+
+int mp_attn_create(mp_attn_t** out) {
+    MP_REQUIRE(out != nullptr, MP_ERR_INVALID, "mp_attn_create: null out");
+    *out = new (std::nothrow) mp_attn();
+    MP_REQUIRE(*out != nullptr, MP_ERR_NOMEM, "mp_attn_create: out of host memory");
+    return MP_OK;
+}
+
+static void attn_free(mp_attn_t* h) {
+    for (auto p : h->kv) if (p) (void)hipFree(p);
+    for (auto p : h->kn) if (p) (void)hipFree(p);
+    h->kv.clear();
+    h->kn.clear();
+    for (auto e : h->prof_ev) (void)hipEventDestroy(e);
+    h->prof_ev.clear();
+    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->score = nullptr; h->part_o = nullptr; h->part_ml = nullptr; h->head_mz = nullptr;
+    h->last_nnz = nullptr;
+    h->allocated = false;
+}
+
+int mp_attn_destroy(mp_attn_t* h) {
+    if (!h) return MP_OK;
+    attn_free(h);
+    delete h;
+    return MP_OK;
+}
+
+int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num_key_value_heads,
+                  int head_dim, int batch_size, int max_length) {
+    MP_REQUIRE(h, MP_ERR_INVALID, "mp_attn_alloc: null handle");
+    MP_REQUIRE(!h->allocated, MP_ERR_STATE, "mp_attn_alloc: already allocated");
+    MP_REQUIRE(attn_supported_head_dim(head_dim), MP_ERR_UNSUPPORTED,
+               "mp_attn_alloc: head_dim must be 64 or 128");
+    MP_REQUIRE(num_layers >= 1 && batch_size >= 1 && num_key_value_heads >= 1 &&
+                   num_attention_heads >= num_key_value_heads &&
+                   num_attention_heads % num_key_value_heads == 0 && max_length >= 1,
+               MP_ERR_INVALID, "mp_attn_alloc: bad head/layer/batch counts");
+    MP_REQUIRE((int64_t)batch_size * num_attention_heads <= 16384, MP_ERR_UNSUPPORTED,
+               "mp_attn_alloc: more than 16384 query heads per call");
+    h->layers = num_layers; h->H = num_attention_heads; h->Hkv = num_key_value_heads;
+    h->D = head_dim; h->B = batch_size; h->G = h->H / h->Hkv; h->M = max_length;
+    const size_t groups = (size_t)h->B * h->Hkv, BH = (size_t)h->B * h->H;
+    int rc = MP_OK;
+    for (int i = 0; i < num_layers && rc == MP_OK; ++i) {
+        void* a = nullptr; void* b = nullptr;
+        rc = alloc_zero(&a, groups * (size_t)h->M * 2 * h->D * 2);
+        if (rc == MP_OK) rc = alloc_zero(&b, groups * (size_t)h->M * 4);
+        h->kv.push_back((uint16_t*)a);
+        h->kn.push_back((float*)b);
+    }
+    const size_t ms = (size_t)attn_max_slices((int)BH, h->M);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->score, BH * (size_t)h->M * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->part_o, ms * h->D * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->part_ml, ms * sizeof(float2));
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->head_mz, BH * sizeof(float2));
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->last_nnz, BH * 4);
+    if (rc != MP_OK) { attn_free(h); return rc; }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        h->grid = prop.multiProcessorCount * 4;
+    h->allocated = true;
+    return MP_OK;
+}
+
+int mp_attn_fill(mp_attn_t* h, int layer_id, int request_id, const uint16_t* k, const uint16_t* v,
+                 const float* kn, int64_t n, int mem, mp_stream_t stream) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_fill: not allocated");
+    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_attn_fill: layer_id out of range");
+    MP_REQUIRE(request_id >= 0 && request_id < h->B, MP_ERR_INVALID, "mp_attn_fill: request_id out of range");
+    MP_REQUIRE(n >= 0 && n <= h->M, MP_ERR_INVALID, "mp_attn_fill: sequence longer than max_length");
+    MP_REQUIRE(k && v && kn, MP_ERR_INVALID, "mp_attn_fill: null argument");
+    if (n == 0) return MP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf dk, dv, dn;
+    const void *kd, *vd, *nd;
+    const size_t eb = (size_t)h->Hkv * n * h->D * 2;
+    int rc = stage_in(k, eb, mem, dk, &kd);
+    if (rc == MP_OK) rc = stage_in(v, eb, mem, dv, &vd);
+    if (rc == MP_OK) rc = stage_in(kn, (size_t)h->Hkv * n * 4, mem, dn, &nd);
+    if (rc) return rc;
+    uint16_t* kv = h->kv[layer_id] + (size_t)request_id * h->Hkv * h->M * 2 * h->D;
+    float* knd = h->kn[layer_id] + (size_t)request_id * h->Hkv * h->M;
+    MP_HIP_CHECK(launch_attn_fill((const uint16_t*)kd, (const uint16_t*)vd, (const float*)nd, h->Hkv,
+                                  n, h->D, h->M, kv, knd, st));
+    if (mem == MP_MEM_HOST) MP_HIP_CHECK(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
+// shared by sparse / full / the fused decode entry; every pointer is a device pointer here
+static int attn_run(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint16_t* output,
+                    float* mve, const void* query, int query_dtype, const float* qn,
+                    const int32_t* ind, const int32_t* nnz, hipStream_t st) {
+    const int BH = h->B * h->H;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (h->prof_on && h->prof_used + 2 <= h->prof_ev.size()) {
+        ev0 = h->prof_ev[h->prof_used];
+        ev1 = h->prof_ev[h->prof_used + 1];
+        h->prof_used += 2;
+    }
+    MP_HIP_CHECK(launch_attn_partial(h->D, dense, query_dtype == MP_DTYPE_BF16, h->kv[layer_id],
+                                     h->kn[layer_id], query, qn, ind, nnz, h->part_o, h->part_ml,
+                                     h->score, BH, h->G, h->M, K, L, h->grid, st, ev0, ev1));
+    MP_HIP_CHECK(launch_attn_merge(h->D, h->part_o, h->part_ml, nnz, BH, h->M, output, mve,
+                                   h->head_mz, st));
+    h->lastz = nnz;
+    h->score_state = 1;
+    return MP_OK;
+}
+
+static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint16_t* output,
+                      float* mve, const void* query, int query_dtype, const float* qn,
+                      const int32_t* ind, const int32_t* nnz, int mem, hipStream_t st,
+                      const char* who) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, std::string(who) + ": not allocated");
+    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, std::string(who) + ": layer_id out of range");
+    MP_REQUIRE(output && mve && query && nnz && (dense || (qn && ind)), MP_ERR_INVALID,
+               std::string(who) + ": null argument");
+    MP_REQUIRE(query_dtype == MP_DTYPE_BF16 || query_dtype == MP_DTYPE_F32, MP_ERR_INVALID,
+               std::string(who) + ": query dtype must be bf16 or f32");
+    MP_REQUIRE(dense || (K >= 1 && L >= 2), MP_ERR_INVALID, std::string(who) + ": need K >= 1, L >= 2");
+    const int BH = h->B * h->H;
+    if (mem == MP_MEM_DEVICE)
+        return attn_run(h, layer_id, dense, K, L, output, mve, query, query_dtype, qn, ind, nnz, st);
+    DevBuf dout, dmve, dq, dqn, dind;
+    const size_t qbytes = (size_t)BH * h->D * (query_dtype == MP_DTYPE_BF16 ? 2 : 4);
+    MP_HIP_CHECK(dout.alloc((size_t)BH * h->D * 2));
+    MP_HIP_CHECK(dmve.alloc((size_t)2 * BH * 4));
+    const void *qd, *qnd = nullptr, *indd = nullptr, *nnzd;
+    int rc = stage_in(query, qbytes, mem, dq, &qd);
+    if (rc == MP_OK) {   // nnz must outlive this call for get_score: stage into the handle
+        MP_HIP_CHECK(hipMemcpy(h->last_nnz, nnz, (size_t)BH * 4, hipMemcpyHostToDevice));
+        nnzd = h->last_nnz;
+    }
+    if (!dense && rc == MP_OK) rc = stage_in(qn, (size_t)BH * 4, mem, dqn, &qnd);
+    if (!dense && rc == MP_OK) {
+        // only the first nnz[h] entries of each row are meaningful: stage just those
+        MP_HIP_CHECK(dind.alloc((size_t)BH * h->M * 4));
+        for (int i = 0; i < BH; ++i) {
+            int64_t z = nnz[i];
+            if (z > h->M) z = h->M;
+            if (z > 0)
+                MP_HIP_CHECK(hipMemcpy(dind.as<int32_t>() + (size_t)i * h->M, ind + (size_t)i * h->M,
+                                       (size_t)z * 4, hipMemcpyHostToDevice));
+        }
+        indd = dind.p;
+    }
+    if (rc) return rc;
+    rc = attn_run(h, layer_id, dense, K, L, dout.as<uint16_t>(), dmve.as<float>(), qd, query_dtype,
+                  (const float*)qnd, (const int32_t*)indd, (const int32_t*)nnzd, st);
+    if (rc) return rc;
+    MP_HIP_CHECK(hipStreamSynchronize(st));
+    MP_HIP_CHECK(hipMemcpy(output, dout.p, (size_t)BH * h->D * 2, hipMemcpyDeviceToHost));
+    MP_HIP_CHECK(hipMemcpy(mve, dmve.p, (size_t)2 * BH * 4, hipMemcpyDeviceToHost));
+    return MP_OK;
+}
+
+int mp_attn_sparse(mp_attn_t* h, int layer_id, int K, int L, uint16_t* output,
+                   float* max_value_expsum, const void* query, int query_dtype,
+                   const float* query_norm, const int32_t* ind, const int32_t* nnz, int mem,
+                   mp_stream_t stream) {
+    return attn_entry(h, layer_id, false, K, L, output, max_value_expsum, query, query_dtype,
+                      query_norm, ind, nnz, mem, (hipStream_t)stream, "mp_attn_sparse");
+}
+
+int mp_attn_full(mp_attn_t* h, int layer_id, uint16_t* output, float* max_value_expsum,
+                 const void* query, int query_dtype, const int32_t* nnz, int mem,
+                 mp_stream_t stream) {
+    return attn_entry(h, layer_id, true, 0, 0, output, max_value_expsum, query, query_dtype, nullptr,
+                      nullptr, nnz, mem, (hipStream_t)stream, "mp_attn_full");
+}
+
+int mp_attn_clear(mp_attn_t* h, mp_stream_t stream) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_clear: not allocated");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t groups = (size_t)h->B * h->Hkv, BH = (size_t)h->B * h->H;
+    for (int i = 0; i < h->layers; ++i) {
+        MP_HIP_CHECK(hipMemsetAsync(h->kv[i], 0, groups * (size_t)h->M * 2 * h->D * 2, st));
+        MP_HIP_CHECK(hipMemsetAsync(h->kn[i], 0, groups * (size_t)h->M * 4, st));
+    }
+    MP_HIP_CHECK(hipMemsetAsync(h->score, 0, BH * (size_t)h->M * 4, st));
+    h->score_state = 0;
+    return MP_OK;
+}
+
+// Measurement hooks (bench.py roofline leg; not part of the reference's interface): time every
+// launch of the dominant kernel (attn_partial_kernel) with HIP events bound to the dispatch
+// itself (hipExtLaunchKernel begin/end events on the launch stream).
+int mp_attn_profile_begin(mp_attn_t* h, int max_launches) {
+    MP_REQUIRE(h && h->allocated && max_launches > 0, MP_ERR_INVALID, "mp_attn_profile_begin: bad argument");
+    while (h->prof_ev.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        MP_HIP_CHECK(hipEventCreate(&e));
+        h->prof_ev.push_back(e);
+    }
+    h->prof_used = 0;
+    h->prof_on = true;
+    return MP_OK;
+}
+
+int mp_attn_profile_end(mp_attn_t* h, float* ms_out, int cap, int* n_out) {
+    MP_REQUIRE(h && ms_out && n_out, MP_ERR_INVALID, "mp_attn_profile_end: bad argument");
+    h->prof_on = false;
+    int n = 0;
+    for (size_t i = 0; i + 1 < h->prof_used && n < cap; i += 2) {
+        MP_HIP_CHECK(hipEventSynchronize(h->prof_ev[i + 1]));
+        float ms = 0.f;
+        MP_HIP_CHECK(hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
+        ms_out[n++] = ms;
+    }
+    *n_out = n;
+    h->prof_used = 0;
+    return MP_OK;
+}
+
+int mp_attn_get_kv(mp_attn_t* h, int layer_id, void** key_dev, void** value_dev,
+                   int64_t* row_stride_elems) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_get_kv: not allocated");
+    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_attn_get_kv: layer_id out of range");
+    if (key_dev) *key_dev = h->kv[layer_id];
+    if (value_dev) *value_dev = h->kv[layer_id] + h->D;
+    if (row_stride_elems) *row_stride_elems = 2 * (int64_t)h->D;
+    return MP_OK;
+}
+
+int mp_attn_get_key_norm(mp_attn_t* h, int layer_id, void** kn_dev) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_get_key_norm: not allocated");
+    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_attn_get_key_norm: layer_id out of range");
+    if (kn_dev) *kn_dev = h->kn[layer_id];
+    return MP_OK;
+}
+
+int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_get_score: not allocated");
+    MP_REQUIRE(score_dev, MP_ERR_INVALID, "mp_attn_get_score: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (h->score_state == 1) {
+        MP_HIP_CHECK(launch_attn_normalize(h->score, h->lastz, h->head_mz, h->B * h->H, h->M, st));
+        h->score_state = 2;
+    }
+    *score_dev = h->score;
+    return MP_OK;
+}
+
+// =================================================================== fused decode step
+
+int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int layer_id,
+                           const uint16_t* q, uint16_t* output, float* max_value_expsum,
+                           int32_t* nnz_out, mp_stream_t stream) {
+    MP_REQUIRE(s && s->Wt, MP_ERR_STATE, "mp_decode_sparse_layer: SimHash planes not set");
+    MP_REQUIRE(lsh && lsh->allocated && attn && attn->allocated, MP_ERR_STATE,
+               "mp_decode_sparse_layer: handles not allocated");
+    MP_REQUIRE(q && output && max_value_expsum, MP_ERR_INVALID, "mp_decode_sparse_layer: null argument");
+    MP_REQUIRE(lsh->B == attn->B && lsh->H == attn->H && lsh->Hkv == attn->Hkv && lsh->M == attn->M &&
+                   s->K == lsh->K && s->L == lsh->L && s->D == attn->D,
+               MP_ERR_INVALID, "mp_decode_sparse_layer: handles disagree on B/H/Hkv/M/K/L/D");
+    MP_REQUIRE(layer_id >= 0 && layer_id < lsh->layers && layer_id < attn->layers, MP_ERR_INVALID,
+               "mp_decode_sparse_layer: layer_id out of range");
+    hipStream_t st = (hipStream_t)stream;
+    const int BH = lsh->B * lsh->H;
+    // a-1: models/attnserver.py:264-270
+    MP_HIP_CHECK(launch_simhash_query(q, s->Wt, s->wnorm, BH, s->D, s->K, s->L, lsh->codes,
+                                      lsh->qnorm, nullptr, st));
+    // a-2: models/attnserver.py:299
+    MP_HIP_CHECK(launch_lsh_retrieve(lsh->bounds[layer_id], lsh->table[layer_id], lsh->codes,
+                                     lsh->results, lsh->nnz, BH, lsh->G, lsh->L, lsh->NB, lsh->M, st));
+    // a-7..a-12: models/attnserver.py:300
+    lsh->lastq = lsh->codes;
+    lsh->last_layer = layer_id;
+    int rc = attn_run(attn, layer_id, false, s->K, s->L, output, max_value_expsum, q, MP_DTYPE_BF16,
+                      lsh->qnorm, lsh->results, lsh->nnz, st);
+    if (rc) return rc;
+    if (nnz_out)
+        MP_HIP_CHECK(hipMemcpyAsync(nnz_out, lsh->nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));
+    return MP_OK;
+}
+
+// =================================================================== LSE merge
+
+int mp_merge_state(const uint16_t* va, const float* sa, const uint16_t* vb, const float* sb, int R,
+                   int D, uint16_t* v, float* s, mp_stream_t stream) {
+    MP_REQUIRE(va && sa && vb && sb && v && R >= 1 && D >= 1, MP_ERR_INVALID, "mp_merge_state: bad argument");
+    MP_HIP_CHECK(launch_merge_state(va, sa, vb, sb, R, D, v, s, (hipStream_t)stream));
+    return MP_OK;
+}
+
+}  // extern "C"

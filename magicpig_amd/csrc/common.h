@@ -1,0 +1,98 @@
+// common.h -- shared device/host helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/magicpig_hip.h"
+
+namespace mp {
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------- error plumbing (host)
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define MP_HIP_CHECK(expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return ::mp::fail(_e == hipErrorOutOfMemory ? MP_ERR_NOMEM : MP_ERR_HIP,        \
+                              std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    } while (0)
+
+#define MP_REQUIRE(cond, code, msg)                      \
+    do {                                                 \
+        if (!(cond)) return ::mp::fail((code), (msg));   \
+    } while (0)
+
+// ---------------------------------------------------------------- bf16 (device)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
+    return __uint_as_float(((uint32_t)h) << 16);
+}
+// low / high bf16 of a packed dword -> f32 (one VALU op each)
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// round-to-nearest-even, NaN preserved (torch semantics)
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// ---------------------------------------------------------------- wave / block primitives
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int s = 1; s < WAVE; s <<= 1) {
+        int t = __shfl_up(v, s);
+        if (l >= s) v += t;
+    }
+    return v;
+}
+
+// Exclusive prefix sum over the block's threads; `total` gets the block sum.
+// s_tmp: LDS scratch of >= blockDim.x/64 + 1 ints.  Contains two __syncthreads().
+__device__ __forceinline__ int block_excl_scan(int v, int* s_tmp, int& total) {
+    const int l = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + WAVE - 1) >> 6;
+    const int inc = wave_incl_scan(v);
+    if (l == WAVE - 1) s_tmp[w] = inc;
+    __syncthreads();
+    if (w == 0) {
+        int x = (l < nw) ? s_tmp[l] : 0;
+        int xi = wave_incl_scan(x);
+        if (l < nw) s_tmp[l] = xi - x;
+        if (l == nw - 1) s_tmp[nw] = xi;
+    }
+    __syncthreads();
+    total = s_tmp[nw];
+    return s_tmp[w] + inc - v;
+}
+
+}  // namespace mp

@@ -1,0 +1,321 @@
+// lsh.hip -- LSH table build and per-step retrieve on gfx950.
+//
+// Replaces library/lsh/lsh.cc: LSH::fill (:143-201), LSH::retrieve / batch_retrieve
+// (:210-288), get_mask (:308-314).  Integer work, bit-exact as a set + nnz.
+//
+// HBM layout (per layer):
+//   bounds int2  [B*Hkv][L][NB]   (start, end) of bucket b of table l -- the reference keeps
+//                                  two arrays (lsh.h:38-39); interleaving makes the per-step
+//                                  probe ONE 8-byte random read instead of two 4-byte ones;
+//   table  int32 [B*Hkv][L][M]    token ids in code-sorted order, row stride M (lsh.h:40).
+//
+// retrieve: the CPU code is serial per head with a byte mask in DRAM (lsh.cc:266-283).  Here
+// one workgroup owns a head: the collision state of all M tokens lives in LDS as two bitmaps
+// (A = seen once, B = seen twice or more; 2*M/8 bytes = 24.6 KB at M = 98304), bucket ids are
+// streamed with coalesced 256-byte wave loads and applied with LDS atomics (ds_or_rtn_b32),
+// and the result is emitted by a popcount sweep of B with a block-wide prefix sum, i.e. in
+// ASCENDING token order (the reference emits second-hit order; only set + nnz are defined,
+// library/lsh/test.py:43-56).
+#include "common.h"
+
+namespace mp {
+
+constexpr int RT_THREADS = 1024;           // 16 waves: one workgroup per query head
+constexpr int RT_WAVES = RT_THREADS / 64;
+constexpr int RT_CHUNK_CAP = 4096;         // (bucket, 64-id chunk) descriptors per pass
+constexpr int RT_UNROLL = 8;               // global loads in flight per wave
+
+// ---------------------------------------------------------------- LSH::fill
+// grid = Hkv*L rows of one request; one workgroup per (kv head, table) row.
+__global__ __launch_bounds__(256) void lsh_fill_kernel(
+    const int16_t* __restrict__ codes,   // [Hkv*L][n] sorted ascending per row
+    const int32_t* __restrict__ ids,     // [Hkv*L][n]
+    int64_t n, int NB, int64_t M,
+    int2* __restrict__ bounds,           // [Hkv*L][NB]   (this request's slice)
+    int32_t* __restrict__ table,         // [Hkv*L][M]
+    int* __restrict__ err) {
+    const int64_t row = blockIdx.x;
+    const int16_t* c = codes + row * n;
+    const int32_t* src = ids + row * n;
+    int2* b = bounds + row * NB;
+    int32_t* dst = table + row * M;
+    // buckets that do not occur keep start = end = 0 (lsh.cc:177-185 on zeroed arrays)
+    for (int i = threadIdx.x; i < NB; i += blockDim.x) b[i] = make_int2(0, 0);
+    __syncthreads();
+    bool bad = false;
+    for (int64_t k = threadIdx.x; k < n; k += blockDim.x) {
+        const int v = c[k];
+        const int prev = (k > 0) ? (int)c[k - 1] : -1;
+        const int next = (k + 1 < n) ? (int)c[k + 1] : 0x7fffffff;
+        const int32_t id = src[k];
+        if (v < 0 || v >= NB || v < prev || id < 0 || id >= M) {
+            bad = true;
+        } else {
+            if (v != prev) b[v].x = (int)k;        // first position of value v
+            if (v != next) b[v].y = (int)(k + 1);  // one past the last
+        }
+        dst[k] = id;
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+// ---------------------------------------------------------------- device-side table build
+// (replacement of the half-written LSH::fastfill, lsh.cc:93-142): stable counting sort of one
+// (kv head, table) row of UNSORTED codes -> bounds + ascending ids per bucket.
+// One workgroup per row; LDS histogram of NB buckets; the stable scatter walks the row in
+// blocks of blockDim tokens, ranking equal codes inside a block by a match-any ballot.
+__global__ __launch_bounds__(1024) void lsh_build_kernel(
+    const int16_t* __restrict__ codes,   // [Hkv*L][n] unsorted
+    int64_t n, int NB, int64_t M, int2* __restrict__ bounds, int32_t* __restrict__ table,
+    int* __restrict__ err) {
+    extern __shared__ int s_mem[];
+    int* s_cnt = s_mem;            // [NB] histogram, then running cursor
+    int* s_tmp = s_mem + NB;       // scan scratch [blockDim/64 + 2]
+    const int64_t row = blockIdx.x;
+    const int16_t* c = codes + row * n;
+    int2* b = bounds + row * NB;
+    int32_t* dst = table + row * M;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NB; i += blockDim.x) s_cnt[i] = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int64_t k = tid; k < n; k += blockDim.x) {
+        const int v = c[k];
+        if (v < 0 || v >= NB) bad = true;
+        else atomicAdd(&s_cnt[v], 1);
+    }
+    if (bad) atomicOr(err, 1);
+    __syncthreads();
+    // exclusive scan of the histogram -> bucket starts; write bounds
+    int carry = 0;
+    for (int base = 0; base < NB; base += blockDim.x) {
+        const int i = base + tid;
+        const int v = (i < NB) ? s_cnt[i] : 0;
+        int total;
+        __syncthreads();
+        const int ex = block_excl_scan(v, s_tmp, total) + carry;
+        if (i < NB) {
+            b[i] = (v > 0) ? make_int2(ex, ex + v) : make_int2(0, 0);
+            s_cnt[i] = ex;  // running cursor of bucket i
+        }
+        carry += total;
+    }
+    __syncthreads();
+    // stable scatter: the row is walked in block-sized tiles; inside a tile the waves take
+    // turns in token order, and equal codes inside a wave are ranked by lane with a match-any
+    // ballot; the wave leader of each code reserves the bucket space with one LDS atomic.
+    const int nw = blockDim.x >> 6, wave = tid >> 6, lane = tid & 63;
+    for (int64_t base = 0; base < n; base += blockDim.x) {
+        for (int w = 0; w < nw; ++w) {
+            if (w == wave) {
+                const int64_t k = base + tid;
+                const bool valid = k < n;
+                const int v = valid ? (int)c[k] : -1;
+                // rank among the lanes of this wave with the same code and a lower lane id
+                unsigned long long peers = 0;
+                {
+                    // match-any by K-bit radix ballots
+                    unsigned long long m = __ballot(valid);
+                    for (int bit = 0; (1 << bit) < NB; ++bit) {
+                        const unsigned long long bm = __ballot((v >> bit) & 1);
+                        m &= ((v >> bit) & 1) ? bm : ~bm;
+                    }
+                    peers = m;
+                }
+                if (valid && v >= 0 && v < NB) {
+                    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+                    const int leader = __ffsll((long long)peers) - 1;
+                    int start = 0;
+                    if (lane == leader) start = atomicAdd(&s_cnt[v], __popcll(peers));
+                    start = __shfl(start, leader);
+                    dst[start + rank] = (int32_t)k;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------- LSH::batch_retrieve
+// grid = B*H (one workgroup per query head), block = 1024, dynamic LDS:
+//   A[words] | B[words] | s_start[Lpad] | s_len[Lpad] | s_chunk[RT_CHUNK_CAP] | s_tmp[32]
+__global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
+    const int2* __restrict__ bounds, const int32_t* __restrict__ table,
+    const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
+    int G, int L, int NB, int64_t M, int words, int Lpad) {
+    extern __shared__ uint32_t s_u32[];
+    uint32_t* bmA = s_u32;
+    uint32_t* bmB = s_u32 + words;
+    int* s_start = reinterpret_cast<int*>(s_u32 + 2 * words);
+    int* s_len = s_start + Lpad;
+    uint32_t* s_chunk = reinterpret_cast<uint32_t*>(s_len + Lpad);
+    int* s_tmp = reinterpret_cast<int*>(s_chunk + RT_CHUNK_CAP);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t h = blockIdx.x;
+    const int64_t g = h / G;
+    const int2* bnd = bounds + g * L * NB;
+    const int32_t* tab = table + g * L * M;
+
+    // probe: one 8-byte random read per table (issued first: longest latency)
+    for (int l = tid; l < Lpad; l += RT_THREADS) {
+        int st = 0, len = 0;
+        if (l < L) {
+            const int code = query[h * L + l];
+            if (code >= 0 && code < NB) {
+                const int2 be = bnd[(int64_t)l * NB + code];
+                st = be.x;
+                len = be.y - be.x;
+                if (st < 0 || len < 0 || (int64_t)st + len > M) len = 0;
+            }
+        }
+        s_start[l] = st;
+        s_len[l] = len;
+    }
+    for (int i = tid; i < 2 * words; i += RT_THREADS) s_u32[i] = 0u;
+    __syncthreads();
+
+    // chunk descriptors: bucket l contributes ceil(len/64) chunks; descriptor = l << 16 | chunk
+    // (buckets longer than 64*65536 ids cannot occur: M <= 2^22 is enforced at alloc)
+    int my_chunks = 0;
+    for (int l = tid; l < Lpad; l += RT_THREADS) my_chunks += (s_len[l] + 63) >> 6;
+    int total_chunks;
+    int my_base = block_excl_scan(my_chunks, s_tmp, total_chunks);
+    // note: with L <= RT_THREADS each thread owns at most one table; the loop form keeps
+    // larger L correct (a thread's tables are then non-adjacent but descriptors need no order)
+    for (int pass0 = 0; pass0 < total_chunks; pass0 += RT_CHUNK_CAP) {
+        int cur = my_base;
+        for (int l = tid; l < Lpad; l += RT_THREADS) {
+            const int nc = (s_len[l] + 63) >> 6;
+            for (int c = 0; c < nc; ++c) {
+                const int slot = cur + c - pass0;
+                if (slot >= 0 && slot < RT_CHUNK_CAP) s_chunk[slot] = ((uint32_t)l << 16) | (uint32_t)c;
+            }
+            cur += nc;
+        }
+        __syncthreads();
+        const int nchunk = min(RT_CHUNK_CAP, total_chunks - pass0);
+        // each wave streams chunks wave, wave+16, ... with RT_UNROLL loads in flight
+        for (int c0 = wave; c0 < nchunk; c0 += RT_WAVES * RT_UNROLL) {
+            int32_t id[RT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < RT_UNROLL; ++u) {
+                const int c = c0 + u * RT_WAVES;
+                id[u] = -1;
+                if (c < nchunk) {
+                    const uint32_t d = s_chunk[c];
+                    const int l = d >> 16, j = ((d & 0xffffu) << 6) + lane;
+                    if (j < s_len[l]) id[u] = tab[(int64_t)l * M + s_start[l] + j];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RT_UNROLL; ++u) {
+                const int32_t t = id[u];
+                if (t >= 0 && t < M) {
+                    const uint32_t bit = 1u << (t & 31);
+                    const uint32_t old = atomicOr(&bmA[t >> 5], bit);       // first hit: 0 -> 1
+                    if (old & bit) atomicOr(&bmB[t >> 5], bit);             // any later hit: -> 2
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // sweep B: contiguous words per thread, block-wide exclusive scan, ascending emission
+    const int wpt = (words + RT_THREADS - 1) / RT_THREADS;
+    const int w0 = tid * wpt;
+    int cnt = 0;
+    for (int k = 0; k < wpt; ++k)
+        if (w0 + k < words) cnt += __popc(bmB[w0 + k]);
+    int total;
+    int off = block_excl_scan(cnt, s_tmp, total);
+    int32_t* out = results + h * M;
+    for (int k = 0; k < wpt; ++k) {
+        if (w0 + k >= words) break;
+        uint32_t bits = bmB[w0 + k];
+        const int base = (w0 + k) << 5;
+        while (bits) {
+            const int p = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            out[off++] = base + p;
+        }
+    }
+    if (tid == 0) nnz[h] = total;
+}
+
+// ---------------------------------------------------------------- LSH::get_mask (debug view)
+// Recomputes min(count, 2) per token for the last query codes; byte counters in global memory,
+// one workgroup per head, atomics on 32-bit words holding 4 counters... kept simple: each
+// workgroup zeroes its row, then applies saturating increments with atomicCAS on words.
+__global__ __launch_bounds__(256) void lsh_mask_kernel(
+    const int2* __restrict__ bounds, const int32_t* __restrict__ table,
+    const int32_t* __restrict__ query, int8_t* __restrict__ mask, int G, int L, int NB, int64_t M) {
+    const int64_t h = blockIdx.x;
+    const int64_t g = h / G;
+    int8_t* row = mask + h * M;
+    for (int64_t i = threadIdx.x; i < M; i += blockDim.x) row[i] = 0;
+    __syncthreads();
+    // tables are processed one after another by the whole block: within one table a token id
+    // occurs at most once, so plain read-modify-write is race-free.
+    for (int l = 0; l < L; ++l) {
+        const int code = query[h * L + l];
+        if (code < 0 || code >= NB) continue;
+        const int2 be = bounds[(g * L + l) * NB + code];
+        const int32_t* src = table + (g * L + l) * M;
+        for (int j = be.x + threadIdx.x; j < be.y; j += blockDim.x) {
+            const int32_t t = src[j];
+            if (t >= 0 && t < M && row[t] < 2) row[t] = row[t] + 1;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- host launchers
+size_t retrieve_lds_bytes(int64_t M, int L) {
+    const int words = (int)((M + 31) / 32);
+    const int Lpad = (L + 63) & ~63;
+    return (size_t)(2 * words + 2 * Lpad + RT_CHUNK_CAP + 64) * 4;
+}
+
+hipError_t launch_lsh_fill(const int16_t* codes, const int32_t* ids, int rows, int64_t n, int NB,
+                           int64_t M, int2* bounds, int32_t* table, int* err, hipStream_t st) {
+    hipLaunchKernelGGL(lsh_fill_kernel, dim3(rows), dim3(256), 0, st, codes, ids, n, NB, M, bounds,
+                       table, err);
+    return hipGetLastError();
+}
+
+hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, int64_t M,
+                            int2* bounds, int32_t* table, int* err, hipStream_t st) {
+    const size_t lds = (size_t)(NB + 64) * 4;
+    hipLaunchKernelGGL(lsh_build_kernel, dim3(rows), dim3(1024), lds, st, codes, n, NB, M, bounds,
+                       table, err);
+    return hipGetLastError();
+}
+
+hipError_t launch_lsh_retrieve(const int2* bounds, const int32_t* table, const int32_t* query,
+                               int32_t* results, int32_t* nnz, int BH, int G, int L, int NB,
+                               int64_t M, hipStream_t st) {
+    const int words = (int)((M + 31) / 32);
+    const int Lpad = (L + 63) & ~63;
+    const size_t lds = retrieve_lds_bytes(M, L);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_retrieve_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(lsh_retrieve_kernel, dim3(BH), dim3(RT_THREADS), lds, st, bounds, table,
+                       query, results, nnz, G, L, NB, M, words, Lpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_lsh_mask(const int2* bounds, const int32_t* table, const int32_t* query,
+                           int8_t* mask, int BH, int G, int L, int NB, int64_t M, hipStream_t st) {
+    hipLaunchKernelGGL(lsh_mask_kernel, dim3(BH), dim3(256), 0, st, bounds, table, query, mask, G,
+                       L, NB, M);
+    return hipGetLastError();
+}
+
+}  // namespace mp

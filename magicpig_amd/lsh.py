@@ -1,0 +1,91 @@
+"""`LSH` -- host-side mirror of the reference's pybind11 class (library/lsh/lsh.cc:316-326) over
+the gfx950 C ABI.  Same method names, argument order and in-place outputs, so a caller written
+against models/attnserver.py:50-53,191-193,299,330 works unchanged; tensors may be CPU tensors
+(staged through HBM, like the reference's pinned buffers) or CUDA tensors (used in place)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class LSH:
+    def __init__(self):                                   # LSH::LSH(), lsh.cc:25-27
+        self._h = C.c_void_p()
+        L.check(L.lib().mp_lsh_create(C.byref(self._h)))
+        self._alloc = False
+
+    def __del__(self):                                    # LSH::~LSH(), lsh.cc:29-42
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                L.lib().mp_lsh_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def alloc(self, K: int, L_: int, num_layers: int, num_attention_heads: int,
+              num_key_value_heads: int, batch_size: int, max_length: int) -> None:
+        """LSH::alloc, lsh.cc:44-91."""
+        L.check(L.lib().mp_lsh_alloc(self._h, K, L_, num_layers, num_attention_heads,
+                                     num_key_value_heads, batch_size, max_length))
+        self.K, self.L, self.num_layers = K, L_, num_layers
+        self.H, self.Hkv, self.B, self.M = (num_attention_heads, num_key_value_heads, batch_size,
+                                            max_length)
+        self.NB = 1 << K
+        self._alloc = True
+
+    def fill(self, layer_id: int, request_id: int, sorted_hash_code: torch.Tensor,
+             sorted_indices: torch.Tensor) -> None:
+        """LSH::fill, lsh.cc:143-201: sorted codes int16 [Hkv,L,n] + token ids int32 [Hkv,L,n]."""
+        n = sorted_hash_code.shape[-1]
+        L.expect(sorted_hash_code, torch.int16, (self.Hkv, self.L, n), "sorted_hash_code")
+        L.expect(sorted_indices, torch.int32, (self.Hkv, self.L, n), "sorted_indices")
+        mem = L.same_memory(sorted_hash_code, sorted_indices)
+        L.check(L.lib().mp_lsh_fill(self._h, layer_id, request_id, L.ptr(sorted_hash_code),
+                                    L.ptr(sorted_indices), n, mem, L.current_stream(sorted_hash_code)))
+
+    def fastfill(self, layer_id: int, request_id: int, hash_code: torch.Tensor) -> None:
+        """Working version of LSH::fastfill (lsh.cc:93-142, unfinished in the reference): builds
+        the tables on device from UNSORTED codes int16 [Hkv,L,n]."""
+        n = hash_code.shape[-1]
+        L.expect(hash_code, torch.int16, (self.Hkv, self.L, n), "hash_code")
+        L.check(L.lib().mp_lsh_build(self._h, layer_id, request_id, L.ptr(hash_code), n,
+                                     L.mem_kind(hash_code), L.current_stream(hash_code)))
+
+    def batch_retrieve(self, layer_id: int, query: torch.Tensor, results: torch.Tensor,
+                       nnz: torch.Tensor) -> None:
+        """LSH::batch_retrieve, lsh.cc:210-241: query int32 [B*H,L] -> results int32 [B*H,M]
+        (first nnz[h] valid, ascending ids), nnz int32 [B*H]."""
+        BH = self.B * self.H
+        L.expect(query, torch.int32, (BH, self.L), "query")
+        L.expect(results, torch.int32, (BH, self.M), "results")
+        L.expect(nnz, torch.int32, (BH,), "nnz")
+        mem = L.same_memory(query, results, nnz)
+        L.check(L.lib().mp_lsh_batch_retrieve(self._h, layer_id, L.ptr(query), L.ptr(results),
+                                              L.ptr(nnz), mem, L.current_stream(query)))
+
+    def clear(self) -> None:
+        """LSH::clear, lsh.cc:293-306."""
+        L.check(L.lib().mp_lsh_clear(self._h, L.current_stream()))
+
+    def copy(self, query: torch.Tensor) -> None:
+        """LSH::copy, lsh.cc:203-207: empty in the reference; kept for API parity."""
+        return None
+
+    def get_mask(self) -> torch.Tensor:
+        """LSH::get_mask, lsh.cc:308-314: int8 [B,H,M] collision counters min(count,2) of the last
+        batch_retrieve (recomputed on demand; returned as a CPU tensor like the reference's)."""
+        out = torch.zeros((self.B, self.H, self.M), dtype=torch.int8)
+        L.check(L.lib().mp_lsh_get_mask(self._h, L.ptr(out), L.MEM_HOST, L.current_stream()))
+        return out
+
+    # debug views (declared but never defined in the reference, lsh.h:24-26)
+    def get_tables(self, layer_id: int):
+        b, t = C.c_void_p(), C.c_void_p()
+        L.check(L.lib().mp_lsh_get_tables(self._h, layer_id, C.byref(b), C.byref(t)))
+        groups = self.B * self.Hkv
+        bounds = L.device_tensor(b.value, (groups, self.L, self.NB, 2), "<i4")
+        table = L.device_tensor(t.value, (groups, self.L, self.M), "<i4")
+        return bounds, table

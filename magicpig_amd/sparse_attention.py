@@ -1,0 +1,120 @@
+"""`SparseAttentionServer` -- host-side mirror of the reference's pybind11 class
+(library/sparse_attention/sparse_attention.cc:1243-1263) over the gfx950 C ABI.  KV cache, key
+norms and scratch live in HBM; per-call tensors are caller-owned and written in place; they may
+be CPU tensors (staged) or CUDA tensors (zero-copy fast path)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class SparseAttentionServer:
+    def __init__(self):                                   # sparse_attention.cc:519-527
+        self._h = C.c_void_p()
+        L.check(L.lib().mp_attn_create(C.byref(self._h)))
+
+    def __del__(self):                                    # sparse_attention.cc:529-544
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                L.lib().mp_attn_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def alloc(self, num_layers: int, num_attention_heads: int, num_key_value_heads: int,
+              head_dim: int, batch_size: int, max_length: int) -> None:
+        """SparseAttentionServer::alloc, sparse_attention.cc:546-583."""
+        L.check(L.lib().mp_attn_alloc(self._h, num_layers, num_attention_heads,
+                                      num_key_value_heads, head_dim, batch_size, max_length))
+        self.num_layers = num_layers
+        self.H, self.Hkv, self.D, self.B, self.M = (num_attention_heads, num_key_value_heads,
+                                                    head_dim, batch_size, max_length)
+
+    def fill(self, layer_id: int, request_id: int, k: torch.Tensor, v: torch.Tensor,
+             kn: torch.Tensor) -> None:
+        """SparseAttentionServer::fill, sparse_attention.cc:601-627: k, v bf16 [Hkv,n,D], kn f32 [Hkv,n]."""
+        n = k.shape[1]
+        L.expect(k, torch.bfloat16, (self.Hkv, n, self.D), "k")
+        L.expect(v, torch.bfloat16, (self.Hkv, n, self.D), "v")
+        L.expect(kn, torch.float32, (self.Hkv, n), "kn")
+        mem = L.same_memory(k, v, kn)
+        L.check(L.lib().mp_attn_fill(self._h, layer_id, request_id, L.ptr(k), L.ptr(v), L.ptr(kn), n,
+                                     mem, L.current_stream(k)))
+
+    def attention_wrapper(self, layer_id: int, K: int, L_: int, output: torch.Tensor,
+                          max_value_expsum: torch.Tensor, query: torch.Tensor,
+                          query_norm: torch.Tensor, ind: torch.Tensor, nnz: torch.Tensor) -> None:
+        """attention_wrapper, sparse_attention.cc:629-745 (all dispatch targets are one kernel
+        here).  output bf16 [B*H,D]; max_value_expsum f32 [2,B*H]; query bf16 (or f32, the
+        non-AVX512BF16 build's `.to(kFloat32)`) [B*H,D]; query_norm f32 [B*H]; ind int32 [B*H,M];
+        nnz int32 [B*H]."""
+        BH = self.B * self.H
+        L.expect(output, torch.bfloat16, (BH, self.D), "output")
+        L.expect(max_value_expsum, torch.float32, (2, BH), "max_value_expsum")
+        if query.dtype not in (torch.bfloat16, torch.float32):
+            query = query.float()
+        L.expect(query, None, (BH, self.D), "query")
+        L.expect(query_norm, torch.float32, (BH,), "query_norm")
+        L.expect(ind, torch.int32, (BH, self.M), "ind")
+        L.expect(nnz, torch.int32, (BH,), "nnz")
+        mem = L.same_memory(output, max_value_expsum, query, query_norm, ind, nnz)
+        qd = L.DTYPE_BF16 if query.dtype == torch.bfloat16 else L.DTYPE_F32
+        L.check(L.lib().mp_attn_sparse(self._h, layer_id, K, L_, L.ptr(output), L.ptr(max_value_expsum),
+                                       L.ptr(query), qd, L.ptr(query_norm), L.ptr(ind), L.ptr(nnz),
+                                       mem, L.current_stream(output)))
+
+    # every reference variant computes the same function (sparse_attention.cc:748-986, 1039-1211)
+    attention = attention_wrapper
+    scheduled_attention = attention_wrapper
+    attention_bf16 = attention_wrapper
+    attention_wrapper_bf16 = attention_wrapper
+
+    def full_attention(self, layer_id: int, output: torch.Tensor, max_value_expsum: torch.Tensor,
+                       query: torch.Tensor, nnz: torch.Tensor) -> None:
+        """full_attention, sparse_attention.cc:988-1037 (dense, K == 0 baseline)."""
+        BH = self.B * self.H
+        L.expect(output, torch.bfloat16, (BH, self.D), "output")
+        L.expect(max_value_expsum, torch.float32, (2, BH), "max_value_expsum")
+        if query.dtype not in (torch.bfloat16, torch.float32):
+            query = query.float()
+        L.expect(query, None, (BH, self.D), "query")
+        L.expect(nnz, torch.int32, (BH,), "nnz")
+        mem = L.same_memory(output, max_value_expsum, query, nnz)
+        qd = L.DTYPE_BF16 if query.dtype == torch.bfloat16 else L.DTYPE_F32
+        L.check(L.lib().mp_attn_full(self._h, layer_id, L.ptr(output), L.ptr(max_value_expsum),
+                                     L.ptr(query), qd, L.ptr(nnz), mem, L.current_stream(output)))
+
+    def clear(self) -> None:
+        """SparseAttentionServer::clear, sparse_attention.cc:586-598."""
+        L.check(L.lib().mp_attn_clear(self._h, L.current_stream()))
+
+    # ---- views of handle-owned HBM (sparse_attention.cc:1213-1241); K|V are interleaved per
+    # token in HBM, so the key/value caches come back as strided (non-contiguous) CUDA views.
+    def _kv(self, layer_id: int, which: int) -> torch.Tensor:
+        k, v, stride = C.c_void_p(), C.c_void_p(), C.c_int64()
+        L.check(L.lib().mp_attn_get_kv(self._h, layer_id, C.byref(k), C.byref(v), C.byref(stride)))
+        rs = stride.value * 2
+        t = L.device_tensor((k.value, v.value)[which], (self.B, self.Hkv, self.M, self.D), "<i2",
+                            (self.Hkv * self.M * rs, self.M * rs, rs, 2))
+        return t.view(torch.bfloat16)
+
+    def get_key_cache(self, layer_id: int) -> torch.Tensor:
+        return self._kv(layer_id, 0)
+
+    def get_value_cache(self, layer_id: int) -> torch.Tensor:
+        return self._kv(layer_id, 1)
+
+    def get_key_norm(self, layer_id: int) -> torch.Tensor:
+        p = C.c_void_p()
+        L.check(L.lib().mp_attn_get_key_norm(self._h, layer_id, C.byref(p)))
+        return L.device_tensor(p.value, (self.B, self.Hkv, self.M), "<f4")
+
+    def get_score(self) -> torch.Tensor:
+        """get_score, sparse_attention.cc:1235-1241: f32 [B,H,M] probabilities of the last call
+        (first nnz entries per head, in `ind` order)."""
+        p = C.c_void_p()
+        L.check(L.lib().mp_attn_get_score(self._h, C.byref(p), L.current_stream()))
+        return L.device_tensor(p.value, (self.B, self.H, self.M), "<f4")
