@@ -40,6 +40,26 @@ __device__ __forceinline__ float powi(float b, int e) {
     return r;
 }
 
+// 8-element bf16 dot product: four chained v_dot2c_f32_bf16 (D += a.lo*b.lo + a.hi*b.hi).
+// Inline asm on purpose: with ROCm 7.2's hipcc, __builtin_amdgcn_fdot2_f32_bf16 fed from
+// ext-vector element extracts selects element 0 for EVERY call (scripts/probe_dot2.hip shows
+// `v_dot2c_f32_bf16 v, v2, v6` four times); the asm form is correct.  hipcc pads nothing
+// inside asm, so the gfx940-class DOT hazards are handled here: a DOT result may feed the next
+// same-opcode DOT as the accumulator with 0 wait states, but any other VALU read / write of it
+// needs 3 / 4 wait states (LLVM GCNHazardRecognizer, DotWriteDifferentVALURead/Write) ->
+// `s_nop 3` after the chain.
+__device__ __forceinline__ float dot8_bf16(const u32x4& k, const uint32_t (&q)[4]) {
+    float acc = 0.f;
+    asm("v_dot2c_f32_bf16 %0, %1, %5\n\t"
+        "v_dot2c_f32_bf16 %0, %2, %6\n\t"
+        "v_dot2c_f32_bf16 %0, %3, %7\n\t"
+        "v_dot2c_f32_bf16 %0, %4, %8\n\t"
+        "s_nop 3"
+        : "+v"(acc)
+        : "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
+    return acc;
+}
+
 __device__ __forceinline__ int slices_of(int nz, int64_t M) {
     if (nz < 0) nz = 0;
     if ((int64_t)nz > M) nz = (int)M;
@@ -146,10 +166,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_partial_kernel(
         for (int u = 0; u < LPR; ++u) {
             float a = 0.f;
             if (QBF16) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, kreg[u][i]),
-                                                        __builtin_bit_cast(bf16x2, qpk[i]), a, false);
+                a = dot8_bf16(kreg[u], qpk);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
