@@ -23,7 +23,7 @@ namespace mp {
 constexpr int RT_THREADS = 1024;           // 16 waves: one workgroup per query head
 constexpr int RT_WAVES = RT_THREADS / 64;
 constexpr int RT_CHUNK_CAP = 4096;         // (bucket, 64-id chunk) descriptors per pass
-constexpr int RT_UNROLL = 8;               // global loads in flight per wave
+constexpr int RT_UNROLL = 16;              // global loads in flight per wave
 
 // ---------------------------------------------------------------- LSH::fill
 // grid = Hkv*L rows of one request; one workgroup per (kv head, table) row.

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(SH_THREADS) void simhash_kernel(
             bool bit = a > 0.f;
             if (dbg_acc != nullptr && r0 + row < R && n < KL) dbg_acc[(r0 + row) * KL + n] = a;
             // guard band: exact recomputation, wave-cooperative (rare)
-            const bool near = fabsf(a) <= wn * s_rn[row];
+            // (zero-padded planes / rows give acc == bound == 0: they are not candidates)
+            const bool near = (n < KL) && (r0 + row < R) && fabsf(a) <= wn * s_rn[row];
             unsigned long long m = __ballot(near);
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
