@@ -11,7 +11,7 @@ torch.distributed.run and every rank serves its own batch of requests (weak scal
 collective inside the path; RCCL only for the barrier and the max-over-ranks time).
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying
-  roofline      the dominant kernel (attn_partial_kernel): algorithmic bytes per launch /
+  roofline      the dominant kernel (attn_sparse_kernel): algorithmic bytes per launch /
                 average dispatch duration from HIP events bound to the dispatches;
   cpu_baseline  the reference's own AVX512 path (oracle/_ref, kind "reference") or the oracle
                 port (kind "port") timed on this box's host cores on a bounded sample.
@@ -75,7 +75,7 @@ def cpu_worker(path: str) -> None:
     z = np.load(path)
     meta = {k: int(v) for k, v in zip(z["meta_keys"], z["meta_vals"])}
     B, H, Hkv, D, M, K, L, n, steps = (meta[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "n", "steps"))
-    cores = len(os.sched_getaffinity(0))
+    cores = meta["cores"]          # host cores seen by the parent (OMP_PROC_BIND pins this process's main thread)
     BH = B * H
     sorted_codes = torch.from_numpy(z["sorted_codes"])        # [B, Hkv, L, n] int16
     sorted_ids = torch.from_numpy(z["sorted_ids"])            # int32
@@ -92,6 +92,7 @@ def cpu_worker(path: str) -> None:
         ref_lsh, ref_attn = build_ref.load_ref()
         lsh, srv = ref_lsh.LSH(), ref_attn.SparseAttentionServer()
         kind = "reference"
+        cores = min(cores, 64)     # LSH_THREADS / ATTENTION_THREADS are compile-time 64 (lsh.h:12, sparse_attention.h:10)
     else:
         import oracle
 
@@ -149,15 +150,16 @@ def run_cpu_baseline(cfg, server, qs, steps):
     BH = B * H
     qcodes = torch.stack([server.hasher.query(qs[i, layer].reshape(BH, D))[0] for i in range(NQ)])
     path = os.path.join(tempfile.gettempdir(), f"mp_cpu_baseline_{os.getpid()}.npz")
-    keys = ["B", "H", "Hkv", "D", "M", "K", "L", "n", "steps"]
-    np.savez(path, meta_keys=np.array(keys), meta_vals=np.array([B, H, Hkv, D, M, K, Lt, n, steps]),
+    cores = len(os.sched_getaffinity(0))
+    keys = ["B", "H", "Hkv", "D", "M", "K", "L", "n", "steps", "cores"]
+    np.savez(path, meta_keys=np.array(keys), meta_vals=np.array([B, H, Hkv, D, M, K, Lt, n, steps, cores]),
              sorted_codes=sorted_codes.cpu().numpy(), sorted_ids=ids.cpu().numpy(),
              k=kc.cpu().view(torch.int16).numpy(), v=vc.cpu().view(torch.int16).numpy(),
              kn=kn.cpu().numpy(), q=qs[:, layer].reshape(NQ, BH, D).cpu().view(torch.int16).numpy(),
              qcodes=qcodes.cpu().numpy())
-    cores = len(os.sched_getaffinity(0))
+    # one OpenMP thread per physical core, packed (the reference pins with numactl, examples/bench.sh:1)
     env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_THREAD_LIMIT=str(cores),
-               OMP_PROC_BIND="close", MKL_NUM_THREADS=str(cores))
+               OMP_PLACES="cores", OMP_PROC_BIND="close", MKL_NUM_THREADS=str(cores))
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path],
                            env=env, capture_output=True, text=True, timeout=900)
@@ -284,23 +286,38 @@ def main():
     tokens_per_s = world * B * args.steps / dt
     us_per_layer = ms_per_step * 1e3 / NL
 
-    # ---- roofline leg: per-dispatch HIP events on the dominant kernel, same workload, eager
-    prof_steps = min(args.steps, 16)
-    cap = prof_steps * NL
-    L.check(L.lib().mp_attn_profile_begin(server.attn_server._h, cap))
-    nnz_sum = 0.0
-    for i in range(prof_steps):
-        q_static.copy_(qs[i % NQ])
-        step()
-    buf = (C.c_float * cap)()
-    got = C.c_int(0)
-    L.check(L.lib().mp_attn_profile_end(server.attn_server._h, buf, cap, C.byref(got)))
+    # ---- roofline leg: the dominant kernel alone (attn_sparse_kernel), same workload: per-layer
+    # index lists from a real retrieve pass, then back-to-back launches of ONLY that kernel on the
+    # current stream, bracketed by HIP events recorded on that same stream.
+    server.collect_nnz = True
+    res_l, nnz_l, qn_l = [], [], []
+    q_static.copy_(qs[0])
+    for li in range(NL):
+        codes, qn = server.hasher.query(q_static[li].reshape(BH, D))
+        r_ = torch.zeros((BH, M), dtype=torch.int32, device=dev)
+        z_ = torch.zeros((BH,), dtype=torch.int32, device=dev)
+        server.lsh_retriever.batch_retrieve(li, codes, r_, z_)
+        res_l.append(r_); nnz_l.append(z_); qn_l.append(qn)
+    prof_reps = 8
+    def partial_pass():
+        for li in range(NL):
+            server.attn_server.attention_wrapper(li, K, Lt, server.output, server.max_value_expsum,
+                                                 q_static[li].reshape(BH, D), qn_l[li], res_l[li], nnz_l[li])
+    partial_pass()
     torch.cuda.synchronize()
-    k_ms = np.array(buf[:got.value], dtype=np.float64)
-    k_us = float(k_ms.mean() * 1e3)
-    # algorithmic bytes of ONE attn_partial_kernel launch (DESIGN.md "Algorithmic bytes"):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(prof_reps):
+        partial_pass()
+    e1.record()
+    torch.cuda.synchronize()
+    n_timed = prof_reps * NL
+    k_us = e0.elapsed_time(e1) * 1e3 / n_timed
+    nnz_prof = float(torch.stack(nnz_l).float().mean())
+    del res_l
+    # algorithmic bytes of ONE attn_sparse_kernel launch (DESIGN.md "Algorithmic bytes"):
     #   per selected token: K row + V row (2*D*2) + key norm (4) + id (4);  per head: q (2*D) + partial
-    bytes_attn = nnz_mean * BH * (4 * D + 8) + BH * (2 * D) + (nnz_mean * BH / 256 + BH) * (D * 4 + 8)
+    bytes_attn = nnz_prof * BH * (4 * D + 8) + BH * (2 * D) + (nnz_prof * BH / 64 + BH) * (D * 4 + 8)
     achieved = bytes_attn / (k_us * 1e-6) / 1e9
     # whole-layer algorithmic bytes, SURVEY.md 8(d)
     bytes_layer = BH * (8 * Lt + 4 * cand_mean + 4 * nnz_mean + nnz_mean * (4 * D + 4) + 4 * nnz_mean
@@ -329,10 +346,10 @@ def main():
         "sparse_attn_us_per_layer": us_per_layer,
         "observed": {"nnz_per_head": nnz_mean, "candidates_per_head": cand_mean,
                      "selected_fraction": nnz_mean / n, "setup_s": t_setup},
-        "roofline": {"bound": "hbm", "kernel": "attn_partial_kernel", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "attn_sparse_kernel", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "bytes_per_launch": bytes_attn, "avg_launch_us": k_us,
-                     "launches_timed": int(got.value),
+                     "launches_timed": n_timed,
                      "layer_bytes": bytes_layer, "layer_frac": bytes_layer / (us_per_layer * 1e-6) / 1e9 / HBM_PEAK_GBS},
     }
 

@@ -139,12 +139,9 @@ int mp_attn_get_key_norm(mp_attn_t* h, int layer_id, void** kn_dev);
  * f32 [B, H, M], first nnz entries per head in `ind` order.  Normalised on demand. */
 int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream);
 
-/* Measurement hooks (no reference counterpart): time each launch of the dominant kernel of
- * mp_attn_sparse / mp_attn_full / mp_decode_sparse_layer with HIP events bound to the dispatch
- * on its launch stream.  begin() arms up to max_launches records; end() returns the durations
- * in milliseconds (ms_out[cap]) of the launches made in between. */
-int mp_attn_profile_begin(mp_attn_t* h, int max_launches);
-int mp_attn_profile_end(mp_attn_t* h, float* ms_out, int cap, int* n_out);
+/* Debug: device buffer of >= 64 uint64 receiving 100 MHz wall-clock stamps at the phase
+ * boundaries of workgroup 0 of the hot kernels (scripts/phase_times.py); NULL switches it off. */
+int mp_debug_set_stamp_buffer(void* dev_u64x64);
 
 /* ---------------------------------------------------------------- one decode step of one layer
  * The device-resident equivalent of LSHSparseAttnServer.decode lines 264-300

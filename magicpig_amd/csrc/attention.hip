@@ -9,26 +9,26 @@
 // share one DRAM page); key norms f32 [B*Hkv][M].
 //
 // Design (memory-bound gather, ~524 B per selected token, no reuse):
-//   * split-KV over the index list: a SLICE is 256 consecutive entries of one head's `ind`;
-//     a persistent grid walks all slices of all heads (slice -> head by a prefix sum over
-//     ceil(nnz/256) computed on device: no host readback of nnz);
+//   * split-KV over the index list: a SLICE is 64 consecutive entries of one head's `ind`, owned
+//     by ONE wave; grid = (GX, B*H) workgroups of 4 independent waves stride over the slices of
+//     their head (nnz is read on device: no host readback, no cross-workgroup prefix);
 //   * a wave owns 64 tokens; one global_load_dwordx4 fetches 4 whole rows (16 lanes x 16 B per
 //     256-byte row), so a wave keeps 16 K-row loads + 16 V-row loads (32 KB) in flight;
 //   * q.K: 4 v_dot2c_f32_bf16 per row chunk, then a 15-step reduce-scatter over the 16 lanes
 //     of a row group leaves exactly ONE token's score per lane, so the transcendental
 //     importance transform (acos, two integer powers, log, exp) runs once per token per lane;
-//   * softmax is per wave (max / sum by DPP shuffles), P.V accumulates 8 f32 per lane, the 4
-//     waves of a slice combine through LDS into one (m, l, o[D]) partial; a second small
-//     kernel merges the partials of a head and writes bf16 out + base-2 LSE.
-#include <hip/hip_ext.h>
-
+//   * softmax is per wave (max / sum by shuffles), P.V accumulates 8 f32 per lane and each slice
+//     publishes one (m, l, o[D]) partial (520 B) write-through; the wave that draws the last
+//     arrival ticket of a head merges that head's partials in the same launch and writes bf16
+//     out + base-2 LSE (no second kernel, no grid-wide wait).
 #include "common.h"
 
 namespace mp {
 
+extern unsigned long long* g_stamp;   // simhash.hip
+
 constexpr int AT_THREADS = 256;
 constexpr int AT_WAVES = AT_THREADS / 64;
-constexpr int AT_SLICE = AT_WAVES * 64;   // tokens per slice
 
 __device__ __forceinline__ float powi(float b, int e) {
     float r = 1.f;
@@ -60,96 +60,123 @@ __device__ __forceinline__ float dot8_bf16(const u32x4& k, const uint32_t (&q)[4
     return acc;
 }
 
-__device__ __forceinline__ int slices_of(int nz, int64_t M) {
-    if (nz < 0) nz = 0;
-    if ((int64_t)nz > M) nz = (int)M;
-    return (nz + AT_SLICE - 1) / AT_SLICE;
+// one reduce-scatter step over lanes l and l^ST: N values -> N/2 values per lane
+template <int N, int ST>
+__device__ __forceinline__ void rs_step(float (&v)[8], int lane, int& doff) {
+    constexpr int half = N / 2;
+    const bool upper = (lane & ST) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+        const float send = upper ? v[i] : v[i + half];
+        const float keep = upper ? v[i + half] : v[i];
+        v[i] = keep + __shfl_xor(send, ST);
+    }
+    doff += upper ? half : 0;
 }
 
 // D: head_dim (64 or 128); DENSE: ids are 0..nnz-1 and no importance transform (full_attention);
 // QBF16: query is bf16 (the reference's __AVX512BF16__ family) else f32.
+//
+// grid = (GX, BH), block = 256: every WAVE is an independent worker that owns 64-entry slices
+// (x*4 + w) + k*GX*4, k = 0, 1, ... of head h's index list -- no LDS, no barrier.  The first
+// slice's index load is issued speculatively, in parallel with the nnz[h] load, so the
+// dependent chain of a wave is  {nnz, ind} -> K/V/|k| gathers -> math -> one 520-byte partial.
 template <int D, bool DENSE, bool QBF16>
-__global__ __launch_bounds__(AT_THREADS) void attn_partial_kernel(
+__global__ __launch_bounds__(AT_THREADS) void attn_sparse_kernel(
     const uint16_t* __restrict__ kv,     // [B*Hkv][M][2][D]
     const float* __restrict__ kn,        // [B*Hkv][M]
     const void* __restrict__ query,      // [BH][D] bf16 or f32
     const float* __restrict__ qnorm,     // [BH]
     const int32_t* __restrict__ ind,     // [BH][M]
     const int32_t* __restrict__ nnz,     // [BH]
-    float* __restrict__ part_o,          // [slices][D]
-    float2* __restrict__ part_ml,        // [slices] (max logit, sum exp)
+    float* __restrict__ part_o,          // [BH][MAXS][D]   slice partials (write-through)
+    float2* __restrict__ part_ml,        // [BH][MAXS]      (max logit, sum exp)
+    int* __restrict__ head_cnt,          // [BH] arrival tickets, zero between launches
+    uint16_t* __restrict__ out,          // [BH][D] bf16
+    float* __restrict__ mve,             // [2][BH] max*log2e, base-2 LSE
+    float2* __restrict__ head_mz,        // [BH] (max logit, Z) for get_score
     float* __restrict__ score,           // [BH][M] transformed logits z_j (nullable)
-    int BH, int G, int64_t M, int K, int L) {
+    int BH, int G, int64_t M, int maxs, int K, int L, unsigned long long* __restrict__ stamp) {
     constexpr int LPR = D / 8;           // lanes per row (16 B each)
     constexpr int RPL = 64 / LPR;        // rows per wave load
-    extern __shared__ int s_pre[];       // [BH + 1] slice prefix
-    __shared__ float s_o[AT_WAVES][D];
-    __shared__ float s_m[AT_WAVES], s_l[AT_WAVES];
-    __shared__ int s_tmp[AT_WAVES + 2];
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane / LPR, c = lane % LPR;
+    const int h = blockIdx.y;
+    const int64_t g = h / G;
+    const int stride = gridDim.x * AT_WAVES;            // slices per pass over this head
+    int s = blockIdx.x * AT_WAVES + wave;
+    MP_STAMP(stamp, 32);
 
-    // ---- slice prefix over heads (every workgroup computes it; BH ints from L2)
-    int carry = 0;
-    for (int base = 0; base < BH; base += AT_THREADS) {
-        const int hh = base + tid;
-        const int v = (hh < BH) ? slices_of(nnz[hh], M) : 0;
-        int total;
-        __syncthreads();
-        const int ex = block_excl_scan(v, s_tmp, total);
-        if (hh < BH) s_pre[hh] = carry + ex;
-        carry += total;
-    }
-    if (tid == 0) s_pre[BH] = carry;
-    __syncthreads();
-    const int total_slices = s_pre[BH];
-    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
-
-    for (int s = blockIdx.x; s < total_slices; s += gridDim.x) {
-        // head of slice s: first h with s_pre[h + 1] > s
-        int lo = 0, hi = BH - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_pre[mid + 1] > s) hi = mid; else lo = mid + 1;
-        }
-        const int h = lo;
-        const int64_t g = h / G;
-        int nz = nnz[h];
-        if ((int64_t)nz > M) nz = (int)M;
-        const int jb = (s - s_pre[h]) * AT_SLICE + wave * 64;   // first token of this wave
-
-        // my token (the one whose score lands on this lane after the reduce-scatter)
-        const int j_my = jb + c * RPL + r;
-        const bool valid_my = j_my < nz;
-        int id_my = 0;
-        if (valid_my) {
-            id_my = DENSE ? j_my : ind[(int64_t)h * M + j_my];
-            if (id_my < 0 || (int64_t)id_my >= M) id_my = 0;   // never fault on a bad index
-        }
-        float kn_my = 1.f;
-        if (!DENSE && valid_my) kn_my = kn[g * M + id_my];
-
-        // query fragment of this lane: elements c*8 .. c*8+7
-        uint32_t qpk[4];
-        float qf[8];
-        if (QBF16) {
-            const u32x4 t = *reinterpret_cast<const u32x4*>(
-                reinterpret_cast<const uint16_t*>(query) + (int64_t)h * D + c * 8);
-            qpk[0] = t[0]; qpk[1] = t[1]; qpk[2] = t[2]; qpk[3] = t[3];
-        } else {
-            const float* qp = reinterpret_cast<const float*>(query) + (int64_t)h * D + c * 8;
+    // Token slot of (gather step u, row group r) is r*LPR + u, so after the reduce-scatter lane l
+    // owns token jb + l, and the LPR ids a row group gathers are LPR CONSECUTIVE ints of `ind`
+    // (read as 16-byte loads, no cross-lane traffic before the gathers are issued).
+    // The first slice's ids are loaded speculatively, alongside nnz[h].
+    const int32_t* ind_h = ind + (int64_t)h * M;
+    u32x4 idv[LPR / 4];
+    auto load_ids = [&](int64_t jb0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) qf[i] = qp[i];
+        for (int v = 0; v < LPR / 4; ++v) {
+            const int64_t j0 = jb0 + r * LPR + v * 4;
+            if (j0 + 3 < M) {
+                idv[v] = *reinterpret_cast<const u32x4*>(ind_h + j0);
+            } else {   // last, partial quad of the row: stay inside [0, M)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) idv[v][e] = (j0 + e < M) ? (uint32_t)ind_h[j0 + e] : 0u;
+            }
         }
+    };
+    if (!DENSE) load_ids((int64_t)s * 64);
+    int nz = nnz[h];
+    if ((int64_t)nz > M) nz = (int)M;
+    if (nz <= 0) {                                      // empty head: out = 0, LSE = -inf (a-10)
+        if (blockIdx.x == 0 && wave == 0) {
+            for (int d = lane; d < D; d += 64) out[(int64_t)h * D + d] = 0;
+            if (lane == 0) {
+                mve[h] = -INFINITY;
+                mve[BH + h] = -INFINITY;
+                head_mz[h] = make_float2(-INFINITY, 0.f);
+            }
+        }
+        return;
+    }
+    if ((int64_t)s * 64 >= nz) return;                  // wave-uniform exit
+    const int ns = (nz + 63) >> 6;                      // slices (= partials, = tickets) of this head
 
-        // ---- issue all row gathers: step u fetches the rows of token slots u*RPL + r
-        const uint16_t* kvg = kv + g * M * 2 * D + c * 8;
+    // query fragment of this lane: elements c*8 .. c*8+7
+    uint32_t qpk[4];
+    float qf[8];
+    if (QBF16) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(
+            reinterpret_cast<const uint16_t*>(query) + (int64_t)h * D + c * 8);
+        qpk[0] = t[0]; qpk[1] = t[1]; qpk[2] = t[2]; qpk[3] = t[3];
+    } else {
+        const float* qp = reinterpret_cast<const float*>(query) + (int64_t)h * D + c * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qf[i] = qp[i];
+    }
+    const float qn_h = DENSE ? 1.f : qnorm[h];
+    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
+    const uint16_t* kvg = kv + g * M * 2 * D + c * 8;
+    MP_STAMP(stamp, 33);
+
+    bool first = true;
+    for (; (int64_t)s * 64 < nz; s += stride) {
+        const int jb = s * 64;
+        if (!DENSE && !first) load_ids(jb);
+        first = false;
+        // my token (the one whose score lands on this lane after the reduce-scatter)
+        const int j_my = jb + lane;
+        const bool valid_my = j_my < nz;
+
+        // ---- issue all row gathers: step u fetches the rows of token slots r*LPR + u
         u32x4 kreg[LPR], vreg[LPR];
+        int id_my = 0;
 #pragma unroll
         for (int u = 0; u < LPR; ++u) {
-            const int id_u = __shfl(id_my, r * LPR + u);
-            const bool valid_u = (jb + u * RPL + r) < nz;
+            int id_u = DENSE ? (jb + r * LPR + u) : (int)idv[u / 4][u % 4];
+            const bool valid_u = (jb + r * LPR + u) < nz;
+            if (id_u < 0 || (int64_t)id_u >= M) id_u = 0;      // never fault on a bad index
+            if (u == c) id_my = id_u;
             const u32x4 zero = {0u, 0u, 0u, 0u};
             kreg[u] = zero;
             vreg[u] = zero;
@@ -159,6 +186,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_partial_kernel(
                 vreg[u] = *reinterpret_cast<const u32x4*>(row + D);
             }
         }
+        float kn_my = 1.f;
+        if (!DENSE && valid_my) kn_my = kn[g * M + id_my];
+        MP_STAMP(stamp, 34);
 
         // ---- q . K partials, then reduce-scatter over the LPR lanes of a row group
         float part[LPR];
@@ -187,6 +217,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_partial_kernel(
             }
         }
         const float sc = part[0];   // = q . K[id_my]
+        MP_STAMP(stamp, 35);
 
         // ---- importance-sampling transform (transform_kernel, sparse_attention.cc:164-184)
         float z = -INFINITY;
@@ -194,22 +225,27 @@ __global__ __launch_bounds__(AT_THREADS) void attn_partial_kernel(
             if (DENSE) {
                 z = sc * inv_sqrt_d;
             } else {
-                float cs = sc / (qnorm[h] * kn_my);
+                float cs = sc / (qn_h * kn_my);
                 cs = fminf(1.f, fmaxf(-1.f, cs));      // the reference does not clamp (NaN when
                                                        // a bf16-rounded norm makes cos > 1)
                 const float theta = acosf(cs);
                 const float proba = 1.f - theta * 0.31830988618379067f;
                 const float p = powi(proba, K);
-                const float qq = 1.f - p;
-                const float w = 1.f - powi(qq, L - 1) * ((float)L * p + qq);
+                // w = 1 - (1-p)^(L-1) (L p + 1 - p) = P[>= 2 of L tables collide].  The reference
+                // evaluates this literally in f32 (two powf and a subtraction from 1), which loses
+                // ~3 digits to cancellation wherever w ~ 1e-4; here the same quantity is computed
+                // without the cancellation: log X = (L-1) log1p(-p) + log1p((L-1) p), w = -expm1(log X).
+                const float lm1 = (float)(L - 1);
+                const float w = -expm1f(lm1 * log1pf(-p) + log1pf(lm1 * p));
                 z = sc * inv_sqrt_d - logf(w + 1e-4f);
             }
             if (score != nullptr) score[(int64_t)h * M + j_my] = z;
         }
+        MP_STAMP(stamp, 36);
 
-        // ---- per-wave softmax
+        // ---- softmax of the slice (max / sum across the wave)
         const float m_w = wave_max(z);
-        const float p_my = (valid_my && m_w > -INFINITY) ? __expf(z - m_w) : 0.f;
+        const float p_my = valid_my ? __expf(z - m_w) : 0.f;    // slice non-empty => m_w finite
         const float l_w = wave_sum(p_my);
 
         // ---- P . V
@@ -225,71 +261,99 @@ __global__ __launch_bounds__(AT_THREADS) void attn_partial_kernel(
                 acc[2 * i + 1] = fmaf(pu, bf16_hi(vreg[u][i]), acc[2 * i + 1]);
             }
         }
-#pragma unroll
-        for (int st = LPR; st < 64; st <<= 1)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], st);
+        // reduce-scatter over the RPL row groups: lane (r, c) ends with VPL = 8/RPL outputs,
+        // elements d0 .. d0+VPL-1 of o[D]
+        int doff = 0;
+        rs_step<8, 32>(acc, lane, doff);
+        rs_step<4, 16>(acc, lane, doff);
+        if (LPR == 8) rs_step<2, 8>(acc, lane, doff);
+        constexpr int VPL = (LPR == 16) ? 2 : 1;
+        const int d0 = c * 8 + doff;
+        MP_STAMP(stamp, 37);
 
-        // ---- combine the 4 waves of the slice in LDS -> one partial
-        if (lane < LPR) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s_o[wave][c * 8 + i] = acc[i];
+        // ---- publish the slice partial WRITE-THROUGH (sc1: agent-scope relaxed atomic stores),
+        // drain, then take an arrival ticket; the wave that draws the last ticket of the head
+        // merges all partials (read back with sc1 loads, which bypass this CU's L1).  Hand-off
+        // recipe: cdna_hip_programming.md G16 (R1 with a counter).
+        const int64_t pidx = (int64_t)h * maxs + s;
+        if (VPL == 2) {
+            const unsigned long long pk = (unsigned long long)__float_as_uint(acc[0]) |
+                                          ((unsigned long long)__float_as_uint(acc[1]) << 32);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(part_o + pidx * D + d0), pk,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(reinterpret_cast<unsigned int*>(part_o + pidx * D + d0),
+                               __float_as_uint(acc[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (lane == 0) { s_m[wave] = m_w; s_l[wave] = l_w; }
-        __syncthreads();
-        if (tid < D) {
-            float m = s_m[0];
+        if (lane == 0) {
+            const unsigned long long pk = (unsigned long long)__float_as_uint(m_w) |
+                                          ((unsigned long long)__float_as_uint(l_w) << 32);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(part_ml + pidx), pk,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing lane of this wave drained
+        int ticket = 0;
+        if (lane == 0)
+            ticket = __hip_atomic_fetch_add(head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        MP_STAMP(stamp, 38);
+        if (ticket != ns - 1) continue;
+
+        // ---- last arriver: merge the ns partials of head h
+        if (lane == 0) __hip_atomic_store(head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t pre = (int64_t)h * maxs;
+        float m = -INFINITY;
+        for (int t = lane; t < ns; t += 64) {
+            const unsigned long long pk = __hip_atomic_load(
+                reinterpret_cast<unsigned long long*>(part_ml + pre + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m = fmaxf(m, __uint_as_float((uint32_t)pk));
+        }
+        m = wave_max(m);
+        float Z = 0.f, o0 = 0.f, o1 = 0.f;
+        for (int t0 = 0; t0 < ns; t0 += 8) {
+            unsigned long long ml[8], ov[8];
 #pragma unroll
-            for (int w = 1; w < AT_WAVES; ++w) m = fmaxf(m, s_m[w]);
-            float o = 0.f, l = 0.f;
-#pragma unroll
-            for (int w = 0; w < AT_WAVES; ++w) {
-                const float e = (s_m[w] > -INFINITY) ? __expf(s_m[w] - m) : 0.f;
-                o = fmaf(e, s_o[w][tid], o);
-                l = fmaf(e, s_l[w], l);
+            for (int u = 0; u < 8; ++u) {
+                ml[u] = 0ull;
+                ov[u] = 0ull;
+                if (t0 + u < ns) {
+                    ml[u] = __hip_atomic_load(reinterpret_cast<unsigned long long*>(part_ml + pre + t0 + u),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (VPL == 2)
+                        ov[u] = __hip_atomic_load(
+                            reinterpret_cast<unsigned long long*>(part_o + (pre + t0 + u) * D + d0),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        ov[u] = __hip_atomic_load(
+                            reinterpret_cast<unsigned int*>(part_o + (pre + t0 + u) * D + d0),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
-            part_o[(int64_t)s * D + tid] = o;
-            if (tid == 0) part_ml[s] = make_float2(m, l);
-        }
-        __syncthreads();
-    }
-}
-
-// Merge the slice partials of each head: out = sum_s e^{m_s-m} o_s / Z, bf16 (RNE);
-// max_value_expsum[0][h] = m*log2e, [1][h] = log2 Z + m*log2e (softmax_kernel, .cc:238-239).
-template <int D>
-__global__ __launch_bounds__(D) void attn_merge_kernel(
-    const float* __restrict__ part_o, const float2* __restrict__ part_ml,
-    const int32_t* __restrict__ nnz, int BH, int64_t M, uint16_t* __restrict__ out,
-    float* __restrict__ mve, float2* __restrict__ head_mz) {
-    __shared__ int s_red[D / 64 + 1];
-    const int h = blockIdx.x, tid = threadIdx.x;
-    // slices before head h
-    int before = 0;
-    for (int hh = tid; hh < h; hh += D) before += slices_of(nnz[hh], M);
-    before = (int)wave_sum((float)before);  // exact: counts < 2^24
-    if ((tid & 63) == 0) s_red[tid >> 6] = before;
-    __syncthreads();
-    int pre = 0;
 #pragma unroll
-    for (int w = 0; w < D / 64; ++w) pre += s_red[w];
-    const int ns = slices_of(nnz[h], M);
-    float m = -INFINITY;
-    for (int s = 0; s < ns; ++s) m = fmaxf(m, part_ml[pre + s].x);
-    float o = 0.f, Z = 0.f;
-    for (int s = 0; s < ns; ++s) {
-        const float2 ml = part_ml[pre + s];
-        const float e = (ml.x > -INFINITY) ? __expf(ml.x - m) : 0.f;
-        o = fmaf(e, part_o[(int64_t)(pre + s) * D + tid], o);
-        Z = fmaf(e, ml.y, Z);
-    }
-    const bool empty = !(Z > 0.f);
-    out[(int64_t)h * D + tid] = empty ? (uint16_t)0 : f32_to_bf16_rne(o / Z);
-    if (tid == 0) {
-        const float mv = empty ? -INFINITY : m * 1.4426950408889634f;
-        mve[h] = mv;
-        mve[BH + h] = empty ? -INFINITY : (log2f(Z) + mv);
-        head_mz[h] = make_float2(m, Z);
+            for (int u = 0; u < 8; ++u) {
+                if (t0 + u < ns) {
+                    const float e = __expf(__uint_as_float((uint32_t)ml[u]) - m);
+                    Z = fmaf(e, __uint_as_float((uint32_t)(ml[u] >> 32)), Z);
+                    o0 = fmaf(e, __uint_as_float((uint32_t)ov[u]), o0);
+                    o1 = fmaf(e, __uint_as_float((uint32_t)(ov[u] >> 32)), o1);
+                }
+            }
+        }
+        // out = sum_s e^{m_s-m} o_s / Z as bf16 (RNE); max_value_expsum[0] = m*log2e,
+        // [1] = log2 Z + m*log2e (softmax_kernel, sparse_attention.cc:238-239)
+        if (VPL == 2) {
+            const uint32_t pk = (uint32_t)f32_to_bf16_rne(o0 / Z) | ((uint32_t)f32_to_bf16_rne(o1 / Z) << 16);
+            *reinterpret_cast<uint32_t*>(out + (int64_t)h * D + d0) = pk;
+        } else {
+            out[(int64_t)h * D + d0] = f32_to_bf16_rne(o0 / Z);
+        }
+        if (lane == 0) {
+            const float mv = m * 1.4426950408889634f;
+            mve[h] = mv;
+            mve[BH + h] = log2f(Z) + mv;
+            head_mz[h] = make_float2(m, Z);
+        }
+        MP_STAMP(stamp, 39);
     }
 }
 
@@ -350,38 +414,33 @@ __global__ void merge_state_kernel(const uint16_t* __restrict__ va, const float*
 }
 
 // ---------------------------------------------------------------- host launchers
-int64_t attn_max_slices(int BH, int64_t M) {
-    return (int64_t)BH * ((M + AT_SLICE - 1) / AT_SLICE + 1);
-}
+// partial records per head: one per 64-entry slice of the index list
+int attn_slices_per_head(int64_t M) { return (int)((M + 63) / 64); }
 
 int attn_supported_head_dim(int D) { return D == 64 || D == 128; }
 
 template <int D, bool DENSE, bool QBF16>
-static hipError_t launch_partial_t(const uint16_t* kv, const float* kn, const void* q,
-                                   const float* qn, const int32_t* ind, const int32_t* nnz,
-                                   float* part_o, float2* part_ml, float* score, int BH, int G,
-                                   int64_t M, int K, int L, int grid, hipStream_t st,
-                                   hipEvent_t ev0, hipEvent_t ev1) {
-    const size_t lds = (size_t)(BH + 1) * sizeof(int);
-    if (ev0 != nullptr)   // per-dispatch begin/end timestamps (bench.py roofline leg)
-        hipExtLaunchKernelGGL((attn_partial_kernel<D, DENSE, QBF16>), dim3(grid), dim3(AT_THREADS), lds,
-                              st, ev0, ev1, 0, kv, kn, q, qn, ind, nnz, part_o, part_ml, score, BH, G,
-                              M, K, L);
-    else
-        hipLaunchKernelGGL((attn_partial_kernel<D, DENSE, QBF16>), dim3(grid), dim3(AT_THREADS), lds,
-                           st, kv, kn, q, qn, ind, nnz, part_o, part_ml, score, BH, G, M, K, L);
+static hipError_t launch_sparse_t(const uint16_t* kv, const float* kn, const void* q, const float* qn,
+                                  const int32_t* ind, const int32_t* nnz, float* part_o,
+                                  float2* part_ml, int* head_cnt, uint16_t* out, float* mve,
+                                  float2* head_mz, float* score, int BH, int G, int64_t M, int K,
+                                  int L, int grid, hipStream_t st) {
+    const int maxs = attn_slices_per_head(M);
+    hipLaunchKernelGGL((attn_sparse_kernel<D, DENSE, QBF16>), dim3(grid, BH), dim3(AT_THREADS), 0, st,
+                       kv, kn, q, qn, ind, nnz, part_o, part_ml, head_cnt, out, mve, head_mz, score, BH,
+                       G, M, maxs, K, L, g_stamp);
     return hipGetLastError();
 }
 
-hipError_t launch_attn_partial(int D, bool dense, bool qbf16, const uint16_t* kv, const float* kn,
-                               const void* q, const float* qn, const int32_t* ind,
-                               const int32_t* nnz, float* part_o, float2* part_ml, float* score,
-                               int BH, int G, int64_t M, int K, int L, int grid, hipStream_t st,
-                               hipEvent_t ev0, hipEvent_t ev1) {
-#define MP_AT_CASE(DD, DE, QB)                                                                    \
-    if (D == DD && dense == DE && qbf16 == QB)                                                    \
-        return launch_partial_t<DD, DE, QB>(kv, kn, q, qn, ind, nnz, part_o, part_ml, score, BH, \
-                                            G, M, K, L, grid, st, ev0, ev1);
+hipError_t launch_attn_sparse(int D, bool dense, bool qbf16, const uint16_t* kv, const float* kn,
+                              const void* q, const float* qn, const int32_t* ind, const int32_t* nnz,
+                              float* part_o, float2* part_ml, int* head_cnt, uint16_t* out, float* mve,
+                              float2* head_mz, float* score, int BH, int G, int64_t M, int K, int L,
+                              int grid, hipStream_t st) {
+#define MP_AT_CASE(DD, DE, QB)                                                                     \
+    if (D == DD && dense == DE && qbf16 == QB)                                                     \
+        return launch_sparse_t<DD, DE, QB>(kv, kn, q, qn, ind, nnz, part_o, part_ml, head_cnt, out, \
+                                           mve, head_mz, score, BH, G, M, K, L, grid, st);
     MP_AT_CASE(128, false, true)
     MP_AT_CASE(128, false, false)
     MP_AT_CASE(128, true, true)
@@ -392,20 +451,6 @@ hipError_t launch_attn_partial(int D, bool dense, bool qbf16, const uint16_t* kv
     MP_AT_CASE(64, true, false)
 #undef MP_AT_CASE
     return hipErrorInvalidValue;
-}
-
-hipError_t launch_attn_merge(int D, const float* part_o, const float2* part_ml, const int32_t* nnz,
-                             int BH, int64_t M, uint16_t* out, float* mve, float2* head_mz,
-                             hipStream_t st) {
-    if (D == 128)
-        hipLaunchKernelGGL((attn_merge_kernel<128>), dim3(BH), dim3(128), 0, st, part_o, part_ml,
-                           nnz, BH, M, out, mve, head_mz);
-    else if (D == 64)
-        hipLaunchKernelGGL((attn_merge_kernel<64>), dim3(BH), dim3(64), 0, st, part_o, part_ml, nnz,
-                           BH, M, out, mve, head_mz);
-    else
-        return hipErrorInvalidValue;
-    return hipGetLastError();
 }
 
 hipError_t launch_attn_normalize(float* score, const int32_t* nnz, const float2* head_mz, int BH,

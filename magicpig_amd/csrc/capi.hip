@@ -27,19 +27,18 @@ hipError_t launch_lsh_retrieve(const int2*, const int32_t*, const int32_t*, int3
                                int, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_mask(const int2*, const int32_t*, const int32_t*, int8_t*, int, int, int, int,
                            int64_t, hipStream_t);
-int64_t attn_max_slices(int BH, int64_t M);
+int attn_slices_per_head(int64_t M);
 int attn_supported_head_dim(int D);
-hipError_t launch_attn_partial(int, bool, bool, const uint16_t*, const float*, const void*,
-                               const float*, const int32_t*, const int32_t*, float*, float2*,
-                               float*, int, int, int64_t, int, int, int, hipStream_t, hipEvent_t,
-                               hipEvent_t);
-hipError_t launch_attn_merge(int, const float*, const float2*, const int32_t*, int, int64_t,
-                             uint16_t*, float*, float2*, hipStream_t);
+hipError_t launch_attn_sparse(int, bool, bool, const uint16_t*, const float*, const void*, const float*,
+                              const int32_t*, const int32_t*, float*, float2*, int*, uint16_t*, float*,
+                              float2*, float*, int, int, int64_t, int, int, int, hipStream_t);
 hipError_t launch_attn_normalize(float*, const int32_t*, const float2*, int, int64_t, hipStream_t);
 hipError_t launch_attn_fill(const uint16_t*, const uint16_t*, const float*, int, int64_t, int,
                             int64_t, uint16_t*, float*, hipStream_t);
 hipError_t launch_merge_state(const uint16_t*, const float*, const uint16_t*, const float*, int,
                               int, uint16_t*, float*, hipStream_t);
+
+extern unsigned long long* g_stamp;
 
 // ---- error text (thread local)
 static thread_local std::string g_err;
@@ -119,15 +118,12 @@ struct mp_attn {
     float* part_o = nullptr;       // [max_slices][D]
     float2* part_ml = nullptr;     // [max_slices]
     float2* head_mz = nullptr;     // [BH] (max logit, Z) of the last call
+    int* head_cnt = nullptr;       // [BH] arrival tickets of the in-launch merge (zero between calls)
     int32_t* last_nnz = nullptr;   // [BH] staging copy of host-side nnz
     const int32_t* lastz = nullptr;// device nnz of the last call (for get_score): last_nnz or the
                                    // caller's own device buffer (valid until it changes)
     int score_state = 0;           // 0 none, 1 logits, 2 probabilities
-    int grid = 1024;               // persistent grid of the partial kernel
-    // optional per-dispatch timing of the dominant kernel (mp_attn_profile_*)
-    bool prof_on = false;
-    std::vector<hipEvent_t> prof_ev;   // (begin, end) pairs
-    size_t prof_used = 0;
+    int grid = 8;                  // workgroups per head of the partial kernel (grid.x)
 };
 
 extern "C" {
@@ -445,12 +441,10 @@ static void attn_free(mp_attn_t* h) {
     for (auto p : h->kn) if (p) (void)hipFree(p);
     h->kv.clear();
     h->kn.clear();
-    for (auto e : h->prof_ev) (void)hipEventDestroy(e);
-    h->prof_ev.clear();
-    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz};
+    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->score = nullptr; h->part_o = nullptr; h->part_ml = nullptr; h->head_mz = nullptr;
-    h->last_nnz = nullptr;
+    h->last_nnz = nullptr; h->head_cnt = nullptr;
     h->allocated = false;
 }
 
@@ -484,17 +478,18 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
         h->kv.push_back((uint16_t*)a);
         h->kn.push_back((float*)b);
     }
-    const size_t ms = (size_t)attn_max_slices((int)BH, h->M);
+    const size_t ms = (size_t)BH * attn_slices_per_head(h->M);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->score, BH * (size_t)h->M * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->part_o, ms * h->D * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->part_ml, ms * sizeof(float2));
     if (rc == MP_OK) rc = alloc_zero((void**)&h->head_mz, BH * sizeof(float2));
     if (rc == MP_OK) rc = alloc_zero((void**)&h->last_nnz, BH * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->head_cnt, BH * 4);
     if (rc != MP_OK) { attn_free(h); return rc; }
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-        h->grid = prop.multiProcessorCount * 4;
+    // GX workgroups (x 4 waves x 64 entries) per head cover ~3 % of max_length in one pass, i.e.
+    // 1.5x the reference's ~2 % sampling rate (README.md:43); longer lists take more passes.
+    h->grid = (int)((h->M + 256 * 32 - 1) / (256 * 32));
+    if (h->grid < 1) h->grid = 1;
     h->allocated = true;
     return MP_OK;
 }
@@ -528,17 +523,10 @@ static int attn_run(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint16
                     float* mve, const void* query, int query_dtype, const float* qn,
                     const int32_t* ind, const int32_t* nnz, hipStream_t st) {
     const int BH = h->B * h->H;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (h->prof_on && h->prof_used + 2 <= h->prof_ev.size()) {
-        ev0 = h->prof_ev[h->prof_used];
-        ev1 = h->prof_ev[h->prof_used + 1];
-        h->prof_used += 2;
-    }
-    MP_HIP_CHECK(launch_attn_partial(h->D, dense, query_dtype == MP_DTYPE_BF16, h->kv[layer_id],
-                                     h->kn[layer_id], query, qn, ind, nnz, h->part_o, h->part_ml,
-                                     h->score, BH, h->G, h->M, K, L, h->grid, st, ev0, ev1));
-    MP_HIP_CHECK(launch_attn_merge(h->D, h->part_o, h->part_ml, nnz, BH, h->M, output, mve,
-                                   h->head_mz, st));
+    MP_HIP_CHECK(launch_attn_sparse(h->D, dense, query_dtype == MP_DTYPE_BF16, h->kv[layer_id],
+                                    h->kn[layer_id], query, qn, ind, nnz, h->part_o, h->part_ml,
+                                    h->head_cnt, output, mve, h->head_mz, h->score, BH, h->G, h->M, K, L,
+                                    h->grid, st));
     h->lastz = nnz;
     h->score_state = 1;
     return MP_OK;
@@ -619,33 +607,10 @@ int mp_attn_clear(mp_attn_t* h, mp_stream_t stream) {
     return MP_OK;
 }
 
-// Measurement hooks (bench.py roofline leg; not part of the reference's interface): time every
-// launch of the dominant kernel (attn_partial_kernel) with HIP events bound to the dispatch
-// itself (hipExtLaunchKernel begin/end events on the launch stream).
-int mp_attn_profile_begin(mp_attn_t* h, int max_launches) {
-    MP_REQUIRE(h && h->allocated && max_launches > 0, MP_ERR_INVALID, "mp_attn_profile_begin: bad argument");
-    while (h->prof_ev.size() < (size_t)max_launches * 2) {
-        hipEvent_t e;
-        MP_HIP_CHECK(hipEventCreate(&e));
-        h->prof_ev.push_back(e);
-    }
-    h->prof_used = 0;
-    h->prof_on = true;
-    return MP_OK;
-}
-
-int mp_attn_profile_end(mp_attn_t* h, float* ms_out, int cap, int* n_out) {
-    MP_REQUIRE(h && ms_out && n_out, MP_ERR_INVALID, "mp_attn_profile_end: bad argument");
-    h->prof_on = false;
-    int n = 0;
-    for (size_t i = 0; i + 1 < h->prof_used && n < cap; i += 2) {
-        MP_HIP_CHECK(hipEventSynchronize(h->prof_ev[i + 1]));
-        float ms = 0.f;
-        MP_HIP_CHECK(hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
-        ms_out[n++] = ms;
-    }
-    *n_out = n;
-    h->prof_used = 0;
+// Debug: device buffer (>= 64 u64) receiving 100 MHz wall-clock stamps at the phase boundaries of
+// workgroup 0 of the hot kernels (slots: simhash 0-3, retrieve 16-21, attention 32-38); NULL = off.
+int mp_debug_set_stamp_buffer(void* dev_u64x64) {
+    g_stamp = reinterpret_cast<unsigned long long*>(dev_u64x64);
     return MP_OK;
 }
 

@@ -49,6 +49,15 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// ---------------------------------------------------------------- debug phase timestamps
+// stamp == nullptr in production; set through mp_debug_set_stamp_buffer (scripts/phase_times.py).
+// One lane of workgroup 0 records the 100 MHz wall clock at phase boundaries.
+#define MP_STAMP(stamp, slot)                                                               \
+    do {                                                                                    \
+        if ((stamp) != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)   \
+            (stamp)[(slot)] = wall_clock64();                                               \
+    } while (0)
+
 // ---------------------------------------------------------------- wave / block primitives
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 

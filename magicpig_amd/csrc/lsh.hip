@@ -14,16 +14,21 @@
 // (A = seen once, B = seen twice or more; 2*M/8 bytes = 24.6 KB at M = 98304), bucket ids are
 // streamed with coalesced 256-byte wave loads and applied with LDS atomics (ds_or_rtn_b32),
 // and the result is emitted by a popcount sweep of B with a block-wide prefix sum, i.e. in
+// (byte counters with non-returning ds_add were measured and lost: the 96 KB sweep costs more
+// than the returning atomics; the phase is bound by streaming ~64 KB of ids through one CU)
 // ASCENDING token order (the reference emits second-hit order; only set + nnz are defined,
 // library/lsh/test.py:43-56).
 #include "common.h"
 
 namespace mp {
 
+extern unsigned long long* g_stamp;   // simhash.hip
+
 constexpr int RT_THREADS = 1024;           // 16 waves: one workgroup per query head
 constexpr int RT_WAVES = RT_THREADS / 64;
-constexpr int RT_CHUNK_CAP = 4096;         // (bucket, 64-id chunk) descriptors per pass
-constexpr int RT_UNROLL = 16;              // global loads in flight per wave
+constexpr int RT_GROUP = 12;               // buckets in flight per wave per round (x 2 chunks of 64 ids)
+constexpr int RT_TAIL_CAP = 2048;          // pooled chunk descriptors for ids beyond 128 per bucket
+constexpr int RT_TAIL_UNROLL = 8;
 
 // ---------------------------------------------------------------- LSH::fill
 // grid = Hkv*L rows of one request; one workgroup per (kv head, table) row.
@@ -138,18 +143,20 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
 
 // ---------------------------------------------------------------- LSH::batch_retrieve
 // grid = B*H (one workgroup per query head), block = 1024, dynamic LDS:
-//   A[words] | B[words] | s_start[Lpad] | s_len[Lpad] | s_chunk[RT_CHUNK_CAP] | s_tmp[32]
+//   A[words] | B[words] | s_start[Lpad] | s_len[Lpad] | s_tail[RT_TAIL_CAP] | s_tmp[32] | s_ntail
+// `words` = ceil(M/32) words per bitmap.
 __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
     const int2* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
-    int G, int L, int NB, int64_t M, int words, int Lpad) {
-    extern __shared__ uint32_t s_u32[];
+    int G, int L, int NB, int64_t M, int words, int Lpad, unsigned long long* __restrict__ stamp) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_u32[];
     uint32_t* bmA = s_u32;
     uint32_t* bmB = s_u32 + words;
     int* s_start = reinterpret_cast<int*>(s_u32 + 2 * words);
     int* s_len = s_start + Lpad;
-    uint32_t* s_chunk = reinterpret_cast<uint32_t*>(s_len + Lpad);
-    int* s_tmp = reinterpret_cast<int*>(s_chunk + RT_CHUNK_CAP);
+    uint32_t* s_tail = reinterpret_cast<uint32_t*>(s_len + Lpad);   // (table << 16 | chunk) of ids beyond 128
+    int* s_tmp = reinterpret_cast<int*>(s_tail + RT_TAIL_CAP);
+    int* s_ntail = s_tmp + 32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t h = blockIdx.x;
@@ -157,6 +164,9 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
     const int2* bnd = bounds + g * L * NB;
     const int32_t* tab = table + g * L * M;
 
+    MP_STAMP(stamp, 16);
+    if (tid == 0) *s_ntail = 0;
+    __syncthreads();
     // probe: one 8-byte random read per table (issued first: longest latency)
     for (int l = tid; l < Lpad; l += RT_THREADS) {
         int st = 0, len = 0;
@@ -171,68 +181,90 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
         }
         s_start[l] = st;
         s_len[l] = len;
+        if (len > 128) {   // 64-id chunks beyond the first two go to a shared pool (skewed buckets)
+            const int nch = (len - 128 + 63) >> 6;
+            const int base = atomicAdd(s_ntail, nch);
+            for (int c = 0; c < nch && base + c < RT_TAIL_CAP; ++c)
+                s_tail[base + c] = ((uint32_t)l << 16) | (uint32_t)(c + 2);
+        }
     }
     for (int i = tid; i < 2 * words; i += RT_THREADS) s_u32[i] = 0u;
     __syncthreads();
+    MP_STAMP(stamp, 17);
+    MP_STAMP(stamp, 18);
 
-    // chunk descriptors: bucket l contributes ceil(len/64) chunks; descriptor = l << 16 | chunk
-    // (buckets longer than 64*65536 ids cannot occur: M <= 2^22 is enforced at alloc)
-    int my_chunks = 0;
-    for (int l = tid; l < Lpad; l += RT_THREADS) my_chunks += (s_len[l] + 63) >> 6;
-    int total_chunks;
-    int my_base = block_excl_scan(my_chunks, s_tmp, total_chunks);
-    // note: with L <= RT_THREADS each thread owns at most one table; the loop form keeps
-    // larger L correct (a thread's tables are then non-adjacent but descriptors need no order)
-    for (int pass0 = 0; pass0 < total_chunks; pass0 += RT_CHUNK_CAP) {
-        int cur = my_base;
-        for (int l = tid; l < Lpad; l += RT_THREADS) {
-            const int nc = (s_len[l] + 63) >> 6;
-            for (int c = 0; c < nc; ++c) {
-                const int slot = cur + c - pass0;
-                if (slot >= 0 && slot < RT_CHUNK_CAP) s_chunk[slot] = ((uint32_t)l << 16) | (uint32_t)c;
-            }
-            cur += nc;
+    // stream the probed buckets: wave w owns tables w, w+16, ...; per round it keeps RT_GROUP
+    // buckets x 2 chunks of 64 ids (<= 128 ids per bucket) in flight, then applies them
+    auto apply = [&](int32_t t) {
+        if (t >= 0 && (int64_t)t < M) {
+            const uint32_t bit = 1u << (t & 31);
+            const uint32_t old = atomicOr(&bmA[t >> 5], bit);           // first hit: 0 -> 1
+            if (old & bit) atomicOr(&bmB[t >> 5], bit);                 // any later hit: -> 2
         }
-        __syncthreads();
-        const int nchunk = min(RT_CHUNK_CAP, total_chunks - pass0);
-        // each wave streams chunks wave, wave+16, ... with RT_UNROLL loads in flight
-        for (int c0 = wave; c0 < nchunk; c0 += RT_WAVES * RT_UNROLL) {
-            int32_t id[RT_UNROLL];
+    };
+    for (int l0 = wave; l0 < L; l0 += RT_WAVES * RT_GROUP) {
+        int32_t id0[RT_GROUP], id1[RT_GROUP];
 #pragma unroll
-            for (int u = 0; u < RT_UNROLL; ++u) {
+        for (int b = 0; b < RT_GROUP; ++b) {
+            const int l = l0 + b * RT_WAVES;
+            id0[b] = -1;
+            id1[b] = -1;
+            if (l < L) {
+                const int len = s_len[l];
+                const int32_t* row = tab + (int64_t)l * M + s_start[l];
+                if (lane < len) id0[b] = row[lane];
+                if (lane + 64 < len) id1[b] = row[lane + 64];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < RT_GROUP; ++b) {
+            apply(id0[b]);
+            apply(id1[b]);
+        }
+    }
+    // ids beyond the first 128 of a bucket (skewed data): pooled 64-id chunks, waves take them
+    // round-robin with RT_TAIL_UNROLL loads in flight
+    const int ntail = __builtin_amdgcn_readfirstlane(*s_ntail);
+    if (ntail <= RT_TAIL_CAP) {
+        for (int c0 = wave; c0 < ntail; c0 += RT_WAVES * RT_TAIL_UNROLL) {
+            int32_t idt[RT_TAIL_UNROLL];
+#pragma unroll
+            for (int u = 0; u < RT_TAIL_UNROLL; ++u) {
                 const int c = c0 + u * RT_WAVES;
-                id[u] = -1;
-                if (c < nchunk) {
-                    const uint32_t d = s_chunk[c];
+                idt[u] = -1;
+                if (c < ntail) {
+                    const uint32_t d = s_tail[c];
                     const int l = d >> 16, j = ((d & 0xffffu) << 6) + lane;
-                    if (j < s_len[l]) id[u] = tab[(int64_t)l * M + s_start[l] + j];
+                    if (j < s_len[l]) idt[u] = tab[(int64_t)l * M + s_start[l] + j];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < RT_UNROLL; ++u) {
-                const int32_t t = id[u];
-                if (t >= 0 && t < M) {
-                    const uint32_t bit = 1u << (t & 31);
-                    const uint32_t old = atomicOr(&bmA[t >> 5], bit);       // first hit: 0 -> 1
-                    if (old & bit) atomicOr(&bmB[t >> 5], bit);             // any later hit: -> 2
-                }
-            }
+            for (int u = 0; u < RT_TAIL_UNROLL; ++u) apply(idt[u]);
         }
-        __syncthreads();
+    } else {   // pool overflow (> 128 K extra ids per head): plain strided sweep of every long bucket
+        for (int l = 0; l < L; ++l) {
+            const int len = s_len[l];
+            if (len <= 128) continue;
+            const int32_t* row = tab + (int64_t)l * M + s_start[l];
+            for (int j = 128 + tid; j < len; j += RT_THREADS) apply(row[j]);
+        }
     }
     __syncthreads();
+    MP_STAMP(stamp, 19);
 
     // sweep B: contiguous words per thread, block-wide exclusive scan, ascending emission
-    const int wpt = (words + RT_THREADS - 1) / RT_THREADS;
-    const int w0 = tid * wpt;
     int cnt = 0;
+    int32_t* out = results + h * M;
+    const int nsw = words;
+    const int wpt = (nsw + RT_THREADS - 1) / RT_THREADS;
+    const int w0 = tid * wpt;
     for (int k = 0; k < wpt; ++k)
-        if (w0 + k < words) cnt += __popc(bmB[w0 + k]);
+        if (w0 + k < nsw) cnt += __popc(bmB[w0 + k]);
     int total;
     int off = block_excl_scan(cnt, s_tmp, total);
-    int32_t* out = results + h * M;
+    MP_STAMP(stamp, 20);
     for (int k = 0; k < wpt; ++k) {
-        if (w0 + k >= words) break;
+        if (w0 + k >= nsw) break;
         uint32_t bits = bmB[w0 + k];
         const int base = (w0 + k) << 5;
         while (bits) {
@@ -242,6 +274,7 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
         }
     }
     if (tid == 0) nnz[h] = total;
+    MP_STAMP(stamp, 21);
 }
 
 // ---------------------------------------------------------------- LSH::get_mask (debug view)
@@ -273,9 +306,8 @@ __global__ __launch_bounds__(256) void lsh_mask_kernel(
 
 // ---------------------------------------------------------------- host launchers
 size_t retrieve_lds_bytes(int64_t M, int L) {
-    const int words = (int)((M + 31) / 32);
     const int Lpad = (L + 63) & ~63;
-    return (size_t)(2 * words + 2 * Lpad + RT_CHUNK_CAP + 64) * 4;
+    return (size_t)(2 * ((M + 31) / 32) + 2 * Lpad + RT_TAIL_CAP + 64) * 4;
 }
 
 hipError_t launch_lsh_fill(const int16_t* codes, const int32_t* ids, int rows, int64_t n, int NB,
@@ -307,7 +339,7 @@ hipError_t launch_lsh_retrieve(const int2* bounds, const int32_t* table, const i
         attr_done = true;
     }
     hipLaunchKernelGGL(lsh_retrieve_kernel, dim3(BH), dim3(RT_THREADS), lds, st, bounds, table,
-                       query, results, nnz, G, L, NB, M, words, Lpad);
+                       query, results, nnz, G, L, NB, M, words, Lpad, g_stamp);
     return hipGetLastError();
 }
 

@@ -6,7 +6,7 @@
 // in LDS, B = pre-transposed hyperplanes Wt[K*L][D] read as one 16-byte load per lane.
 //
 // Bit-exactness: the sign of an f32-accumulated dot product is order-dependent only when
-// |S| is within rounding of zero.  Every |acc| <= EPS * ||x|| * ||w|| (Cauchy-Schwarz bound
+// |S| is within rounding of zero.  Every |acc| <= 2^-15 * ||x|| * ||w|| (Cauchy-Schwarz bound
 // on sum|x_i w_i|, EPS far above the f32 accumulation error) is recomputed exactly in f64
 // (products of two bf16 are exact in f64), so the emitted bit is the exact sign, which is
 // the order-independent definition the parity tests check against.
@@ -14,12 +14,10 @@
 
 namespace mp {
 
-constexpr int SH_THREADS = 256;          // 4 waves
 constexpr int SH_ROWS = 32;              // MFMA M
-constexpr int SH_MAXD = 256;             // max head_dim (LDS row)
-constexpr int SH_LDS_STRIDE = SH_MAXD + 8;  // +16 B pad: conflict-free ds_read_b128 across rows
 constexpr int SH_MAX_TILES = 16;         // max 32-column tiles per workgroup
-constexpr float SH_EPS = 1.0f / 4096.0f; // guard band (2^-12) relative to ||x||*||w||
+constexpr float SH_EPS = 1.0f / 32768.0f; // guard band (2^-15) relative to ||x||*||w||; the measured
+                                          // MFMA accumulation error is < 2^-20 (tests/test_gpu_parity.py)
 
 // Transpose hash_func [D][KL] -> Wt [KLpad][D] (zero rows beyond KL) and column norms.
 __global__ void simhash_prepare_kernel(const uint16_t* __restrict__ W, int D, int KL, int KLpad,
@@ -39,14 +37,20 @@ __global__ void simhash_prepare_kernel(const uint16_t* __restrict__ W, int D, in
 // MODE 0: query rows -- L2-normalise in bf16 exactly as torch does (attnserver.py:264-266),
 //         codes int32 [R][L], optional qnorm f32 [R].
 // MODE 1: key rows   -- no normalisation (attnserver.py:162), codes int16 [L][n] (transposed).
-template <int MODE>
-__global__ __launch_bounds__(SH_THREADS) void simhash_kernel(
+// Block = 64 * max(4, tiles_per_wg) threads: wave w owns column tile w of the workgroup's span
+// and prefetches its B fragments (the hyperplanes) before the rows are staged, so the HBM/L2
+// latency of the planes overlaps the normalisation.
+template <int MODE, int D>
+__global__ __launch_bounds__(1024) void simhash_kernel(
     const uint16_t* __restrict__ x,      // [R][D] bf16
     const uint16_t* __restrict__ Wt,     // [KLpad][D] bf16
     const float* __restrict__ wnorm,     // [KLpad]
-    int64_t R, int D, int K, int L, int tables_per_wg, int tiles_per_wg, int64_t ld_out,
-    void* __restrict__ codes_out, float* __restrict__ qnorm, float* __restrict__ dbg_acc) {
-    __shared__ __attribute__((aligned(16))) uint16_t s_x[SH_ROWS * SH_LDS_STRIDE];
+    int64_t R, int K, int L, int tables_per_wg, int tiles_per_wg, int64_t ld_out,
+    void* __restrict__ codes_out, float* __restrict__ qnorm, float* __restrict__ dbg_acc,
+    unsigned long long* __restrict__ stamp) {
+    constexpr int KSTEPS = D / 16;
+    constexpr int STRIDE = D + 8;        // +16 B pad: conflict-free ds_read_b128 across rows
+    __shared__ __attribute__((aligned(16))) uint16_t s_x[SH_ROWS * STRIDE];
     __shared__ float s_rn[SH_ROWS];
     __shared__ uint32_t s_bits[SH_ROWS][SH_MAX_TILES + 1];
 
@@ -55,99 +59,154 @@ __global__ __launch_bounds__(SH_THREADS) void simhash_kernel(
     const int table0 = blockIdx.x * tables_per_wg;
     const int col0 = table0 * K;
     const int KL = K * L;
+    MP_STAMP(stamp, 0);
+
+    // ---- prefetch this wave's hyperplane fragments (B operand): 16 B per lane per k-step
+    const bool has_tile = wave < tiles_per_wg;
+    const int n = col0 + wave * 32 + (lane & 31);        // this lane's hyperplane (B column)
+    bf16x8 bfrag[KSTEPS];
+    float wn = 0.f;
+    if (has_tile) {
+        const uint16_t* wrow = Wt + (int64_t)n * D + (lane >> 5) * 8;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) bfrag[kk] = *reinterpret_cast<const bf16x8*>(wrow + kk * 16);
+        wn = wnorm[n] * SH_EPS;
+    }
 
     // ---- phase A: stage 32 rows (normalised for MODE 0) into LDS; 8 threads per row
-    {
+    if (tid < SH_ROWS * 8) {
+        constexpr int PER = D / 8;       // elements per thread: 8, 16 or 32
         const int row = tid >> 3, part = tid & 7;
         const int64_t gr = r0 + row;
-        const int per = D >> 3;  // elements per thread (D multiple of 16 -> per multiple of 2)
-        const uint16_t* src = x + gr * D + part * per;
-        double ss = 0.0;
-        if (gr < R)
-            for (int i = 0; i < per; ++i) {
-                double v = (double)bf16_bits_to_f32(src[i]);
-                ss += v * v;  // exact: squares of bf16 fit f64, so the sum is order-free
+        uint16_t e[PER];
+        if (gr < R) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(x + gr * D + part * PER);
+#pragma unroll
+            for (int v = 0; v < PER / 8; ++v) {
+                const u32x4 t = src[v];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    e[v * 8 + 2 * i] = (uint16_t)(t[i] & 0xffffu);
+                    e[v * 8 + 2 * i + 1] = (uint16_t)(t[i] >> 16);
+                }
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) e[i] = 0;
+        }
+        double ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const double v = (double)bf16_bits_to_f32(e[i]);
+            ss += v * v;                 // exact: squares of bf16 fit f64, so the sum is order-free
+        }
         ss += __shfl_xor(ss, 1);
         ss += __shfl_xor(ss, 2);
         ss += __shfl_xor(ss, 4);
-        double ssn = 0.0;  // sum of squares of what goes to LDS (for the guard bound)
+        double ssn = ss;                 // sum of squares of what goes to LDS (guard bound)
         if (MODE == 0) {
-            const float nrm = (float)sqrt((double)(float)ss);     // == sqrtf(f32 sum), correctly rounded
-            const float nb = bf16_bits_to_f32(f32_to_bf16_rne(nrm));  // torch: bf16 norm tensor
+            const float nrm = (float)sqrt((double)(float)ss);         // == sqrtf(f32 sum), correctly rounded
+            const float nb = bf16_bits_to_f32(f32_to_bf16_rne(nrm));  // torch: the norm is a bf16 tensor
             if (qnorm != nullptr && blockIdx.x == 0 && part == 0 && gr < R) qnorm[gr] = nrm;
-            for (int i = 0; i < per; ++i) {
-                uint16_t o = 0;
-                if (gr < R) {
-                    // f32 division, correctly rounded (f64 divide + round: p >= 2q+2), then RNE to bf16
-                    const float qv = (float)((double)bf16_bits_to_f32(src[i]) / (double)nb);
-                    o = f32_to_bf16_rne(qv);
-                }
-                s_x[row * SH_LDS_STRIDE + part * per + i] = o;
-                double v = (double)bf16_bits_to_f32(o);
+            ssn = 0.0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                // IEEE f32 division (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt),
+                // then RNE to bf16 -- what torch's bf16 `q / norm` computes
+                const float qv = __fdiv_rn(bf16_bits_to_f32(e[i]), nb);
+                e[i] = (gr < R) ? f32_to_bf16_rne(qv) : (uint16_t)0;
+                const double v = (double)bf16_bits_to_f32(e[i]);
                 ssn += v * v;
             }
             ssn += __shfl_xor(ssn, 1);
             ssn += __shfl_xor(ssn, 2);
             ssn += __shfl_xor(ssn, 4);
-        } else {
-            for (int i = 0; i < per; ++i)
-                s_x[row * SH_LDS_STRIDE + part * per + i] = (gr < R) ? src[i] : (uint16_t)0;
-            ssn = ss;
+        }
+        u32x4* dst = reinterpret_cast<u32x4*>(s_x + row * STRIDE + part * PER);
+#pragma unroll
+        for (int v = 0; v < PER / 8; ++v) {
+            u32x4 t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                t[i] = (uint32_t)e[v * 8 + 2 * i] | ((uint32_t)e[v * 8 + 2 * i + 1] << 16);
+            dst[v] = t;
         }
         if (part == 0) s_rn[row] = (float)sqrt(ssn) * 1.000001f;
     }
     __syncthreads();
+    MP_STAMP(stamp, 1);
 
-    // ---- phase B: MFMA tiles, sign bits by ballot
-    const int ksteps = D >> 4;
-    for (int ct = wave; ct < tiles_per_wg; ct += SH_THREADS / 64) {
-        const int n = col0 + ct * 32 + (lane & 31);       // this lane's hyperplane (B column)
-        const uint16_t* wrow = Wt + (int64_t)n * D + (lane >> 5) * 8;
-        const uint16_t* arow = s_x + (lane & 31) * SH_LDS_STRIDE + (lane >> 5) * 8;
+    // ---- phase B: one 32x32 MFMA tile per wave, sign bits by ballot
+    if (has_tile) {
+        const uint16_t* arow = s_x + (lane & 31) * STRIDE + (lane >> 5) * 8;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        for (int kk = 0; kk < ksteps; ++kk) {
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + kk * 16);
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wrow + kk * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[kk], acc, 0, 0, 0);
         }
-        const float wn = wnorm[n] * SH_EPS;
+        uint32_t nearmask = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);  // C/D layout of 32x32 MFMA
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);  // C/D layout of the 32x32 MFMA
             const float a = acc[i];
-            bool bit = a > 0.f;
             if (dbg_acc != nullptr && r0 + row < R && n < KL) dbg_acc[(r0 + row) * KL + n] = a;
-            // guard band: exact recomputation, wave-cooperative (rare)
-            // (zero-padded planes / rows give acc == bound == 0: they are not candidates)
+            // guard band candidates; zero-padded planes / rows (acc == bound == 0) are not
             const bool near = (n < KL) && (r0 + row < R) && fabsf(a) <= wn * s_rn[row];
-            unsigned long long m = __ballot(near);
-            while (m) {
-                const int src = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int rs = __shfl(row, src);
-                const int ns = __shfl(n, src);
-                double part = 0.0;
-                for (int d = lane; d < D; d += 64)
-                    part += (double)bf16_bits_to_f32(s_x[rs * SH_LDS_STRIDE + d]) *
-                            (double)bf16_bits_to_f32(Wt[(int64_t)ns * D + d]);
-                const double tot = wave_sum(part);
-                if (lane == src) bit = tot > 0.0;
-            }
-            const unsigned long long bm = __ballot(bit);
+            nearmask |= (uint32_t)near << i;
+            const unsigned long long bm = __ballot(a > 0.f);
             if (lane == 0) {
-                s_bits[(i & 3) + 8 * (i >> 2)][ct] = (uint32_t)bm;
-                s_bits[(i & 3) + 8 * (i >> 2) + 4][ct] = (uint32_t)(bm >> 32);
+                s_bits[(i & 3) + 8 * (i >> 2)][wave] = (uint32_t)bm;
+                s_bits[(i & 3) + 8 * (i >> 2) + 4][wave] = (uint32_t)(bm >> 32);
+            }
+        }
+        // exact fix-up of the candidates (rare, rolled loops: keeps the hot code small).  Column
+        // n's k-values are split between lanes l and l^32, so every flagged element is redone by
+        // its own lane pair: f64 products of bf16 pairs are exact, one shuffle joins the halves,
+        // and the lane patches its bit in LDS.
+        if (__ballot(nearmask != 0)) {
+            const uint16_t* wcol = Wt + (int64_t)n * D + (lane >> 5) * 8;
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                const bool near = (nearmask >> i) & 1u;
+                if (!__ballot(near)) continue;                                   // wave-uniform
+                const bool partner_near = __shfl_xor((int)near, 32) != 0;
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const int prow = (i & 3) + 8 * (i >> 2) + 4 * ((lane >> 5) ^ 1);  // partner's row
+                double mine = 0.0, forp = 0.0;
+                if (near || partner_near) {
+                    const uint16_t* xm = s_x + row * STRIDE + (lane >> 5) * 8;
+                    const uint16_t* xp = s_x + prow * STRIDE + (lane >> 5) * 8;
+#pragma unroll
+                    for (int kk = 0; kk < KSTEPS; ++kk) {
+                        const u32x4 w = *reinterpret_cast<const u32x4*>(wcol + kk * 16);
+                        const u32x4 a = *reinterpret_cast<const u32x4*>(xm + kk * 16);
+                        const u32x4 p = *reinterpret_cast<const u32x4*>(xp + kk * 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const double wl = (double)bf16_lo(w[j]), wh = (double)bf16_hi(w[j]);
+                            mine += (double)bf16_lo(a[j]) * wl + (double)bf16_hi(a[j]) * wh;
+                            forp += (double)bf16_lo(p[j]) * wl + (double)bf16_hi(p[j]) * wh;
+                        }
+                    }
+                }
+                const double other = __shfl_xor(forp, 32);                       // partner's half for MY row
+                if (near) {
+                    uint32_t* wd = &s_bits[row][wave];
+                    const uint32_t bmask = 1u << (lane & 31);
+                    if (mine + other > 0.0) atomicOr(wd, bmask); else atomicAnd(wd, ~bmask);
+                }
             }
         }
     }
     __syncthreads();
+    MP_STAMP(stamp, 2);
 
     // ---- phase C: K-bit pack (bit i of code l <- column l*K + i), coalesced stores
-    const uint32_t kmask = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
-    for (int p = tid; p < SH_ROWS * tables_per_wg; p += SH_THREADS) {
+    const uint32_t kmask = (1u << K) - 1u;
+    for (int p = tid; p < SH_ROWS * tables_per_wg; p += blockDim.x) {
         int row, tb;
         if (MODE == 0) { row = p / tables_per_wg; tb = p % tables_per_wg; }   // codes[r][l]: l fastest
         else           { tb = p / SH_ROWS;        row = p % SH_ROWS; }        // codes[l][t]: t fastest
@@ -161,6 +220,7 @@ __global__ __launch_bounds__(SH_THREADS) void simhash_kernel(
         if (MODE == 0) reinterpret_cast<int32_t*>(codes_out)[gr * ld_out + l] = (int32_t)v;
         else           reinterpret_cast<int16_t*>(codes_out)[(int64_t)l * ld_out + gr] = (int16_t)v;
     }
+    MP_STAMP(stamp, 3);
 }
 
 // ---------------------------------------------------------------- host launchers
@@ -187,7 +247,7 @@ int simhash_padded_cols(int K, int L) {
 int simhash_supported(int D, int K) {
     int tp, tiles;
     simhash_geometry(K, tp, tiles);
-    return D >= 16 && D <= SH_MAXD && (D % 16) == 0 && K >= 1 && K <= 15 && tiles <= SH_MAX_TILES;
+    return (D == 64 || D == 128 || D == 256) && K >= 1 && K <= 15 && tiles <= SH_MAX_TILES;
 }
 
 hipError_t launch_simhash_prepare(const uint16_t* W, int D, int K, int L, uint16_t* Wt,
@@ -198,34 +258,48 @@ hipError_t launch_simhash_prepare(const uint16_t* W, int D, int K, int L, uint16
     return hipGetLastError();
 }
 
+unsigned long long* g_stamp = nullptr;   // debug phase-timestamp sink (mp_debug_set_stamp_buffer)
+
+template <int MODE>
+static hipError_t launch_simhash_t(const uint16_t* x, const uint16_t* Wt, const float* wnorm,
+                                   int64_t R, int D, int K, int L, int64_t ld_out, void* codes,
+                                   float* qnorm, float* dbg, unsigned grid_y, hipStream_t st) {
+    int tp, tiles;
+    simhash_geometry(K, tp, tiles);
+    dim3 grid((L + tp - 1) / tp, grid_y);
+    dim3 block(64 * (tiles > 4 ? tiles : 4));
+    unsigned long long* stamp = (MODE == 0) ? g_stamp : nullptr;
+#define MP_SH_CASE(DD)                                                                          \
+    if (D == DD) {                                                                              \
+        hipLaunchKernelGGL((simhash_kernel<MODE, DD>), grid, block, 0, st, x, Wt, wnorm, R, K, L, \
+                           tp, tiles, ld_out, codes, qnorm, dbg, stamp);                        \
+        return hipGetLastError();                                                               \
+    }
+    MP_SH_CASE(128)
+    MP_SH_CASE(64)
+    MP_SH_CASE(256)
+#undef MP_SH_CASE
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_simhash_query(const uint16_t* q, const uint16_t* Wt, const float* wnorm, int R,
                                 int D, int K, int L, int32_t* codes, float* qnorm, float* dbg,
                                 hipStream_t st) {
-    int tp, tiles;
-    simhash_geometry(K, tp, tiles);
-    dim3 grid((L + tp - 1) / tp, (R + SH_ROWS - 1) / SH_ROWS);
-    hipLaunchKernelGGL(simhash_kernel<0>, grid, dim3(SH_THREADS), 0, st, q, Wt, wnorm, (int64_t)R,
-                       D, K, L, tp, tiles, (int64_t)L, (void*)codes, qnorm, dbg);
-    return hipGetLastError();
+    return launch_simhash_t<0>(q, Wt, wnorm, R, D, K, L, L, (void*)codes, qnorm, dbg,
+                               (unsigned)((R + SH_ROWS - 1) / SH_ROWS), st);
 }
 
 // one kv head: keys [n][D] -> codes int16 [L][n]
 hipError_t launch_simhash_keys(const uint16_t* keys, const uint16_t* Wt, const float* wnorm,
                                int64_t n, int D, int K, int L, int16_t* codes, hipStream_t st) {
-    int tp, tiles;
-    simhash_geometry(K, tp, tiles);
     const int64_t row_tiles = (n + SH_ROWS - 1) / SH_ROWS;
-    // gridDim.y is limited to 65535: chunk the token axis
-    const int64_t max_y = 65535;
+    const int64_t max_y = 65535;   // gridDim.y limit: chunk the token axis
     for (int64_t t0 = 0; t0 < row_tiles; t0 += max_y) {
         const int64_t ny = (row_tiles - t0 < max_y) ? (row_tiles - t0) : max_y;
         const int64_t off = t0 * SH_ROWS;
-        dim3 grid((L + tp - 1) / tp, (unsigned)ny);
         // codes are [L][n]: row stride n (ld_out), pointers offset by `off` tokens
-        hipLaunchKernelGGL(simhash_kernel<1>, grid, dim3(SH_THREADS), 0, st, keys + off * D, Wt,
-                           wnorm, n - off, D, K, L, tp, tiles, n, (void*)(codes + off), (float*)nullptr,
-                           (float*)nullptr);
-        hipError_t e = hipGetLastError();
+        hipError_t e = launch_simhash_t<1>(keys + off * D, Wt, wnorm, n - off, D, K, L, n,
+                                           (void*)(codes + off), nullptr, nullptr, (unsigned)ny, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

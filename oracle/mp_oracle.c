@@ -263,10 +263,15 @@ static inline float ref_poly_exp(float x) {
  * key/value: bf16 [M, D] of the head's kv group; kn: f32 [M]; q: f32 [D] (already widened);
  * ind: int32 [>= nnz]; score: f32 scratch [>= nnz] -> probabilities (== get_score());
  * out: bf16 [D]; mv/es: scalars of max_value_expsum rows 0/1.
- * exp_mode 0: exact expf everywhere (the oracle proper).
- * exp_mode 1: the reference's polynomial exp on the first 16*floor(nnz/16) elements and expf
- *             on the tail (sparse_attention.cc:200-222) -- used only to pin this restatement
+ * exp_mode bit 0 clear: exact expf everywhere (the oracle proper).
+ * exp_mode bit 0 set  : the reference's polynomial exp on the first 16*floor(nnz/16) elements and
+ *             expf on the tail (sparse_attention.cc:200-222) -- used only to pin this restatement
  *             tightly against oracle/_ref.
+ * exp_mode bit 1 set  : the importance weight w is evaluated in binary64 without cancellation
+ *             (w = -expm1((L-1) log1p(-p) + log1p((L-1) p))) instead of the reference's literal
+ *             f32 expression (.cc:176-181), whose subtraction from 1 carries ~1e-7 absolute noise,
+ *             i.e. up to ~1e-3 relative noise in w + 1e-4.  Used to separate that inherent noise of
+ *             the reference formula from kernel error in the parity tests.
  * clamp_cos 1: clamp cos to [-1,1] before acosf (the reference does not, .cc:177: NaN when
  *             a bf16-rounded norm makes cos > 1).  The HIP path clamps.
  */
@@ -289,6 +294,12 @@ static void sparse_attention_head(const uint16_t* key, const uint16_t* value, co
         if (clamp_cos) c = fminf(1.f, fmaxf(-1.f, c));
         const float theta = acosf(c);
         const float proba = (float)(1 - theta / M_PI);
+        if (exp_mode & 2) {
+            const double pd = pow((double)proba, (double)K);
+            const double wd = -expm1((L - 1) * log1p(-pd) + log1p((L - 1) * pd));
+            score[j] = (float)((double)score[j] / sqrt((double)D) - log(wd + 1e-4));
+            continue;
+        }
         const float p = powf(proba, (float)K);
         const float qq = 1 - p;
         const float w = 1 - powf(qq, (float)(L - 1)) * (L * p + qq);
@@ -305,8 +316,8 @@ static void sparse_attention_head(const uint16_t* key, const uint16_t* value, co
     float m = score[0];
     for (int64_t j = 1; j < nnz; ++j) m = fmaxf(m, score[j]);
     float sum = 0.f;
-    const int64_t vec_end = (exp_mode == 1) ? (nnz / 16) * 16 : 0;
-    if (exp_mode == 1) {
+    const int64_t vec_end = (exp_mode & 1) ? (nnz / 16) * 16 : 0;
+    if (exp_mode & 1) {
         /* 16 partial sums, lane i accumulates elements i, i+16, ... (.cc:200-214) */
         float lanes[16];
         for (int i = 0; i < 16; ++i) lanes[i] = 0.f;

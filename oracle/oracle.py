@@ -241,7 +241,7 @@ class SparseAttentionServer:
 
     def __init__(self, nthreads: int = 0, exp_mode: int = 0, clamp_cos: int = 0):
         self.nthreads = nthreads
-        self.exp_mode = exp_mode      # 0 exact expf (oracle proper); 1 reference polynomial
+        self.exp_mode = exp_mode      # bit 0: reference polynomial exp; bit 1: cancellation-free f64 weight
         self.clamp_cos = clamp_cos    # reference: no clamp (sparse_attention.cc:177)
         self.allocated = False
 

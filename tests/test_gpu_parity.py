@@ -3,9 +3,9 @@ CPU oracle and the reference's golden vectors.  Needs a real MI355X: `pytest -m 
 
 Bars (BASELINE.json north_star): hash codes and selected token sets bit-exact; attention
 outputs within the tolerance written at each assert (the reference's own test tolerance is
-rtol = atol = 1e-2, library/sparse_attention/test_sparse.py:87-92; vs the exact-exp oracle we
-hold the HIP path to <= 1 bf16 ulp on outputs, 2e-3 relative on probabilities, 1e-3 on the
-base-2 LSE)."""
+rtol = atol = 1e-2, library/sparse_attention/test_sparse.py:87-92; vs the oracle with exact exp
+and the cancellation-free importance weight we hold the HIP path to <= 1 bf16 ulp on outputs,
+1e-3 relative on probabilities, 1e-3 on the base-2 LSE)."""
 import hashlib
 
 import numpy as np
@@ -158,19 +158,29 @@ def _oracle_attention(r, ind, nnz, exp_mode=0):
 
 
 def _check_attention(r, g=None):
+    """(a) tight: against the oracle with the importance weight evaluated cancellation-free in
+    f64 (exp_mode bit 1) -- what the HIP kernel computes; (b) against the oracle's literal
+    restatement of the reference's f32 formula, whose own cancellation noise (~1e-3 relative in
+    w + 1e-4) only supports the reference's test tolerance; (c) against the reference's outputs."""
     B, H, Hkv, n, M, D, K, L = r["dims"]
     nnz = r["nnz"]
-    o_out, o_mve, o_probs = _oracle_attention(r, r["results"], nnz)
+    live = nnz > 0
+    a = synth.bf16_bits_to_f32(r["out"])
+    o_out, o_mve, o_probs = _oracle_attention(r, r["results"], nnz, exp_mode=2)
     for h in range(B * H):
         z = nnz[h]
-        assert np.allclose(r["probs"][h, :z], o_probs[h, :z], rtol=2e-3, atol=1e-7), h
+        assert np.allclose(r["probs"][h, :z], o_probs[h, :z], rtol=1e-3, atol=1e-7), h
         assert abs(r["probs"][h, :z].sum() - 1) < 1e-4 or z == 0
     assert np.allclose(r["mve"][1], o_mve[1], atol=1e-3)                      # base-2 LSE
-    live = nnz > 0
     assert np.allclose(r["mve"][0][live], o_mve[0][live], atol=1e-3)
-    a, b = synth.bf16_bits_to_f32(r["out"]), synth.bf16_bits_to_f32(o_out)
-    assert np.allclose(a, b, rtol=2 ** -7, atol=2e-4)                         # <= 1 bf16 ulp
+    assert np.allclose(a, synth.bf16_bits_to_f32(o_out), rtol=2 ** -7, atol=2e-4)   # <= 1 bf16 ulp
     assert (r["out"] == o_out).mean() > 0.9
+    f_out, f_mve, f_probs = _oracle_attention(r, r["results"], nnz, exp_mode=0)
+    for h in range(B * H):
+        z = nnz[h]
+        assert np.allclose(r["probs"][h, :z], f_probs[h, :z], rtol=1e-2, atol=1e-2), h   # test_sparse.py:87
+    assert np.allclose(a, synth.bf16_bits_to_f32(f_out), rtol=1e-2, atol=1e-2)           # test_sparse.py:92
+    assert np.allclose(r["mve"][1], f_mve[1], atol=5e-3)
     if g is not None:   # the reference's own outputs at the reference's own tolerance
         assert np.allclose(a, synth.bf16_bits_to_f32(g["out_bits"]), rtol=1e-2, atol=1e-2)
         assert np.allclose(r["mve"][1], g["mve"][1], atol=0.03)
@@ -343,6 +353,59 @@ def test_sparse_attention_like_reference_test(mp, G, batch_size, H, D, delta):
         o = (p.unsqueeze(0) @ valr[i][idx]).cpu()
         assert torch.allclose(output[i].float(), o, rtol=1e-2, atol=1e-2)
         assert abs(float(mve[1][i]) - float(lse2)) < 1e-2          # the reference never asserts its LSE
+
+
+def test_in_launch_merge_is_deterministic_under_load(mp):
+    """The attention kernel merges a head's slice partials inside the launch (last-arriver ticket,
+    write-through partials).  Any stale read shows up as run-to-run differences: 60 launches over
+    256 heads with ragged list lengths (1 .. 6000 entries, i.e. 1 .. 94 slices per head) must be
+    bit-identical, and equal to the oracle."""
+    H, Hkv, B, D, n, M, K, L = 32, 8, 8, 128, 8000, 8192, 10, 150
+    gen = torch.Generator().manual_seed(99)
+    key = torch.randn((B, Hkv, n, D), generator=gen).to(torch.bfloat16)
+    val = torch.randn((B, Hkv, n, D), generator=gen).to(torch.bfloat16)
+    kn = key.norm(p=2, dim=-1).float()
+    srv = mp.SparseAttentionServer()
+    srv.alloc(1, H, Hkv, D, B, M)
+    for b in range(B):
+        srv.fill(0, b, key[b].cuda(), val[b].cuda(), kn[b].cuda())
+    BH = B * H
+    q = torch.randn((BH, D), generator=gen).to(torch.bfloat16)
+    qn = q.float().norm(p=2, dim=-1)
+    nnz = torch.randint(1, 6000, (BH,), generator=gen).int()
+    nnz[5] = 0
+    nnz[17] = 1
+    ind = torch.zeros((BH, M), dtype=torch.int32)
+    for i in range(BH):
+        ind[i, :nnz[i]] = torch.randperm(n, generator=gen)[:nnz[i]].int()
+    qd, qnd, indd, nnzd = q.cuda(), qn.cuda(), ind.cuda(), nnz.cuda()
+    first = None
+    for rep in range(60):
+        out = torch.zeros((BH, D), dtype=torch.bfloat16, device="cuda")
+        mve = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
+        srv.attention_wrapper(0, K, L, out, mve, qd, qnd, indd, nnzd)
+        cur = (out.view(torch.int16).cpu(), mve.cpu())
+        if first is None:
+            first = cur
+        else:
+            assert torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1]), rep
+    got = synth.bf16_bits_to_f32(first[0].numpy().view(np.uint16))
+    # (a) against the cancellation-free f64 evaluation of the importance weight: <= 1 bf16 ulp;
+    # (b) against the reference's literal f32 formula: its own ~1e-3 noise in w + 1e-4 on these
+    #     low-collision-probability tokens allows only the reference's tolerance (1e-2).
+    for mode, rt, at in ((2, 2 ** -7, 2e-4), (0, 1e-2, 2e-3)):
+        osrv = oracle.SparseAttentionServer(exp_mode=mode, clamp_cos=1)
+        osrv.alloc(1, H, Hkv, D, B, M)
+        for b in range(B):
+            osrv.fill(0, b, key[b], val[b], kn[b])
+        oout = np.zeros((BH, D), np.uint16)
+        omve = np.zeros((2, BH), np.float32)
+        osrv.attention_wrapper(0, K, L, oout, omve, q, qn, ind, nnz)
+        ref = synth.bf16_bits_to_f32(oout)
+        bad = np.argwhere(~np.isclose(got, ref, rtol=rt, atol=at))
+        assert len(bad) == 0, (mode, [(int(h), int(d), int(nnz[h]), float(got[h, d]), float(ref[h, d]))
+                                      for h, d in bad[:8]])
+        assert np.allclose(first[1].numpy()[1], omve[1], atol=1e-3 if mode == 2 else 5e-3)
 
 
 def test_full_attention_vs_oracle(mp):
