@@ -196,6 +196,7 @@ def main():
 
     import magicpig_amd as mp
     import magicpig_amd._lib as L
+    from magicpig_amd import sharding
 
     cfg = CONFIGS[args.config]
     B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
@@ -204,9 +205,12 @@ def main():
     BH = B * H
     n = P - 68
 
-    # identical hyperplanes on every rank (attnserver_dist.py:279 broadcasts them; here seeded)
+    # identical hyperplanes on every rank: rank 0's are broadcast once (attnserver_dist.py:279)
+    gen0 = torch.Generator(device="cpu").manual_seed(7 + rank)
+    hash_func = torch.randn((D, K * Lt), generator=gen0, dtype=torch.float32).to(torch.bfloat16).to(dev)
+    hash_func = sharding.sync_hash_func(hash_func, src=0)
     server = mp.LSHSparseAttnServer(NL, H, Hkv, D, K=K, L=Lt, batch_size=B, max_length=M,
-                                    dense_layers=(), device=str(dev), seed=7,
+                                    dense_layers=(), device=str(dev), hash_func=hash_func,
                                     table_build=args.table_build)
     t_setup = time.time()
     for li in range(NL):
@@ -278,10 +282,7 @@ def main():
     run_steps(args.warmup, args.steps)
     sync_all()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = sharding.max_over_ranks(dt, device=dev)
     ms_per_step = dt / args.steps * 1e3
     tokens_per_s = world * B * args.steps / dt
     us_per_layer = ms_per_step * 1e3 / NL

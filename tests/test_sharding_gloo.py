@@ -1,0 +1,105 @@
+"""N > 1 path on CPU: two gloo processes shard the units (batch- and head-sharded), each computes
+its shard with the ORACLE standing in for the HIP library (tests only), and the gathered result
+must equal the unsharded oracle result on every rank.  Also covers the partition arithmetic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp_
+
+import cases
+import oracle
+import synth
+from magicpig_amd import sharding
+
+
+def test_partition_arithmetic():
+    s = sharding.partition(64, 32, 8, 8, 3, "batch")          # BASELINE cfg 3
+    assert list(s.requests) == list(range(24, 32)) and s.local_kv_heads == 8 and s.local_heads == 32
+    s = sharding.partition(1, 64, 8, 8, 5, "head")            # BASELINE cfg 4: 70B TP=8
+    assert list(s.kv_heads) == [5] and list(s.heads) == list(range(40, 48)) and s.local_batch == 1
+    # ragged batch: 10 requests over 4 ranks -> 3, 3, 2, 2 and every request owned exactly once
+    owned = [r for k in range(4) for r in sharding.partition(10, 8, 2, 4, k).requests]
+    assert owned == list(range(10))
+    assert [sharding.partition(10, 8, 2, 4, k).local_batch for k in range(4)] == [3, 3, 2, 2]
+    with pytest.raises(ValueError):
+        sharding.partition(1, 32, 8, 3, 0, "head")            # 8 kv heads do not split over 3 ranks
+    with pytest.raises(ValueError):
+        sharding.partition(1, 32, 8, 2, 2, "batch")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+B, H, HKV, N, M, D, K, L = 3, 8, 2, 384, 448, 128, 8, 40
+
+
+def _oracle_layer(keys, kns, vals, W, qb, b_ids, kv_ids):
+    """Oracle decode of one layer restricted to requests b_ids x kv heads kv_ids."""
+    G = H // HKV
+    Bl, Hkvl = len(b_ids), len(kv_ids)
+    Hl = Hkvl * G
+    heads = [g * G + i for g in kv_ids for i in range(G)]
+    q = np.stack([qb.reshape(B, H, D)[b][heads] for b in b_ids]).reshape(Bl * Hl, D)
+    qcodes, qn = oracle.simhash_query(q, W, K, L)
+    lsh = oracle.LSH()
+    lsh.alloc(K, L, 1, Hl, Hkvl, Bl, M)
+    srv = oracle.SparseAttentionServer(exp_mode=2, clamp_cos=1)
+    srv.alloc(1, Hl, Hkvl, D, Bl, M)
+    for i, b in enumerate(b_ids):
+        kk = np.ascontiguousarray(keys[b][list(kv_ids)])
+        sc, si = cases.stable_sort_codes(oracle.simhash_keys(kk, W, K, L))
+        lsh.fill(0, i, sc, si)
+        srv.fill(0, i, kk, np.ascontiguousarray(vals[b][list(kv_ids)]), np.ascontiguousarray(kns[b][list(kv_ids)]))
+    res = np.zeros((Bl * Hl, M), np.int32)
+    nnz = np.zeros((Bl * Hl,), np.int32)
+    lsh.batch_retrieve(0, qcodes, res, nnz)
+    ind = np.zeros_like(res)
+    for h in range(Bl * Hl):
+        ind[h, :nnz[h]] = np.sort(res[h, :nnz[h]])
+    out = np.zeros((Bl * Hl, D), np.uint16)
+    mve = np.zeros((2, Bl * Hl), np.float32)
+    srv.attention_wrapper(0, K, L, out, mve, q, qn, ind, nnz)
+    return out.reshape(Bl, Hl, D)
+
+
+def _worker(rank, world, port, mode, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        keys, kns, vals, W, qb = cases.case_inputs(77, B, H, HKV, N, D, K, L)
+        # rank 0 owns the hyperplanes; the others start from garbage and must receive them
+        Wt = synth.to_torch_bf16(W if rank == 0 else np.zeros_like(W))
+        Wt = sharding.sync_hash_func(Wt, src=0)
+        Wl = Wt.view(torch.int16).numpy().view(np.uint16)
+        assert np.array_equal(Wl, W)
+        shard = sharding.partition(B, H, HKV, world, rank, mode)
+        local = _oracle_layer(keys, kns, vals, Wl, qb, list(shard.requests), list(shard.kv_heads))
+        full = sharding.gather_outputs(synth.to_torch_bf16(local), shard, B, H)
+        t = sharding.max_over_ranks(1.0 + rank)
+        ret[rank] = (full.view(torch.int16).numpy().copy(), t)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["batch", "head"])
+def test_two_rank_sharded_decode_equals_unsharded(mode):
+    world = 2
+    port = _free_port()
+    with mp_.Manager() as mgr:
+        ret = mgr.dict()
+        mp_.spawn(_worker, args=(world, port, mode, ret), nprocs=world, join=True)
+        keys, kns, vals, W, qb = cases.case_inputs(77, B, H, HKV, N, D, K, L)
+        ref = _oracle_layer(keys, kns, vals, W, qb, list(range(B)), list(range(HKV)))
+        for r in range(world):
+            got, t = ret[r]
+            assert np.array_equal(got.view(np.uint16), ref), (mode, r)     # bit-identical: units are independent
+            assert t == 2.0                                                 # max over ranks
