@@ -182,8 +182,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_sparse_kernel(
             vreg[u] = zero;
             if (valid_u) {
                 const uint16_t* row = kvg + (int64_t)id_u * 2 * D;
-                kreg[u] = *reinterpret_cast<const u32x4*>(row);
-                vreg[u] = *reinterpret_cast<const u32x4*>(row + D);
+                // rows are read once and never reused: non-temporal loads (no L2/MALL allocation)
+                kreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row));
+                vreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row + D));
             }
         }
         float kn_my = 1.f;
