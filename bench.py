@@ -330,7 +330,7 @@ def main():
             with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("config") == args.config:
-                traffic = tj.get("attn_partial_bytes_per_launch")
+                traffic = tj.get("attn_sparse_bytes_per_launch")
         except Exception:
             traffic = None
 
