@@ -40,26 +40,6 @@ __device__ __forceinline__ float powi(float b, int e) {
     return r;
 }
 
-// 8-element bf16 dot product: four chained v_dot2c_f32_bf16 (D += a.lo*b.lo + a.hi*b.hi).
-// Inline asm on purpose: with ROCm 7.2's hipcc, __builtin_amdgcn_fdot2_f32_bf16 fed from
-// ext-vector element extracts selects element 0 for EVERY call (scripts/probe_dot2.hip shows
-// `v_dot2c_f32_bf16 v, v2, v6` four times); the asm form is correct.  hipcc pads nothing
-// inside asm, so the gfx940-class DOT hazards are handled here: a DOT result may feed the next
-// same-opcode DOT as the accumulator with 0 wait states, but any other VALU read / write of it
-// needs 3 / 4 wait states (LLVM GCNHazardRecognizer, DotWriteDifferentVALURead/Write) ->
-// `s_nop 3` after the chain.
-__device__ __forceinline__ float dot8_bf16(const u32x4& k, const uint32_t (&q)[4]) {
-    float acc = 0.f;
-    asm("v_dot2c_f32_bf16 %0, %1, %5\n\t"
-        "v_dot2c_f32_bf16 %0, %2, %6\n\t"
-        "v_dot2c_f32_bf16 %0, %3, %7\n\t"
-        "v_dot2c_f32_bf16 %0, %4, %8\n\t"
-        "s_nop 3"
-        : "+v"(acc)
-        : "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
-    return acc;
-}
-
 // one reduce-scatter step over lanes l and l^ST: N values -> N/2 values per lane
 template <int N, int ST>
 __device__ __forceinline__ void rs_step(float (&v)[8], int lane, int& doff) {
@@ -101,10 +81,15 @@ __global__ __launch_bounds__(AT_THREADS) void attn_sparse_kernel(
     constexpr int RPL = 64 / LPR;        // rows per wave load
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane / LPR, c = lane % LPR;
-    const int h = blockIdx.y;
+    // 1-D grid, head fastest: block b -> (x = b / BH, h = b % BH).  Blocks land on XCD b % 8, so
+    // the blocks that own the first slices of every head (the only ones with work when the list is
+    // short) are dispatched first and spread evenly over the 8 XCDs; a (x, h) 2-D grid would pin
+    // each x to one XCD residue class.
+    const int h = blockIdx.x % BH;
+    const int bx = blockIdx.x / BH, gx = gridDim.x / BH;
     const int64_t g = h / G;
-    const int stride = gridDim.x * AT_WAVES;            // slices per pass over this head
-    int s = blockIdx.x * AT_WAVES + wave;
+    const int stride = gx * AT_WAVES;                   // slices per pass over this head
+    int s = bx * AT_WAVES + wave;
     MP_STAMP(stamp, 32);
 
     // Token slot of (gather step u, row group r) is r*LPR + u, so after the reduce-scatter lane l
@@ -129,7 +114,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_sparse_kernel(
     int nz = nnz[h];
     if ((int64_t)nz > M) nz = (int)M;
     if (nz <= 0) {                                      // empty head: out = 0, LSE = -inf (a-10)
-        if (blockIdx.x == 0 && wave == 0) {
+        if (bx == 0 && wave == 0) {
             for (int d = lane; d < D; d += 64) out[(int64_t)h * D + d] = 0;
             if (lane == 0) {
                 mve[h] = -INFINITY;
@@ -197,7 +182,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_sparse_kernel(
         for (int u = 0; u < LPR; ++u) {
             float a = 0.f;
             if (QBF16) {
-                a = dot8_bf16(kreg[u], qpk);
+                const u32x4 qv = {qpk[0], qpk[1], qpk[2], qpk[3]};
+                dot8_bf16_chain(a, kreg[u], qv);
+                dot_settle(a);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -427,7 +414,7 @@ static hipError_t launch_sparse_t(const uint16_t* kv, const float* kn, const voi
                                   float2* head_mz, float* score, int BH, int G, int64_t M, int K,
                                   int L, int grid, hipStream_t st) {
     const int maxs = attn_slices_per_head(M);
-    hipLaunchKernelGGL((attn_sparse_kernel<D, DENSE, QBF16>), dim3(grid, BH), dim3(AT_THREADS), 0, st,
+    hipLaunchKernelGGL((attn_sparse_kernel<D, DENSE, QBF16>), dim3(grid * BH), dim3(AT_THREADS), 0, st,
                        kv, kn, q, qn, ind, nnz, part_o, part_ml, head_cnt, out, mve, head_mz, score, BH,
                        G, M, maxs, K, L, g_stamp);
     return hipGetLastError();

@@ -1,5 +1,6 @@
 // capi.hip -- the C ABI declared in include/magicpig_hip.h: handle state in HBM + launches.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -13,7 +14,7 @@ namespace mp {
 // ---- kernels' host launchers (simhash.hip, lsh.hip, attention.hip)
 int simhash_padded_cols(int K, int L);
 int simhash_supported(int D, int K);
-hipError_t launch_simhash_prepare(const uint16_t*, int, int, int, uint16_t*, float*, hipStream_t);
+hipError_t launch_simhash_prepare(const uint16_t*, int, int, int, uint16_t*, uint16_t*, float*, hipStream_t);
 hipError_t launch_simhash_query(const uint16_t*, const uint16_t*, const float*, int, int, int, int,
                                 int32_t*, float*, float*, hipStream_t);
 hipError_t launch_simhash_keys(const uint16_t*, const uint16_t*, const float*, int64_t, int, int,
@@ -25,6 +26,9 @@ hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int2*, i
                             hipStream_t);
 hipError_t launch_lsh_retrieve(const int2*, const int32_t*, const int32_t*, int32_t*, int32_t*, int,
                                int, int, int, int64_t, hipStream_t);
+hipError_t launch_lsh_hash_retrieve(const int2*, const int32_t*, const uint16_t*, const uint16_t*,
+                                    const float*, int, int, int, int32_t*, float*, int32_t*, int32_t*,
+                                    int, int, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_mask(const int2*, const int32_t*, const int32_t*, int8_t*, int, int, int, int,
                            int64_t, hipStream_t);
 int attn_slices_per_head(int64_t M);
@@ -85,7 +89,8 @@ using namespace mp;
 
 struct mp_simhash {
     int D = 0, K = 0, L = 0, KLpad = 0;
-    uint16_t* Wt = nullptr;   // [KLpad][D]
+    uint16_t* Wt = nullptr;   // [KLpad][D]        plane-major  (MFMA B operand)
+    uint16_t* Wk = nullptr;   // [D/8][KLpad][8]   chunk-major  (hash fused into the retrieve)
     float* wnorm = nullptr;   // [KLpad]
     float* dbg_acc = nullptr; // optional debug sink (set by mp_simhash_debug_acc)
 };
@@ -144,6 +149,7 @@ int mp_simhash_create(mp_simhash_t** out) {
 int mp_simhash_destroy(mp_simhash_t* s) {
     if (!s) return MP_OK;
     if (s->Wt) (void)hipFree(s->Wt);
+    if (s->Wk) (void)hipFree(s->Wk);
     if (s->wnorm) (void)hipFree(s->wnorm);
     delete s;
     return MP_OK;
@@ -157,16 +163,18 @@ int mp_simhash_set_planes(mp_simhash_t* s, int D, int K, int L, const uint16_t* 
                "mp_simhash_set_planes: need head_dim % 16 == 0, head_dim <= 256, 1 <= K <= 15");
     hipStream_t st = (hipStream_t)stream;
     if (s->Wt) { (void)hipFree(s->Wt); s->Wt = nullptr; }
+    if (s->Wk) { (void)hipFree(s->Wk); s->Wk = nullptr; }
     if (s->wnorm) { (void)hipFree(s->wnorm); s->wnorm = nullptr; }
     s->D = D; s->K = K; s->L = L;
     s->KLpad = simhash_padded_cols(K, L);
     MP_HIP_CHECK(hipMalloc((void**)&s->Wt, (size_t)s->KLpad * D * 2));
+    MP_HIP_CHECK(hipMalloc((void**)&s->Wk, (size_t)s->KLpad * D * 2));
     MP_HIP_CHECK(hipMalloc((void**)&s->wnorm, (size_t)s->KLpad * 4));
     DevBuf tmp;
     const void* W = nullptr;
     int rc = stage_in(hash_func, (size_t)D * K * L * 2, mem, tmp, &W);
     if (rc) return rc;
-    MP_HIP_CHECK(launch_simhash_prepare((const uint16_t*)W, D, K, L, s->Wt, s->wnorm, st));
+    MP_HIP_CHECK(launch_simhash_prepare((const uint16_t*)W, D, K, L, s->Wt, s->Wk, s->wnorm, st));
     MP_HIP_CHECK(hipStreamSynchronize(st));
     return MP_OK;
 }
@@ -486,10 +494,22 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
     if (rc == MP_OK) rc = alloc_zero((void**)&h->last_nnz, BH * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->head_cnt, BH * 4);
     if (rc != MP_OK) { attn_free(h); return rc; }
-    // GX workgroups (x 4 waves x 64 entries) per head cover ~3 % of max_length in one pass, i.e.
-    // 1.5x the reference's ~2 % sampling rate (README.md:43); longer lists take more passes.
-    h->grid = (int)((h->M + 256 * 32 - 1) / (256 * 32));
-    if (h->grid < 1) h->grid = 1;
+    // grid.x of the attention kernel: B*H * GX workgroups of 4 waves should fill the chip exactly
+    // once (4 resident workgroups per CU at 120 VGPRs): no second dispatch round with a ragged tail.
+    {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        h->grid = (int)((size_t)cus * 4 / BH);
+        if (h->grid < 1) h->grid = 1;
+        const int cap = (int)((h->M + 255) / 256);          // never more waves than 64-entry slices
+        if (h->grid > cap) h->grid = cap;
+        if (const char* e = getenv("MP_ATTN_GX")) {         // tuning override (scripts/gather_probe.py)
+            const int v = atoi(e);
+            if (v >= 1) h->grid = v;
+        }
+    }
     h->allocated = true;
     return MP_OK;
 }
@@ -659,12 +679,12 @@ int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int 
                "mp_decode_sparse_layer: layer_id out of range");
     hipStream_t st = (hipStream_t)stream;
     const int BH = lsh->B * lsh->H;
-    // a-1: models/attnserver.py:264-270
-    MP_HIP_CHECK(launch_simhash_query(q, s->Wt, s->wnorm, BH, s->D, s->K, s->L, lsh->codes,
-                                      lsh->qnorm, nullptr, st));
-    // a-2: models/attnserver.py:299
-    MP_HIP_CHECK(launch_lsh_retrieve(lsh->bounds[layer_id], lsh->table[layer_id], lsh->codes,
-                                     lsh->results, lsh->nnz, BH, lsh->G, lsh->L, lsh->NB, lsh->M, st));
+    // a-1 + a-2: models/attnserver.py:264-270 and :299 in ONE launch (the q-hash is the prologue of
+    // the retrieve workgroup of its head; codes and ||q|| are written as by-products)
+    MP_HIP_CHECK(launch_lsh_hash_retrieve(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk,
+                                          s->wnorm, s->D, s->K, s->KLpad, lsh->codes, lsh->qnorm,
+                                          lsh->results, lsh->nnz, BH, lsh->G, lsh->L, lsh->NB, lsh->M,
+                                          st));
     // a-7..a-12: models/attnserver.py:300
     lsh->lastq = lsh->codes;
     lsh->last_layer = layer_id;

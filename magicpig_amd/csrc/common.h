@@ -49,6 +49,24 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// ---------------------------------------------------------------- bf16 dot products (v_dot2c_f32_bf16)
+// acc += sum of 8 bf16 products: four chained v_dot2c_f32_bf16 (D += a.lo*b.lo + a.hi*b.hi).
+// Inline asm on purpose: with ROCm 7.2's hipcc, __builtin_amdgcn_fdot2_f32_bf16 fed from ext-vector
+// element extracts selects element 0 for EVERY call (scripts/probe_dot2.hip); the asm form is
+// correct.  hipcc pads nothing inside asm, so the gfx940-class DOT hazards are handled by hand: a
+// DOT result may feed the next same-opcode DOT as its accumulator with 0 wait states, but any other
+// VALU read / write of it needs 3 / 4 wait states (LLVM GCNHazardRecognizer,
+// DotWriteDifferentVALURead / Write) -> call dot_settle(acc) once after the last link of a chain.
+__device__ __forceinline__ void dot8_bf16_chain(float& acc, const u32x4& a, const u32x4& b) {
+    asm("v_dot2c_f32_bf16 %0, %1, %5\n\t"
+        "v_dot2c_f32_bf16 %0, %2, %6\n\t"
+        "v_dot2c_f32_bf16 %0, %3, %7\n\t"
+        "v_dot2c_f32_bf16 %0, %4, %8"
+        : "+v"(acc)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+__device__ __forceinline__ void dot_settle(float& acc) { asm("s_nop 3" : "+v"(acc)); }
+
 // ---------------------------------------------------------------- debug phase timestamps
 // stamp == nullptr in production; set through mp_debug_set_stamp_buffer (scripts/phase_times.py).
 // One lane of workgroup 0 records the 100 MHz wall clock at phase boundaries.

@@ -145,10 +145,26 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
 // grid = B*H (one workgroup per query head), block = 1024, dynamic LDS:
 //   A[words] | B[words] | s_start[Lpad] | s_len[Lpad] | s_tail[RT_TAIL_CAP] | s_tmp[32] | s_ntail
 // `words` = ceil(M/32) words per bitmap.
+// HASH = true fuses the query SimHash of models/attnserver.py:264-270 into the prologue: the head's
+// query row is normalised (bf16 semantics as simhash.hip), every thread evaluates <= 2 hyperplanes
+// from the chunk-major plane copy Wk[D/8][KLpad][8] (coalesced 16-byte loads, 128 f32 FMAs each,
+// exact-sign guard in f64), the sign bits meet in LDS by ballot and thread l packs table l's code --
+// the codes never travel through HBM between two kernels (they are still written for get_mask).
+struct HashArgs {
+    const uint16_t* q;       // [BH][D] bf16 queries
+    const uint16_t* Wk;      // [D/8][KLpad][8] bf16 hyperplanes, chunk-major
+    const float* wnorm;      // [KLpad] column norms (upper bounds)
+    int32_t* codes_out;      // [BH][L]
+    float* qnorm_out;        // [BH]
+    int D, K, KLpad;
+};
+
+template <bool HASH>
 __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
     const int2* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
-    int G, int L, int NB, int64_t M, int words, int Lpad, unsigned long long* __restrict__ stamp) {
+    int G, int L, int NB, int64_t M, int words, int Lpad, HashArgs ha,
+    unsigned long long* __restrict__ stamp) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_u32[];
     uint32_t* bmA = s_u32;
     uint32_t* bmB = s_u32 + words;
@@ -157,6 +173,11 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
     uint32_t* s_tail = reinterpret_cast<uint32_t*>(s_len + Lpad);   // (table << 16 | chunk) of ids beyond 128
     int* s_tmp = reinterpret_cast<int*>(s_tail + RT_TAIL_CAP);
     int* s_ntail = s_tmp + 32;
+    // HASH only: s_q (normalised query, bf16 pairs) | s_rn | s_bits (sign bits of the K*L planes)
+    uint32_t* s_q = reinterpret_cast<uint32_t*>(                    // rounded up to 16 bytes (ds_read_b128)
+        (reinterpret_cast<uintptr_t>(s_ntail + 4) + 15) & ~static_cast<uintptr_t>(15));
+    float* s_rn = reinterpret_cast<float*>(s_q + 128);
+    uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_rn + 4);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t h = blockIdx.x;
@@ -166,12 +187,94 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
 
     MP_STAMP(stamp, 16);
     if (tid == 0) *s_ntail = 0;
+    if (HASH) {
+        const int D = ha.D, KL = ha.K * L;
+        const int chunks = D >> 3;                              // 16-byte plane chunks per hyperplane
+        const u32x4* Wk4 = reinterpret_cast<const u32x4*>(ha.Wk);
+        // -- the first pass's hyperplane chunks do not depend on q: put them in flight first
+        u32x4 w[16];
+        if (tid < KL) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < chunks) w[i] = Wk4[tid + (int64_t)i * ha.KLpad];
+        }
+        // -- normalise the query row: wave 0, D/64 elements per lane (D = 64, 128 or 256)
+        if (wave == 0) {
+            const int per = D >> 6;
+            const uint16_t* src = ha.q + h * D + lane * per;
+            uint16_t e[4];
+            double ss = 0.0;
+            for (int i = 0; i < per; ++i) {
+                e[i] = src[i];
+                const double v = (double)bf16_bits_to_f32(e[i]);
+                ss += v * v;                                   // exact, order-free
+            }
+            ss = wave_sum(ss);
+            const float nrm = (float)sqrt((double)(float)ss);
+            const float nb = bf16_bits_to_f32(f32_to_bf16_rne(nrm));
+            if (lane == 0 && ha.qnorm_out != nullptr) ha.qnorm_out[h] = nrm;
+            uint16_t* dst = reinterpret_cast<uint16_t*>(s_q) + lane * per;
+            for (int i = 0; i < per; ++i) dst[i] = f32_to_bf16_rne(__fdiv_rn(bf16_bits_to_f32(e[i]), nb));
+            // ||nq|| <= ||q||/nb * (1 + 2^-8): every element is rounded to bf16 once (guard bound)
+            if (lane == 0) *s_rn = (nrm / nb) * 1.005f;
+        }
+        __syncthreads();
+        MP_STAMP(stamp, 22);
+        // -- one hyperplane per thread per pass: f32 FMA chain over D, exact-sign guard; the next
+        //    pass's chunks are fetched into the registers this pass has just consumed
+        const float rn = *s_rn;
+        const u32x4* q4 = reinterpret_cast<const u32x4*>(s_q);
+        for (int c0 = 0; c0 < KL; c0 += RT_THREADS) {
+            const int c = c0 + tid, cn = c + RT_THREADS;
+            bool bit = false;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i < chunks && c < KL) dot8_bf16_chain(acc, q4[i], w[i]);   // q4[i]: LDS broadcast
+                if (i < chunks && cn < KL) w[i] = Wk4[cn + (int64_t)i * ha.KLpad];
+            }
+            if (c < KL) {
+                for (int kc = 16; kc < chunks; ++kc)                // head_dim 256: remaining chunks
+                    dot8_bf16_chain(acc, q4[kc], Wk4[c + (int64_t)kc * ha.KLpad]);
+                dot_settle(acc);
+                bit = acc > 0.f;
+                if (fabsf(acc) <= (1.0f / 32768.0f) * rn * ha.wnorm[c]) {   // 2^-15 guard band (simhash.hip)
+                    double ex = 0.0;
+                    for (int kc = 0; kc < chunks; ++kc) {
+                        const u32x4 wv = Wk4[c + (int64_t)kc * ha.KLpad];
+                        const u32x4 x = q4[kc];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            ex += (double)bf16_lo(x[j]) * (double)bf16_lo(wv[j]) +
+                                  (double)bf16_hi(x[j]) * (double)bf16_hi(wv[j]);
+                    }
+                    bit = ex > 0.0;
+                }
+            }
+            const unsigned long long bm = __ballot(bit);
+            if (lane == 0) {
+                s_bits[(c0 >> 5) + wave * 2] = (uint32_t)bm;
+                s_bits[(c0 >> 5) + wave * 2 + 1] = (uint32_t)(bm >> 32);
+            }
+            MP_STAMP(stamp, 23 + (c0 >> 10));
+        }
+    }
     __syncthreads();
+    MP_STAMP(stamp, 27);
     // probe: one 8-byte random read per table (issued first: longest latency)
     for (int l = tid; l < Lpad; l += RT_THREADS) {
         int st = 0, len = 0;
         if (l < L) {
-            const int code = query[h * L + l];
+            int code;
+            if (HASH) {   // bit i of code l <- plane l*K + i
+                const int bp = l * ha.K, w = bp >> 5, sh = bp & 31;
+                uint32_t v = s_bits[w] >> sh;
+                if (sh + ha.K > 32) v |= s_bits[w + 1] << (32 - sh);
+                code = (int)(v & ((1u << ha.K) - 1u));
+                ha.codes_out[h * L + l] = code;
+            } else {
+                code = query[h * L + l];
+            }
             if (code >= 0 && code < NB) {
                 const int2 be = bnd[(int64_t)l * NB + code];
                 st = be.x;
@@ -307,7 +410,8 @@ __global__ __launch_bounds__(256) void lsh_mask_kernel(
 // ---------------------------------------------------------------- host launchers
 size_t retrieve_lds_bytes(int64_t M, int L) {
     const int Lpad = (L + 63) & ~63;
-    return (size_t)(2 * ((M + 31) / 32) + 2 * Lpad + RT_TAIL_CAP + 64) * 4;
+    // + fused-hash scratch: 128 words of query, 4 of norm, sign bits of up to 16*L planes (+ ballot slack)
+    return (size_t)(2 * ((M + 31) / 32) + 2 * Lpad + RT_TAIL_CAP + 64 + 140 + (16 * L + 31) / 32 + 2 * RT_WAVES + 4) * 4;
 }
 
 hipError_t launch_lsh_fill(const int16_t* codes, const int32_t* ids, int rows, int64_t n, int NB,
@@ -325,21 +429,45 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     return hipGetLastError();
 }
 
+static hipError_t retrieve_attr_once() {
+    static bool attr_done = false;
+    if (attr_done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_retrieve_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_retrieve_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) attr_done = true;
+    return e;
+}
+
 hipError_t launch_lsh_retrieve(const int2* bounds, const int32_t* table, const int32_t* query,
                                int32_t* results, int32_t* nnz, int BH, int G, int L, int NB,
                                int64_t M, hipStream_t st) {
     const int words = (int)((M + 31) / 32);
     const int Lpad = (L + 63) & ~63;
-    const size_t lds = retrieve_lds_bytes(M, L);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_retrieve_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(lsh_retrieve_kernel, dim3(BH), dim3(RT_THREADS), lds, st, bounds, table,
-                       query, results, nnz, G, L, NB, M, words, Lpad, g_stamp);
+    hipError_t e = retrieve_attr_once();
+    if (e != hipSuccess) return e;
+    HashArgs ha = {};
+    hipLaunchKernelGGL(lsh_retrieve_kernel<false>, dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+                       st, bounds, table, query, results, nnz, G, L, NB, M, words, Lpad, ha, g_stamp);
+    return hipGetLastError();
+}
+
+// q-hash fused into the retrieve (mp_decode_sparse_layer): codes and ||q|| are by-products
+hipError_t launch_lsh_hash_retrieve(const int2* bounds, const int32_t* table, const uint16_t* q,
+                                    const uint16_t* Wk, const float* wnorm, int D, int K, int KLpad,
+                                    int32_t* codes_out, float* qnorm_out, int32_t* results,
+                                    int32_t* nnz, int BH, int G, int L, int NB, int64_t M,
+                                    hipStream_t st) {
+    const int words = (int)((M + 31) / 32);
+    const int Lpad = (L + 63) & ~63;
+    hipError_t e = retrieve_attr_once();
+    if (e != hipSuccess) return e;
+    HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
+    hipLaunchKernelGGL(lsh_retrieve_kernel<true>, dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+                       st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, words,
+                       Lpad, ha, g_stamp);
     return hipGetLastError();
 }
 

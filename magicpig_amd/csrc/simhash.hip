@@ -19,15 +19,18 @@ constexpr int SH_MAX_TILES = 16;         // max 32-column tiles per workgroup
 constexpr float SH_EPS = 1.0f / 32768.0f; // guard band (2^-15) relative to ||x||*||w||; the measured
                                           // MFMA accumulation error is < 2^-20 (tests/test_gpu_parity.py)
 
-// Transpose hash_func [D][KL] -> Wt [KLpad][D] (zero rows beyond KL) and column norms.
+// Transpose hash_func [D][KL] -> Wt [KLpad][D] (zero rows beyond KL), the chunk-major copy
+// Wk [D/8][KLpad][8] used by the hash fused into the retrieve kernel, and column norms.
 __global__ void simhash_prepare_kernel(const uint16_t* __restrict__ W, int D, int KL, int KLpad,
-                                       uint16_t* __restrict__ Wt, float* __restrict__ wnorm) {
+                                       uint16_t* __restrict__ Wt, uint16_t* __restrict__ Wk,
+                                       float* __restrict__ wnorm) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= KLpad) return;
     double ss = 0.0;
     for (int d = 0; d < D; ++d) {
         uint16_t v = (n < KL) ? W[(int64_t)d * KL + n] : (uint16_t)0;
         Wt[(int64_t)n * D + d] = v;
+        Wk[((int64_t)(d >> 3) * KLpad + n) * 8 + (d & 7)] = v;
         double x = (double)bf16_bits_to_f32(v);
         ss += x * x;
     }
@@ -251,10 +254,10 @@ int simhash_supported(int D, int K) {
 }
 
 hipError_t launch_simhash_prepare(const uint16_t* W, int D, int K, int L, uint16_t* Wt,
-                                  float* wnorm, hipStream_t st) {
+                                  uint16_t* Wk, float* wnorm, hipStream_t st) {
     const int KLpad = simhash_padded_cols(K, L);
     hipLaunchKernelGGL(simhash_prepare_kernel, dim3((KLpad + 255) / 256), dim3(256), 0, st, W, D,
-                       K * L, KLpad, Wt, wnorm);
+                       K * L, KLpad, Wt, Wk, wnorm);
     return hipGetLastError();
 }
 
