@@ -157,17 +157,30 @@ def run_cpu_baseline(cfg, server, qs, steps):
              k=kc.cpu().view(torch.int16).numpy(), v=vc.cpu().view(torch.int16).numpy(),
              kn=kn.cpu().numpy(), q=qs[:, layer].reshape(NQ, BH, D).cpu().view(torch.int16).numpy(),
              qcodes=qcodes.cpu().numpy())
-    # one OpenMP thread per physical core, packed (the reference pins with numactl, examples/bench.sh:1)
-    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_THREAD_LIMIT=str(cores),
-               OMP_PLACES="cores", OMP_PROC_BIND="close", MKL_NUM_THREADS=str(cores))
+    # two thread placements (the reference pins with numactl, examples/bench.sh:1); the faster one
+    # is reported: (a) libgomp default places, (b) one thread per physical core, packed
+    best = None
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path],
-                           env=env, capture_output=True, text=True, timeout=900)
+        for places in (None, "cores"):
+            env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_THREAD_LIMIT=str(cores),
+                       OMP_PROC_BIND="close", MKL_NUM_THREADS=str(cores))
+            if places:
+                env["OMP_PLACES"] = places
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path],
+                               env=env, capture_output=True, text=True, timeout=900)
+            for line in r.stdout.splitlines():
+                if line.startswith("CPU_BASELINE_JSON "):
+                    cb = json.loads(line[len("CPU_BASELINE_JSON "):])
+                    cb["omp_places"] = places or "default"
+                    if best is None or cb["t_retrieve_us"] + cb["t_attention_us"] < best["t_retrieve_us"] + best["t_attention_us"]:
+                        best = cb
     finally:
         try:
             os.remove(path)
         except OSError:
             pass
+    if best is not None:
+        return best
     for line in r.stdout.splitlines():
         if line.startswith("CPU_BASELINE_JSON "):
             return json.loads(line[len("CPU_BASELINE_JSON "):])
@@ -362,7 +375,8 @@ def main():
                 "value": B / (NL * t_layer * 1e-6), "unit": "tokens/s", "cores": cb["cores"],
                 "kind": cb["kind"],
                 "sample": f"1 of {NL} sparse layers x {cb['steps']} decode steps, same tables/KV/queries as "
-                          f"the GPU's first sparse layer; tokens/s = B / ({NL} x t_layer)",
+                          f"the GPU's first sparse layer; tokens/s = B / ({NL} x t_layer); "
+                          f"OMP_PLACES={cb.get('omp_places')}, best of 2 placements",
                 "t_retrieve_us": cb["t_retrieve_us"], "t_attention_us": cb["t_attention_us"]}
             # cross-check of the GPU result against the CPU path on the full-size layer
             q_static.copy_(qs[0])
