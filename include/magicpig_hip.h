@@ -129,6 +129,15 @@ int mp_attn_full(mp_attn_t* h, int layer_id, uint16_t* output, float* max_value_
                  const void* query, int query_dtype, const int32_t* nnz, int mem,
                  mp_stream_t stream);
 int mp_attn_clear(mp_attn_t* h, mp_stream_t stream);  /* sparse_attention.cc:586-598 */
+/* One decode step's (k, v) appended at row pos[b] of every kv head of request b -- the role of
+ * flashinfer.append_paged_kv_cache at models/attnserver.py:281-290 for the static-window store
+ * (a second mp_attn_t whose max_length is sink + local + generation buffer; the window's exact
+ * attention is mp_attn_full on it, replacing BatchDecodeWithPagedKVCacheWrapper.run_return_lse,
+ * :293-296).  k, v bf16 [B, Hkv, D]; pos int32 [B]; device pointers; the key norm of the new row
+ * is computed on the fly.  A position >= max_length is reported by mp_attn_check (MP_ERR_DATA). */
+int mp_attn_append(mp_attn_t* h, int layer_id, const uint16_t* k, const uint16_t* v,
+                   const int32_t* pos, mp_stream_t stream);
+int mp_attn_check(mp_attn_t* h, mp_stream_t stream);
 /* get_key_cache / get_value_cache / get_key_norm, sparse_attention.cc:1213-1233: device
  * pointers into the handle's storage.  K and V rows are INTERLEAVED per token in HBM
  * ([B*Hkv, M, 2, D]); *row_stride_elems = 2*D, the V pointer is the K pointer + D elements. */

@@ -69,6 +69,8 @@ def lib() -> C.CDLL:
         "mp_attn_sparse": ([p, i32, i32, i32, p, p, p, i32, p, p, p, i32, p], i32),
         "mp_attn_full": ([p, i32, p, p, p, i32, p, i32, p], i32),
         "mp_attn_clear": ([p, p], i32),
+        "mp_attn_append": ([p, i32, p, p, p, p], i32),
+        "mp_attn_check": ([p, p], i32),
         "mp_debug_set_stamp_buffer": ([p], i32),
         "mp_attn_get_kv": ([p, i32, pp, pp, C.POINTER(i64)], i32),
         "mp_attn_get_key_norm": ([p, i32, pp], i32),

@@ -5,11 +5,14 @@
                             offloaded K/V/|k| -> HBM store
     build_table (:178-193)  per-table sort of the key codes -> CSR tables in HBM
     decode      (:264-300)  q SimHash -> batch_retrieve -> attention_wrapper, all in HBM
+    decode_full (:228-312, sparse-layer branch) additionally does what the reference delegates to
+                FlashInfer around the hot path: append this step's centred (k, v) to the static
+                window (:275-290), exact attention over the window with a base-2 LSE (:293-296) and
+                the LSE merge of the two partial attentions (:302-308)  [SURVEY.md 8(f) row f-2]
     clear       (:314-331)
 
-The exact static-window attention and LSE merge that surround it in the reference (FlashInfer
-calls, :275-296, 302-308) are SURVEY.md 8(f) "next" rows; `merge` exposes the LSE merge kernel.
-Everything runs on one device; there is no PCIe hop and no CPU fallback.
+Dense layers (0, 16, ...: FlashInfer full attention over the whole sequence, :235-259) are not part
+of this path.  Everything runs on one device; there is no PCIe hop and no CPU fallback.
 """
 from __future__ import annotations
 
@@ -26,7 +29,8 @@ from .sparse_attention import SparseAttentionServer
 class LSHSparseAttnServer:
     def __init__(self, num_layers: int, num_attention_heads: int, num_key_value_heads: int,
                  head_dim: int, K: int = 10, L: int = 150, batch_size: int = 1,
-                 num_sink_tokens: int = 4, num_local_tokens: int = 64, max_length: int = 8192,
+                 num_sink_tokens: int = 4, num_local_tokens: int = 64, generation_buffer: int = 256,
+                 max_length: int = 8192,
                  dense_layers=(0, 16, 32, 48, 64), device: str = "cuda:0",
                  dtype=torch.bfloat16, hash_func: torch.Tensor | None = None, seed: int = 7,
                  table_build: str = "sort"):
@@ -66,6 +70,16 @@ class LSHSparseAttnServer:
         self.max_value_expsum = torch.zeros((2, BH), dtype=torch.float32, device=self.device)
         self.nnz = torch.zeros((BH,), dtype=torch.int32, device=self.device)
         self.collect_nnz = True     # copy the per-head selected counts into self.nnz every decode
+        # static window (sink + local + generated tokens), attnserver.py:25, 73-78, 97-106
+        self.length = num_sink_tokens + num_local_tokens + generation_buffer
+        with torch.cuda.device(self.device):
+            self.window_server = SparseAttentionServer()
+            self.window_server.alloc(num_layers, num_attention_heads, num_key_value_heads, head_dim,
+                                     batch_size, self.length)
+        self.kv_last_page_len = torch.zeros((batch_size,), dtype=torch.int32, device=self.device)
+        self.window_nnz = torch.zeros((BH,), dtype=torch.int32, device=self.device)
+        self.window_out = torch.zeros((BH, head_dim), dtype=torch.bfloat16, device=self.device)
+        self.window_mve = torch.zeros((2, BH), dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------ prefill side
     def fill(self, layer_idx: int, request_id: int, key_cache: torch.Tensor,
@@ -79,6 +93,14 @@ class LSHSparseAttnServer:
         offload_key = offload_key - avg_k
         kn = offload_key.norm(p=2, dim=-1).float()
         self.avg_k[layer_idx][request_id] = avg_k
+        # sink + local tokens -> the static window, centred with the same avg_k (:126-153)
+        if s + l > 0:
+            wkey = torch.cat([key_cache[:s], key_cache[seq_len - l:seq_len]], dim=0).transpose(0, 1) - avg_k
+            wval = torch.cat([value_cache[:s], value_cache[seq_len - l:seq_len]], dim=0).transpose(0, 1)
+            wkey = wkey.contiguous()
+            self.window_server.fill(layer_idx, request_id, wkey, wval.contiguous(),
+                                    wkey.norm(p=2, dim=-1).float())
+        self.kv_last_page_len[request_id] = s + l
         # key SimHash (:159-168) -> int16 [Hkv, L, n] on device
         self.hash_code_buffer = self.hasher.keys(offload_key)
         self.attn_server.fill(layer_idx, request_id, offload_key, offload_value, kn)
@@ -112,6 +134,27 @@ class LSHSparseAttnServer:
         lse = self.max_value_expsum[1].view(self.batch_size, self.num_attention_heads)
         return out, lse
 
+    def plan(self) -> None:
+        """models/attnserver.py:196-198: one more token in every request's window this step."""
+        self.kv_last_page_len += 1
+        self.window_nnz.copy_(self.kv_last_page_len.repeat_interleave(self.num_attention_heads))
+
+    def decode_full(self, query_states: torch.Tensor, key_states: torch.Tensor,
+                    value_states: torch.Tensor, layer_idx: int) -> torch.Tensor:
+        """models/attnserver.py:261-312 (sparse-layer branch) entirely on the device: returns
+        hidden_states bf16 [B, 1, H*D].  Call plan() once per step before the first layer."""
+        B, H, Hkv, D = self.batch_size, self.num_attention_heads, self.num_key_value_heads, self.head_dim
+        q = query_states.reshape(B * H, D)
+        k = (key_states.reshape(B, Hkv, 1, D) - self.avg_k[layer_idx]).reshape(B, Hkv, D).contiguous()
+        v = value_states.reshape(B, Hkv, D).contiguous()
+        self.window_server.append(layer_idx, k, v, self.kv_last_page_len - 1)          # :275-290
+        self.window_server.full_attention(layer_idx, self.window_out, self.window_mve, q,
+                                          self.window_nnz)                             # :293-296
+        sparse_out, sparse_lse = self.decode(query_states, layer_idx)                  # :264-300
+        hidden, _ = self.merge(self.window_out.view(B, H, D), self.window_mve[1].view(B, H),
+                               sparse_out, sparse_lse)                                 # :302-308
+        return hidden.reshape(B, 1, H * D)
+
     @staticmethod
     def merge(gpu_hidden_states, gpu_lse, cpu_hidden_states, cpu_lse):
         """flashinfer.merge_state as used at models/attnserver.py:308 (base-2 LSEs)."""
@@ -134,5 +177,8 @@ class LSHSparseAttnServer:
         self.output.zero_()
         for i in range(self.num_layers):
             self.avg_k[i].zero_()
+        self.kv_last_page_len.zero_()
+        self.window_nnz.zero_()
         self.lsh_retriever.clear()
         self.attn_server.clear()
+        self.window_server.clear()

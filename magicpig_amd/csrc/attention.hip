@@ -379,6 +379,36 @@ __global__ void attn_fill_kernel(const uint16_t* __restrict__ k, const uint16_t*
     }
 }
 
+// flashinfer.append_paged_kv_cache as used at models/attnserver.py:281-290: write this step's
+// (k, v) of every request at row pos[b] of its kv heads.  k, v: bf16 [B][Hkv][D].
+__global__ void attn_append_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+                                   const int32_t* __restrict__ pos, int Hkv, int D, int64_t M,
+                                   uint16_t* __restrict__ kv, float* __restrict__ kn, int* __restrict__ err) {
+    const int b = blockIdx.x / Hkv;
+    const int64_t unit = blockIdx.x;                 // b*Hkv + kv head
+    const int p = pos[b];
+    if (p < 0 || (int64_t)p >= M) {                  // window full: report, never write out of bounds
+        if (threadIdx.x == 0) atomicOr(err, 2);
+        return;
+    }
+    const int cpr = D / 8;
+    double ss = 0.0;
+    if ((int)threadIdx.x < cpr) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(k + unit * D + threadIdx.x * 8);
+        const u32x4 c = *reinterpret_cast<const u32x4*>(v + unit * D + threadIdx.x * 8);
+        uint16_t* dst = kv + (unit * M + p) * 2 * D + threadIdx.x * 8;
+        *reinterpret_cast<u32x4*>(dst) = a;
+        *reinterpret_cast<u32x4*>(dst + D) = c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double lo = (double)bf16_lo(a[j]), hi = (double)bf16_hi(a[j]);
+            ss += lo * lo + hi * hi;
+        }
+    }
+    ss = wave_sum(ss);                               // cpr <= 16 lanes of wave 0 contribute
+    if (threadIdx.x == 0) kn[unit * M + p] = bf16_bits_to_f32(f32_to_bf16_rne((float)sqrt(ss)));
+}
+
 // flashinfer.merge_state as used at models/attnserver.py:308 (base-2 LSEs).
 __global__ void merge_state_kernel(const uint16_t* __restrict__ va, const float* __restrict__ sa,
                                    const uint16_t* __restrict__ vb, const float* __restrict__ sb,
@@ -457,6 +487,12 @@ hipError_t launch_attn_fill(const uint16_t* k, const uint16_t* v, const float* k
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(attn_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, k, v, knorm, Hkv,
                        n, D, M, kv, kn);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_append(const uint16_t* k, const uint16_t* v, const int32_t* pos, int B, int Hkv,
+                              int D, int64_t M, uint16_t* kv, float* kn, int* err, hipStream_t st) {
+    hipLaunchKernelGGL(attn_append_kernel, dim3(B * Hkv), dim3(64), 0, st, k, v, pos, Hkv, D, M, kv, kn, err);
     return hipGetLastError();
 }
 

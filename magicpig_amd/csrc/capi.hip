@@ -41,6 +41,8 @@ hipError_t launch_attn_fill(const uint16_t*, const uint16_t*, const float*, int,
                             int64_t, uint16_t*, float*, hipStream_t);
 hipError_t launch_merge_state(const uint16_t*, const float*, const uint16_t*, const float*, int,
                               int, uint16_t*, float*, hipStream_t);
+hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int64_t,
+                              uint16_t*, float*, int*, hipStream_t);
 
 extern unsigned long long* g_stamp;
 
@@ -124,6 +126,7 @@ struct mp_attn {
     float2* part_ml = nullptr;     // [max_slices]
     float2* head_mz = nullptr;     // [BH] (max logit, Z) of the last call
     int* head_cnt = nullptr;       // [BH] arrival tickets of the in-launch merge (zero between calls)
+    int* err = nullptr;            // device-side validation flag (append past max_length)
     int32_t* last_nnz = nullptr;   // [BH] staging copy of host-side nnz
     const int32_t* lastz = nullptr;// device nnz of the last call (for get_score): last_nnz or the
                                    // caller's own device buffer (valid until it changes)
@@ -449,10 +452,10 @@ static void attn_free(mp_attn_t* h) {
     for (auto p : h->kn) if (p) (void)hipFree(p);
     h->kv.clear();
     h->kn.clear();
-    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt};
+    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt, h->err};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->score = nullptr; h->part_o = nullptr; h->part_ml = nullptr; h->head_mz = nullptr;
-    h->last_nnz = nullptr; h->head_cnt = nullptr;
+    h->last_nnz = nullptr; h->head_cnt = nullptr; h->err = nullptr;
     h->allocated = false;
 }
 
@@ -493,6 +496,7 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
     if (rc == MP_OK) rc = alloc_zero((void**)&h->head_mz, BH * sizeof(float2));
     if (rc == MP_OK) rc = alloc_zero((void**)&h->last_nnz, BH * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->head_cnt, BH * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->err, 4);
     if (rc != MP_OK) { attn_free(h); return rc; }
     // grid.x of the attention kernel: B*H * GX workgroups of 4 waves should fill the chip exactly
     // once (4 resident workgroups per CU at 120 VGPRs): no second dispatch round with a ragged tail.
@@ -535,6 +539,29 @@ int mp_attn_fill(mp_attn_t* h, int layer_id, int request_id, const uint16_t* k, 
     MP_HIP_CHECK(launch_attn_fill((const uint16_t*)kd, (const uint16_t*)vd, (const float*)nd, h->Hkv,
                                   n, h->D, h->M, kv, knd, st));
     if (mem == MP_MEM_HOST) MP_HIP_CHECK(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
+int mp_attn_append(mp_attn_t* h, int layer_id, const uint16_t* k, const uint16_t* v,
+                   const int32_t* pos, mp_stream_t stream) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_append: not allocated");
+    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_attn_append: layer_id out of range");
+    MP_REQUIRE(k && v && pos, MP_ERR_INVALID, "mp_attn_append: null argument");
+    MP_HIP_CHECK(launch_attn_append(k, v, pos, h->B, h->Hkv, h->D, h->M, h->kv[layer_id], h->kn[layer_id],
+                                    h->err, (hipStream_t)stream));
+    return MP_OK;
+}
+
+int mp_attn_check(mp_attn_t* h, mp_stream_t stream) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_check: not allocated");
+    hipStream_t st = (hipStream_t)stream;
+    int flag = 0;
+    MP_HIP_CHECK(hipMemcpyAsync(&flag, h->err, 4, hipMemcpyDeviceToHost, st));
+    MP_HIP_CHECK(hipStreamSynchronize(st));
+    if (flag) {
+        MP_HIP_CHECK(hipMemsetAsync(h->err, 0, 4, st));
+        return fail(MP_ERR_DATA, "mp_attn_check: an append hit a full store (position >= max_length)");
+    }
     return MP_OK;
 }
 

@@ -87,6 +87,21 @@ class SparseAttentionServer:
         L.check(L.lib().mp_attn_full(self._h, layer_id, L.ptr(output), L.ptr(max_value_expsum),
                                      L.ptr(query), qd, L.ptr(nnz), mem, L.current_stream(output)))
 
+    def append(self, layer_id: int, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor) -> None:
+        """Not in the reference class: the role of flashinfer.append_paged_kv_cache
+        (models/attnserver.py:281-290) for a store used as the static window.  k, v bf16
+        [B, Hkv, D], pos int32 [B] (row to write for each request); CUDA tensors."""
+        L.expect(k, torch.bfloat16, (self.B, self.Hkv, self.D), "k")
+        L.expect(v, torch.bfloat16, (self.B, self.Hkv, self.D), "v")
+        L.expect(pos, torch.int32, (self.B,), "pos")
+        if not (k.is_cuda and v.is_cuda and pos.is_cuda):
+            raise ValueError("append takes CUDA tensors")
+        L.check(L.lib().mp_attn_append(self._h, layer_id, L.ptr(k), L.ptr(v), L.ptr(pos), L.current_stream(k)))
+
+    def check(self) -> None:
+        """Raise if a device-side validation failed since the last check (append past max_length)."""
+        L.check(L.lib().mp_attn_check(self._h, L.current_stream()))
+
     def clear(self) -> None:
         """SparseAttentionServer::clear, sparse_attention.cc:586-598."""
         L.check(L.lib().mp_attn_clear(self._h, L.current_stream()))

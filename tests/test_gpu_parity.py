@@ -516,6 +516,79 @@ def test_server_fill_centres_keys(mp):
     assert torch.isfinite(out.float()).all()
 
 
+def test_decode_full_window_plus_sparse_merge(mp):
+    """LSHSparseAttnServer.decode_full (models/attnserver.py:261-312): static-window exact attention
+    (sink + local + generated tokens, centred keys) merged by base-2 LSE with the LSH-sampled part.
+    Oracle: torch f32 restatement of the window part (attnserver_dist.py:832-851) + the CPU oracle for
+    the sampled part + oracle.merge_state.  FlashInfer is not in the reference tree: parity of this
+    row is pinned only by that in-tree torch statement of the math."""
+    import math
+
+    H, Hkv, D, K, L, seq, B = 8, 2, 128, 8, 40, 700, 2
+    G = H // Hkv
+    gen = torch.Generator().manual_seed(11)
+    W = synth.normal_bf16_bits(91, (D, K * L))
+    server = mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, max_length=1024,
+                                    dense_layers=(), hash_func=bf16_t(W, "cuda"), generation_buffer=8)
+    kcs, vcs = [], []
+    for b in range(B):
+        kc = (torch.randn((seq, Hkv, D), generator=gen) * 0.5 + 0.3).to(torch.bfloat16)
+        vc = torch.randn((seq, Hkv, D), generator=gen).to(torch.bfloat16)
+        server.fill(0, b, kc.cuda(), vc.cuda(), seq)
+        server.build_table(0, b, seq)
+        kcs.append(kc)
+        vcs.append(vc)
+    n = seq - 68
+    new_k, new_v = [], []
+    for step in range(3):
+        server.plan()
+        q = torch.randn((B, H, 1, D), generator=gen).to(torch.bfloat16)
+        # pull some queries toward a key so the sampled part carries weight
+        for b in range(B):
+            for h in range(0, H, 2):
+                q[b, h, 0] = (0.5 * q[b, h, 0].float() + 2.0 * (kcs[b][100 + 7 * h + step, h // G].float() - 0.3)).to(torch.bfloat16)
+        k_new = torch.randn((B, Hkv, 1, D), generator=gen).to(torch.bfloat16)
+        v_new = torch.randn((B, Hkv, 1, D), generator=gen).to(torch.bfloat16)
+        new_k.append(k_new)
+        new_v.append(v_new)
+        hidden = server.decode_full(q.cuda(), k_new.cuda(), v_new.cuda(), 0)
+        server.window_server.check()
+        torch.cuda.synchronize()
+        # ---- oracle
+        s_out = bits_of(server.output)                         # sampled part, checked elsewhere;
+        s_lse = server.max_value_expsum[1].cpu().numpy()       # here it is an input of the merge
+        w_out = np.zeros((B * H, D), np.float32)
+        w_lse = np.zeros((B * H,), np.float32)
+        for b in range(B):
+            off = kcs[b][4:seq - 64].transpose(0, 1).contiguous()          # same ops as fill()
+            avg = off.mean(dim=1, keepdim=True)                            # bf16 [Hkv,1,D]
+            wk = torch.cat([kcs[b][:4], kcs[b][seq - 64:seq]] + [x[b].transpose(0, 1) for x in new_k], 0)
+            wv = torch.cat([vcs[b][:4], vcs[b][seq - 64:seq]] + [x[b].transpose(0, 1) for x in new_v], 0)
+            wk = (wk.transpose(0, 1) - avg).float()                        # [Hkv, W, D] centred (bf16 op, then f32)
+            wv = wv.transpose(0, 1).float()
+            for h in range(H):
+                sc = (wk[h // G] @ q[b, h, 0].float()) / math.sqrt(D)
+                p = torch.softmax(sc, 0)
+                w_out[b * H + h] = (p @ wv[h // G]).numpy()
+                w_lse[b * H + h] = float(torch.logsumexp(sc, 0)) / math.log(2)
+        assert np.allclose(server.window_mve[1].cpu().numpy(), w_lse, atol=2e-3)
+        assert np.allclose(server.window_out.float().cpu().numpy(), w_out, rtol=2 ** -7, atol=2e-3)
+        mo, ms = oracle.merge_state(bits_of(server.window_out), server.window_mve[1].cpu().numpy(), s_out, s_lse)
+        got = bits_of(hidden.reshape(B * H, D))
+        assert np.allclose(synth.bf16_bits_to_f32(got), synth.bf16_bits_to_f32(mo), rtol=2 ** -7, atol=1e-5)
+        # and end to end against an all-f32 merge of the two oracle parts
+        wa = np.exp2(w_lse - np.maximum(w_lse, s_lse)); sa = np.exp2(s_lse - np.maximum(w_lse, s_lse))
+        ref = (wa[:, None] * w_out + sa[:, None] * synth.bf16_bits_to_f32(s_out)) / (wa + sa)[:, None]
+        assert np.allclose(synth.bf16_bits_to_f32(got), ref, rtol=1e-2, atol=3e-3)
+    assert server.kv_last_page_len.tolist() == [71, 71]
+    # the window is 4 + 64 + 8 rows: 6 more appends overflow it and are reported, not written
+    for _ in range(6):
+        server.plan()
+        server.decode_full(q.cuda(), k_new.cuda(), v_new.cuda(), 0)
+    with pytest.raises(mp.MagicPigError):
+        server.window_server.check()
+
+
 # ------------------------------------------------------------------ BASELINE cfg-1 shape
 
 def test_cfg1_shaped_retrieve_sha(mp):
