@@ -238,7 +238,7 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
                     dot8_bf16_chain(acc, q4[kc], Wk4[c + (int64_t)kc * ha.KLpad]);
                 dot_settle(acc);
                 bit = acc > 0.f;
-                if (fabsf(acc) <= (1.0f / 32768.0f) * rn * ha.wnorm[c]) {   // 2^-15 guard band (simhash.hip)
+                if (fabsf(acc) <= (1.0f / 65536.0f) * rn * ha.wnorm[c]) {   // 2^-16 guard band (simhash.hip SH_EPS)
                     double ex = 0.0;
                     for (int kc = 0; kc < chunks; ++kc) {
                         const u32x4 wv = Wk4[c + (int64_t)kc * ha.KLpad];
