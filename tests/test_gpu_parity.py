@@ -92,9 +92,9 @@ def test_query_simhash_guard_band_covers_mfma_error(mp):
 
 
 def test_simhash_exact_sign_when_every_dot_product_is_tiny(mp):
-    """Forces the rare branch (HIP guide rule 26): every hyperplane is made almost orthogonal to the
-    (normalised) query, so EVERY dot product sits inside the guard band and its bit comes from the
-    exact f64 recomputation -- in the MFMA kernel (codes compared directly) and in the hash fused
+    """Forces the rare branch (HIP guide rule 26): every hyperplane is built exactly or almost exactly
+    orthogonal to one of the (normalised) queries, so a quarter of all dot products sit inside the
+    guard band -- true ties and +-1e-7 -- and their bits come from the exact f64 recomputation -- in the MFMA kernel (codes compared directly) and in the hash fused
     into the retrieve kernel (nnz / selected ids compared through a decode)."""
     D, K, L, H, Hkv, n, M = 128, 10, 24, 4, 2, 1500, 1536
     qb = synth.normal_bf16_bits(321, (H, D))
@@ -269,6 +269,50 @@ def test_device_table_build_equals_sorted_fill(mp, name):
         for b in range(bounds.shape[2]):
             s, e = bounds[gi, l, b]
             assert np.all(np.diff(table[gi, l, s:e]) > 0)
+
+
+@pytest.mark.parametrize("K,L,H,Hkv,B,n,M", [(4, 1100, 4, 2, 1, 600, 640),      # more tables than threads in a workgroup
+                                             (15, 12, 8, 8, 2, 3000, 3001),    # widest codes (int16), odd max_length
+                                             (11, 300, 8, 1, 1, 5000, 5056)])  # cfg-4 hyper-parameters
+def test_retrieve_and_fused_hash_unusual_shapes(mp, K, L, H, Hkv, B, n, M):
+    """Sets + nnz bit-exact against the oracle for table counts / code widths / lengths away from the
+    headline config, through both entry points (stand-alone calls and the fused decode)."""
+    D = 128
+    keys, kns, vals, W, qb = cases.case_inputs(500 + K + L, B, H, Hkv, n, D, K, L)
+    server = mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, num_sink_tokens=0,
+                                    num_local_tokens=0, max_length=M, dense_layers=(), hash_func=bf16_t(W, "cuda"))
+    olsh = oracle.LSH()
+    olsh.alloc(K, L, 1, H, Hkv, B, M)
+    for b in range(B):
+        server.hash_code_buffer = server.hasher.keys(bf16_t(keys[b], "cuda"))
+        kc = server.hash_code_buffer.cpu().numpy()
+        assert np.array_equal(kc, oracle.simhash_keys(keys[b], W, K, L))
+        server.build_table(0, b, n)
+        server.attn_server.fill(0, b, bf16_t(keys[b], "cuda"), bf16_t(vals[b], "cuda"), torch.from_numpy(kns[b]).cuda())
+        sc, si = cases.stable_sort_codes(kc)
+        olsh.fill(0, b, sc, si)
+    qcodes, _ = oracle.simhash_query(qb, W, K, L)
+    ores = np.zeros((B * H, M), np.int32)
+    onnz = np.zeros((B * H,), np.int32)
+    olsh.batch_retrieve(0, qcodes, ores, onnz)
+    # stand-alone entry points
+    codes, qn = server.hasher.query(bf16_t(qb, "cuda"))
+    assert np.array_equal(codes.cpu().numpy(), qcodes)
+    res = torch.zeros((B * H, M), dtype=torch.int32, device="cuda")
+    nnz = torch.zeros((B * H,), dtype=torch.int32, device="cuda")
+    server.lsh_retriever.batch_retrieve(0, codes, res, nnz)
+    assert np.array_equal(nnz.cpu().numpy(), onnz)
+    r = res.cpu().numpy()
+    for h in range(B * H):
+        assert np.array_equal(r[h, :onnz[h]], np.sort(ores[h, :onnz[h]]))
+    # fused decode entry
+    out, lse = server.decode(bf16_t(qb, "cuda").view(B, H, 1, D), 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(server.nnz.cpu().numpy(), onnz)
+    rr = dict(dims=(B, H, Hkv, n, M, D, K, L), inputs=(keys, kns, vals, W, qb), nnz=onnz, results=r,
+              out=bits_of(out.reshape(B * H, D)), mve=server.max_value_expsum.cpu().numpy(),
+              probs=server.attn_server.get_score().reshape(B * H, M).cpu().numpy())
+    _check_attention(rr)
 
 
 def test_lsh_edge_cases(mp):
