@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=48)
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--table-build", default="sort", choices=["sort", "counting"])
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="examples/bench.py-style full decode step with synthetic weights (SURVEY 8f-3) "
+                         "instead of the hot path alone")
     return ap.parse_args()
 
 
@@ -187,6 +190,35 @@ def run_cpu_baseline(cfg, server, qs, steps):
     raise RuntimeError("cpu baseline worker failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
 
 
+# ---------------------------------------------------------------------------- end-to-end variant
+
+def end_to_end(args, cfg, rank, world, dev, dist):
+    """examples/bench.py:43-59 with synthetic weights: full decode step (embedding, 32 layers of
+    projections + RoPE + attention server + MLP, lm_head).  Not the headline metric: the model GEMMs are
+    torch-ROCm plumbing outside the north-star path."""
+    from magicpig_amd import decode_harness as dh
+    from magicpig_amd import sharding
+
+    assert cfg["model"].startswith("Llama-3.1-8B"), "--end-to-end is wired for the 8B shape"
+    steps, warmup = args.steps, args.warmup
+    dec = dh.SyntheticLlamaDecoder(dh.LLAMA_3_1_8B, K=cfg["K"], L=cfg["L"], batch_size=cfg["B"],
+                                   max_length=cfg["M"], generation_buffer=max(256, steps + warmup + 8),
+                                   dense_layers=cfg["dense"], device=str(dev), seed=rank)
+    ms, tps = dh.run_decode_benchmark(dec, cfg["P"], warmup=warmup, steps=steps, use_graph=not args.no_graph)
+    ms = sharding.max_over_ranks(ms, device=dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"end-to-end decode tokens/sec, synthetic-weight {cfg['model']} P={cfg['P']} K{cfg['K']}L{cfg['L']}",
+            "value": world * cfg["B"] * 1e3 / ms, "unit": "tokens/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.config} end-to-end: {cfg['model']} B={cfg['B']} P={cfg['P']}, random weights, "
+                                   "30 LSH-sparse layers + 2 dense layers + projections/MLP/lm_head (torch-ROCm)",
+                       "launch": "eager" if args.no_graph else "hipGraph"}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 # ---------------------------------------------------------------------------- main
 
 def main():
@@ -212,6 +244,8 @@ def main():
     from magicpig_amd import sharding
 
     cfg = CONFIGS[args.config]
+    if args.end_to_end:
+        return end_to_end(args, cfg, rank, world, dev, dist)
     B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
     sparse_layers = [i for i in range(cfg["layers"]) if i not in cfg["dense"]]
     NL = len(sparse_layers)

@@ -1,0 +1,250 @@
+"""Decode-step harness at Llama shapes with SYNTHETIC weights.
+
+Restates the decode side of the reference's minimal Llama runtime -- `LLM.inference` /
+`layer_compute` (models/llama.py:185-220, 288-301) with the helpers of models/utils.py -- around
+this repository's attention path, so that the loop and the printed metrics of examples/bench.py
+(:43-59: prefill B requests, 32 warm-up + 128 timed `llm.inference` steps, ms/token and token/s)
+can be reproduced without HF weights (no network here): weights are random tensors of the model's
+shapes, the prompt's KV cache is synthetic.
+
+What runs where:
+  * sparse layers : LSHSparseAttnServer.decode_full -- q-hash + retrieve + sampled attention
+                    (the hot path, HIP), static-window attention + LSE merge (HIP);
+  * dense layers  : (0, 16, ...; models/attnserver.py:235-259) exact attention over the whole
+                    sequence = the dense mode of the same HIP kernel on a full-length store;
+  * everything else (embedding, RMSNorm, q/k/v/o and MLP projections, RoPE, lm_head) is plain
+    torch-ROCm -- model plumbing outside the north-star path, kept only so that an end-to-end
+    tokens/s can be quoted next to the hot-path number.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from .attnserver import LSHSparseAttnServer
+from .sparse_attention import SparseAttentionServer
+
+
+@dataclass
+class LlamaShape:
+    hidden_size: int = 4096
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    intermediate_size: int = 14336
+    vocab_size: int = 128256
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+
+LLAMA_3_1_8B = LlamaShape()
+LLAMA_3_1_70B = LlamaShape(hidden_size=8192, num_hidden_layers=80, num_attention_heads=64,
+                           num_key_value_heads=8, intermediate_size=28672)
+
+
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """models/utils.py:47-56 (`flashinfer.rmsnorm`): x * rsqrt(mean(x^2) + eps) * w, f32 inside."""
+    xf = x.float()
+    return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype) * weight
+
+
+def rotate_half(x: torch.Tensor) -> torch.Tensor:
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def apply_rotary_pos_emb(x, cos, sin, position_ids, unsqueeze_dim=1):
+    """models/utils.py:36-45."""
+    c = cos[position_ids].unsqueeze(unsqueeze_dim)
+    s = sin[position_ids].unsqueeze(unsqueeze_dim)
+    return (x * c) + (rotate_half(x) * s)
+
+
+class SyntheticLlamaDecoder:
+    """`LLM` of models/llama.py:64-101 reduced to what `inference` needs, with random weights."""
+
+    def __init__(self, shape: LlamaShape = LLAMA_3_1_8B, K: int = 10, L: int = 150, batch_size: int = 1,
+                 max_length: int = 8192, generation_buffer: int = 256, dense_layers=(0, 16, 32, 48, 64),
+                 device: str = "cuda:0", dtype=torch.bfloat16, seed: int = 0):
+        self.shape, self.K, self.L = shape, K, L
+        self.batch_size, self.max_length = batch_size, max_length
+        self.device, self.dtype = torch.device(device), dtype
+        self.num_layers = shape.num_hidden_layers
+        self.dense_layers = tuple(i for i in dense_layers if i < self.num_layers)
+        self.sparse_layers = tuple(i for i in range(self.num_layers) if i not in self.dense_layers)
+        H, Hkv, D = shape.num_attention_heads, shape.num_key_value_heads, shape.head_dim
+        g = torch.Generator(device=self.device).manual_seed(seed)
+
+        def w(*dims, scale):
+            return (torch.randn(dims, device=self.device, dtype=torch.float32, generator=g) * scale).to(dtype)
+
+        hs, it = shape.hidden_size, shape.intermediate_size
+        self.embed_tokens = w(shape.vocab_size, hs, scale=1.0)
+        self.lm_head = w(shape.vocab_size, hs, scale=hs ** -0.5)
+        self.norm_weight = torch.ones(hs, device=self.device, dtype=dtype)
+        self.layers = []
+        for _ in range(self.num_layers):
+            self.layers.append(dict(
+                wq=w(H * D, hs, scale=hs ** -0.5), wk=w(Hkv * D, hs, scale=hs ** -0.5),
+                wv=w(Hkv * D, hs, scale=hs ** -0.5), wo=w(hs, H * D, scale=(H * D) ** -0.5),
+                gate=w(it, hs, scale=hs ** -0.5), up=w(it, hs, scale=hs ** -0.5),
+                down=w(hs, it, scale=it ** -0.5),
+                ln1=torch.ones(hs, device=self.device, dtype=dtype),
+                ln2=torch.ones(hs, device=self.device, dtype=dtype)))
+        # RoPE tables (models/llama.py:114-126)
+        inv_freq = 1.0 / (shape.rope_theta ** (torch.arange(0, D, 2, device=self.device).float() / D))
+        pos = torch.arange(0, max_length, device=self.device).float()
+        freqs = torch.outer(pos, inv_freq)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        self.cos_cache, self.sin_cache = emb.cos().to(dtype), emb.sin().to(dtype)
+        # attention state: sparse layers -> LSH server (indexed by position in sparse_layers);
+        # dense layers -> one full-length store (indexed by position in dense_layers)
+        self.sparse_index = {l: i for i, l in enumerate(self.sparse_layers)}
+        self.dense_index = {l: i for i, l in enumerate(self.dense_layers)}
+        self.attention_server = LSHSparseAttnServer(
+            max(1, len(self.sparse_layers)), H, Hkv, D, K=K, L=L, batch_size=batch_size,
+            generation_buffer=generation_buffer, max_length=max_length, dense_layers=(), device=device,
+            seed=seed + 7)
+        if self.dense_layers:
+            with torch.cuda.device(self.device):
+                self.dense_server = SparseAttentionServer()
+                self.dense_server.alloc(len(self.dense_layers), H, Hkv, D, batch_size, max_length)
+        BH = batch_size * H
+        self.dense_len = torch.zeros((batch_size,), dtype=torch.int32, device=self.device)
+        self.dense_nnz = torch.zeros((BH,), dtype=torch.int32, device=self.device)
+        self.dense_out = torch.zeros((BH, D), dtype=torch.bfloat16, device=self.device)
+        self.dense_mve = torch.zeros((2, BH), dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ prefill (synthetic KV)
+    def prefill_synthetic(self, request_id: int, seq_len: int, seed: int = 0, kv=None) -> None:
+        """Stands in for `LLM.prefill` (models/llama.py:304-325): per layer a KV cache bf16
+        [seq_len, Hkv, D] (random unless `kv(layer) -> (k, v)` supplies one) is handed to the attention
+        state exactly as `layer_prefill` does (:264, 282: fill + build_table)."""
+        Hkv, D = self.shape.num_key_value_heads, self.shape.head_dim
+        for layer in range(self.num_layers):
+            if kv is not None:
+                k, v = kv(layer)
+            else:
+                g = torch.Generator(device=self.device).manual_seed(seed * 1000 + layer)
+                k = torch.randn((seq_len, Hkv, D), device=self.device, generator=g).to(self.dtype)
+                v = torch.randn((seq_len, Hkv, D), device=self.device, generator=g).to(self.dtype)
+            if layer in self.dense_index:
+                kk = k.transpose(0, 1).contiguous()
+                self.dense_server.fill(self.dense_index[layer], request_id, kk, v.transpose(0, 1).contiguous(),
+                                       kk.norm(p=2, dim=-1).float())
+            else:
+                li = self.sparse_index[layer]
+                self.attention_server.fill(li, request_id, k, v, seq_len)
+                self.attention_server.build_table(li, request_id, seq_len)
+        self.dense_len[request_id] = seq_len
+
+    # ------------------------------------------------------------------ decode
+    def _dense_attention(self, q, k, v, layer: int) -> torch.Tensor:
+        """models/attnserver.py:235-259: append, then exact attention over the whole sequence."""
+        B, H, Hkv, D = self.batch_size, self.shape.num_attention_heads, self.shape.num_key_value_heads, self.shape.head_dim
+        di = self.dense_index[layer]
+        self.dense_server.append(di, k.reshape(B, Hkv, D).contiguous(), v.reshape(B, Hkv, D).contiguous(),
+                                 self.dense_len - 1)
+        self.dense_server.full_attention(di, self.dense_out, self.dense_mve, q.reshape(B * H, D), self.dense_nnz)
+        return self.dense_out.view(B, 1, H * D)
+
+    def plan(self) -> None:
+        self.attention_server.plan()
+        self.dense_len += 1
+        self.dense_nnz.copy_(self.dense_len.repeat_interleave(self.shape.num_attention_heads))
+
+    @torch.inference_mode()
+    def layer_compute(self, layer: int, hidden_states: torch.Tensor, position_ids: torch.Tensor) -> torch.Tensor:
+        """models/llama.py:185-220 (+ pre/post_attention_compute :134-183)."""
+        W = self.layers[layer]
+        B, H, Hkv, D = self.batch_size, self.shape.num_attention_heads, self.shape.num_key_value_heads, self.shape.head_dim
+        eps = self.shape.rms_norm_eps
+        residual = hidden_states
+        x = rms_norm(hidden_states, W["ln1"], eps)
+        q = F.linear(x, W["wq"]).view(B, 1, H, D).transpose(1, 2)
+        k = F.linear(x, W["wk"]).view(B, 1, Hkv, D).transpose(1, 2)
+        v = F.linear(x, W["wv"]).view(B, 1, Hkv, D).transpose(1, 2)
+        k = apply_rotary_pos_emb(k, self.cos_cache, self.sin_cache, position_ids)
+        q = apply_rotary_pos_emb(q, self.cos_cache, self.sin_cache, position_ids)
+        if layer in self.dense_index:
+            attn = self._dense_attention(q.contiguous(), k, v, layer)
+        else:
+            attn = self.attention_server.decode_full(q.contiguous(), k.contiguous(), v.contiguous(),
+                                                     self.sparse_index[layer])
+        h = residual + F.linear(attn.reshape(B, 1, H * D), W["wo"])
+        y = rms_norm(h, W["ln2"], eps)
+        y = F.linear(F.silu(F.linear(y, W["gate"])) * F.linear(y, W["up"]), W["down"])
+        return h + y
+
+    @torch.inference_mode()
+    def inference(self, input_ids: torch.Tensor, position_ids: torch.Tensor) -> torch.Tensor:
+        """models/llama.py:288-301.  input_ids, position_ids: int64 [B, 1]."""
+        self.plan()
+        hidden_states = F.embedding(input_ids, self.embed_tokens)
+        for layer in range(self.num_layers):
+            hidden_states = self.layer_compute(layer, hidden_states, position_ids)
+        hidden_states = rms_norm(hidden_states[:, -1:, :], self.norm_weight, self.shape.rms_norm_eps)
+        return F.linear(hidden_states, self.lm_head).float()
+
+
+def run_decode_benchmark(decoder: SyntheticLlamaDecoder, prompt_len: int, warmup: int = 32, steps: int = 128,
+                         use_graph: bool = True):
+    """examples/bench.py:43-59: prefill every request, 32 warm-up + 128 timed inference steps; returns
+    (ms per step, tokens/s).  The window's generation buffer must hold every new token.  With
+    use_graph the whole step (torch ops + HIP launches, including plan()'s length increments) is
+    captured once in a hipGraph and replayed; the token ids / positions are copied into static
+    buffers before each replay."""
+    import time
+
+    B = decoder.batch_size
+    for b in range(B):
+        decoder.prefill_synthetic(b, prompt_len, seed=b)
+    g = torch.Generator(device=decoder.device).manual_seed(123)
+    total = warmup + steps + 3
+    ids = torch.randint(0, decoder.shape.vocab_size, (B, total), device=decoder.device, generator=g)
+    pos = torch.arange(prompt_len, prompt_len + total, device=decoder.device).unsqueeze(0).repeat(B, 1)
+    s_ids, s_pos = ids[:, :1].clone(), pos[:, :1].clone()
+    graph = None
+    done = 0
+    if use_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                       # eager passes: lazy initialisation outside the capture
+                s_ids.copy_(ids[:, done:done + 1]); s_pos.copy_(pos[:, done:done + 1])
+                decoder.inference(s_ids, s_pos)
+                done += 1
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        s_ids.copy_(ids[:, done:done + 1]); s_pos.copy_(pos[:, done:done + 1])
+        with torch.cuda.graph(graph):
+            decoder.inference(s_ids, s_pos)
+        # (a capture records the step without executing it: lengths advance only on replay)
+
+    def one(i):
+        if graph is not None:
+            s_ids.copy_(ids[:, i:i + 1]); s_pos.copy_(pos[:, i:i + 1])
+            graph.replay()
+        else:
+            decoder.inference(ids[:, i:i + 1], pos[:, i:i + 1])
+
+    for i in range(done, done + warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(done + warmup, done + warmup + steps):
+        one(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    decoder.attention_server.window_server.check()
+    if decoder.dense_layers:
+        decoder.dense_server.check()
+    return dt / steps * 1e3, B * steps / dt
