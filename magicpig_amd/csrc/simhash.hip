@@ -44,8 +44,11 @@ __global__ void simhash_prepare_kernel(const uint16_t* __restrict__ W, int D, in
 // Block = 64 * max(4, tiles_per_wg) threads: wave w owns column tile w of the workgroup's span
 // and prefetches its B fragments (the hyperplanes) before the rows are staged, so the HBM/L2
 // latency of the planes overlaps the normalisation.
-template <int MODE, int D>
-__global__ __launch_bounds__(1024) void simhash_kernel(
+// MINW: minimum waves per SIMD the register allocation must allow.  The key side is a chain of
+// short dependent phases per workgroup (load 8 KB -> 8 MFMAs -> ballots -> pack): its throughput is
+// set by how many workgroups a CU can interleave, so it is compiled for 8 waves per SIMD (<= 64 VGPRs).
+template <int MODE, int D, int MINW>
+__global__ __launch_bounds__(1024, MINW) void simhash_kernel(
     const uint16_t* __restrict__ x,      // [R][D] bf16
     const uint16_t* __restrict__ Wt,     // [KLpad][D] bf16
     const float* __restrict__ wnorm,     // [KLpad]
@@ -275,7 +278,7 @@ static hipError_t launch_simhash_t(const uint16_t* x, const uint16_t* Wt, const 
     unsigned long long* stamp = (MODE == 0) ? g_stamp : nullptr;
 #define MP_SH_CASE(DD)                                                                          \
     if (D == DD) {                                                                              \
-        hipLaunchKernelGGL((simhash_kernel<MODE, DD>), grid, block, 0, st, x, Wt, wnorm, R, K, L, \
+        hipLaunchKernelGGL((simhash_kernel<MODE, DD, (MODE == 1 ? 2 : 1)>), grid, block, 0, st, x, Wt, wnorm, R, K, L, \
                            tp, tiles, ld_out, codes, qnorm, dbg, stamp);                        \
         return hipGetLastError();                                                               \
     }
