@@ -580,6 +580,50 @@ def test_fused_decode_layer(mp, name, table_build):
     assert np.allclose(lse.cpu().numpy().reshape(-1), r["mve"][1])
 
 
+def test_clear_and_refill(mp):
+    """clear() x2 (lsh.cc:293-306, sparse_attention.cc:586-598): after a clear every bucket is empty
+    (nnz == 0, out == 0, LSE == -inf), get_mask is all zero, the stores read back as zeros, and a
+    refill with other data behaves like a fresh object."""
+    g = cases.load_golden("b2_k8_l60")
+    seed, B, H, Hkv, n, M, D, K, L = (int(x) for x in g["meta"])
+    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L)
+    server = mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, num_sink_tokens=0,
+                                    num_local_tokens=0, max_length=M, dense_layers=(), hash_func=bf16_t(W, "cuda"))
+
+    def load(kk, vv, nn):
+        for b in range(B):
+            server.hash_code_buffer = server.hasher.keys(bf16_t(kk[b], "cuda"))
+            server.build_table(0, b, n)
+            server.attn_server.fill(0, b, bf16_t(kk[b], "cuda"), bf16_t(vv[b], "cuda"), torch.from_numpy(nn[b]).cuda())
+
+    load(keys, vals, kns)
+    q = bf16_t(qb, "cuda").view(B, H, 1, D)
+    server.decode(q, 0)
+    assert np.array_equal(server.nnz.cpu().numpy(), g["nnz"])
+    assert np.array_equal(np.stack([np.bincount(m.astype(np.int64), minlength=3) for m in
+                                    server.lsh_retriever.get_mask().numpy().reshape(B * H, M)]), g["mask_hist"])
+    server.clear()
+    out, lse = server.decode(q, 0)
+    torch.cuda.synchronize()
+    assert int(server.nnz.abs().sum()) == 0 and not out.float().abs().sum().item()
+    assert torch.isinf(lse).all() and (lse < 0).all()
+    assert not server.lsh_retriever.get_mask().any()
+    assert not server.attn_server.get_key_cache(0).float().abs().sum().item()
+    assert not server.attn_server.get_key_norm(0).abs().sum().item()
+    # refill with DIFFERENT data: results equal a fresh object's
+    keys2, kns2, vals2, _, _ = cases.case_inputs(seed + 99, B, H, Hkv, n, D, K, L)
+    load(keys2, vals2, kns2)
+    out2, lse2 = server.decode(q, 0)
+    fresh = mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, num_sink_tokens=0,
+                                   num_local_tokens=0, max_length=M, dense_layers=(), hash_func=bf16_t(W, "cuda"))
+    server, keep = fresh, server
+    load(keys2, vals2, kns2)
+    out3, lse3 = fresh.decode(q, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(keep.nnz, fresh.nnz) and int(fresh.nnz.sum()) > 0
+    assert torch.equal(out2, out3) and torch.equal(lse2, lse3)
+
+
 def test_server_fill_centres_keys(mp):
     """LSHSparseAttnServer.fill (models/attnserver.py:112-175): sink/local split, centring, norms."""
     H, Hkv, D, K, L, seq = 8, 2, 128, 8, 20, 600
