@@ -17,8 +17,8 @@ int simhash_supported(int D, int K);
 hipError_t launch_simhash_prepare(const uint16_t*, int, int, int, uint16_t*, uint16_t*, float*, hipStream_t);
 hipError_t launch_simhash_query(const uint16_t*, const uint16_t*, const float*, int, int, int, int,
                                 int32_t*, float*, float*, hipStream_t);
-hipError_t launch_simhash_keys(const uint16_t*, const uint16_t*, const float*, int64_t, int, int,
-                               int, int16_t*, hipStream_t);
+hipError_t launch_simhash_keys(const uint16_t*, const uint16_t*, const float*, int, int64_t, int,
+                               int, int, int16_t*, hipStream_t);
 size_t retrieve_lds_bytes(int64_t M, int L);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int2*,
                            int32_t*, int*, hipStream_t);
@@ -229,9 +229,7 @@ int mp_simhash_keys(mp_simhash_t* s, const uint16_t* keys, int Hkv, int64_t n, i
         kd = dk.as<uint16_t>();
         cd = dc.as<int16_t>();
     }
-    for (int i = 0; i < Hkv; ++i)
-        MP_HIP_CHECK(launch_simhash_keys(kd + (size_t)i * n * s->D, s->Wt, s->wnorm, n, s->D, s->K,
-                                         s->L, cd + (size_t)i * s->L * n, st));
+    MP_HIP_CHECK(launch_simhash_keys(kd, s->Wt, s->wnorm, Hkv, n, s->D, s->K, s->L, cd, st));
     if (mem == MP_MEM_HOST) {
         MP_HIP_CHECK(hipStreamSynchronize(st));
         MP_HIP_CHECK(hipMemcpy(codes, dc.p, cb, hipMemcpyDeviceToHost));

@@ -72,7 +72,7 @@ __device__ __forceinline__ void dot_settle(float& acc) { asm("s_nop 3" : "+v"(ac
 // One lane of workgroup 0 records the 100 MHz wall clock at phase boundaries.
 #define MP_STAMP(stamp, slot)                                                               \
     do {                                                                                    \
-        if ((stamp) != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)   \
+        if ((stamp) != nullptr && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) \
             (stamp)[(slot)] = wall_clock64();                                               \
     } while (0)
 
@@ -88,6 +88,34 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
     return v;
+}
+// Reductions over the 16 lanes of a DPP row (lanes 16r .. 16r+15) by row rotation: four VALU
+// instructions with a DPP operand instead of four ds_bpermute round trips; every lane of the
+// row ends up with the result.
+template <int N>
+__device__ __forceinline__ float dpp_row_ror(float v) {
+    const int x = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x120 + N, 0xf, 0xf, true));
+}
+template <int N>
+__device__ __forceinline__ uint32_t dpp_row_ror(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x120 + N, 0xf, 0xf, true);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_row_ror<8>(v);
+    v += dpp_row_ror<4>(v);
+    v += dpp_row_ror<2>(v);
+    v += dpp_row_ror<1>(v);
+    return v;
+}
+// max of NON-NEGATIVE floats (ordered like their bit patterns; integer max needs no NaN canonicalisation)
+__device__ __forceinline__ float row16_max_nonneg(float f) {
+    uint32_t v = (uint32_t)__float_as_int(f);
+    v = max(v, dpp_row_ror<8>(v));
+    v = max(v, dpp_row_ror<4>(v));
+    v = max(v, dpp_row_ror<2>(v));
+    v = max(v, dpp_row_ror<1>(v));
+    return __int_as_float((int)v);
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -38,22 +38,19 @@ __global__ void simhash_prepare_kernel(const uint16_t* __restrict__ W, int D, in
     wnorm[n] = (float)sqrt(ss) * 1.000001f;  // rounded up: it is used as an upper bound
 }
 
-// MODE 0: query rows -- L2-normalise in bf16 exactly as torch does (attnserver.py:264-266),
-//         codes int32 [R][L], optional qnorm f32 [R].
-// MODE 1: key rows   -- no normalisation (attnserver.py:162), codes int16 [L][n] (transposed).
+// Query rows (the standalone form of attnserver.py:264-270; the decode path uses the hash fused
+// into the retrieve kernel): L2-normalise in bf16 exactly as torch does, codes int32 [R][L],
+// optional qnorm f32 [R].  One workgroup per 32 rows x one span of whole tables.
 // Block = 64 * max(4, tiles_per_wg) threads: wave w owns column tile w of the workgroup's span
 // and prefetches its B fragments (the hyperplanes) before the rows are staged, so the HBM/L2
 // latency of the planes overlaps the normalisation.
-// MINW: minimum waves per SIMD the register allocation must allow.  The key side is a chain of
-// short dependent phases per workgroup (load 8 KB -> 8 MFMAs -> ballots -> pack): its throughput is
-// set by how many workgroups a CU can interleave, so it is compiled for 8 waves per SIMD (<= 64 VGPRs).
-template <int MODE, int D, int MINW>
-__global__ __launch_bounds__(1024, MINW) void simhash_kernel(
+template <int D>
+__global__ __launch_bounds__(1024) void simhash_query_kernel(
     const uint16_t* __restrict__ x,      // [R][D] bf16
     const uint16_t* __restrict__ Wt,     // [KLpad][D] bf16
     const float* __restrict__ wnorm,     // [KLpad]
-    int64_t R, int K, int L, int tables_per_wg, int tiles_per_wg, int64_t ld_out,
-    void* __restrict__ codes_out, float* __restrict__ qnorm, float* __restrict__ dbg_acc,
+    int64_t R, int K, int L, int tables_per_wg, int tiles_per_wg,
+    int32_t* __restrict__ codes_out, float* __restrict__ qnorm, float* __restrict__ dbg_acc,
     unsigned long long* __restrict__ stamp) {
     constexpr int KSTEPS = D / 16;
     constexpr int STRIDE = D + 8;        // +16 B pad: conflict-free ds_read_b128 across rows
@@ -80,7 +77,7 @@ __global__ __launch_bounds__(1024, MINW) void simhash_kernel(
         wn = wnorm[n] * SH_EPS;
     }
 
-    // ---- phase A: stage 32 rows (normalised for MODE 0) into LDS; 8 threads per row
+    // ---- phase A: stage 32 normalised rows into LDS; 8 threads per row
     if (tid < SH_ROWS * 8) {
         constexpr int PER = D / 8;       // elements per thread: 8, 16 or 32
         const int row = tid >> 3, part = tid & 7;
@@ -110,12 +107,11 @@ __global__ __launch_bounds__(1024, MINW) void simhash_kernel(
         ss += __shfl_xor(ss, 1);
         ss += __shfl_xor(ss, 2);
         ss += __shfl_xor(ss, 4);
-        double ssn = ss;                 // sum of squares of what goes to LDS (guard bound)
-        if (MODE == 0) {
+        double ssn = 0.0;                // sum of squares of what goes to LDS (guard bound)
+        {
             const float nrm = (float)sqrt((double)(float)ss);         // == sqrtf(f32 sum), correctly rounded
             const float nb = bf16_bits_to_f32(f32_to_bf16_rne(nrm));  // torch: the norm is a bf16 tensor
             if (qnorm != nullptr && blockIdx.x == 0 && part == 0 && gr < R) qnorm[gr] = nrm;
-            ssn = 0.0;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 // IEEE f32 division (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt),
@@ -214,9 +210,7 @@ __global__ __launch_bounds__(1024, MINW) void simhash_kernel(
     // ---- phase C: K-bit pack (bit i of code l <- column l*K + i), coalesced stores
     const uint32_t kmask = (1u << K) - 1u;
     for (int p = tid; p < SH_ROWS * tables_per_wg; p += blockDim.x) {
-        int row, tb;
-        if (MODE == 0) { row = p / tables_per_wg; tb = p % tables_per_wg; }   // codes[r][l]: l fastest
-        else           { tb = p / SH_ROWS;        row = p % SH_ROWS; }        // codes[l][t]: t fastest
+        const int row = p / tables_per_wg, tb = p % tables_per_wg;          // codes[r][l]: l fastest
         const int l = table0 + tb;
         const int64_t gr = r0 + row;
         if (l >= L || gr >= R) continue;
@@ -224,10 +218,289 @@ __global__ __launch_bounds__(1024, MINW) void simhash_kernel(
         uint32_t v = s_bits[row][w] >> sh;
         if (sh + K > 32) v |= s_bits[row][w + 1] << (32 - sh);
         v &= kmask;
-        if (MODE == 0) reinterpret_cast<int32_t*>(codes_out)[gr * ld_out + l] = (int32_t)v;
-        else           reinterpret_cast<int16_t*>(codes_out)[(int64_t)l * ld_out + gr] = (int16_t)v;
+        codes_out[gr * L + l] = (int32_t)v;
     }
     MP_STAMP(stamp, 3);
+}
+
+// ---------------------------------------------------------------- key hashing at prefill
+// models/attnserver.py:159-168: keys [heads][n][D] -> codes int16 [heads][L][n]; the one place of
+// the path where MFMA throughput matters (37.6 GFLOP per kv head at cfg 1).  A workgroup of eight
+// waves owns floor(256 / K) tables -- wave w keeps the B fragments of planes 32w .. 32w+31 of that
+// span in registers for the whole kernel -- and walks chunk_tiles consecutive 32-row tiles:
+//   * the rows of tile t+2 are requested while tile t is on the matrix pipe and tile t+1 is being
+//     written to the other half of a double-buffered LDS stage: ONE barrier per tile;
+//   * the 32x32 sign matrix of a tile leaves the wave as one LDS store (see `compute`) and is
+//     packed to K-bit codes into an LDS code block that is stored at the end as long runs of
+//     every [L][n] row;
+//   * guard-band candidates are NOT resolved inline (any stall would hold all waves at the
+//     barrier): they are queued in LDS and resolved together at the end, one 16-lane group per
+//     candidate (exact f64 dot product of the row and the plane, both re-read from L2), patching
+//     the code block before it is stored.
+// What bounds it is VALU issue, not the matrix pipe: ~200 vector instructions per wave and tile
+// against 8 MFMAs, which is why the epilogue is written the way it is.
+constexpr int SK_CH_MAX = 32;             // 32-row tiles per workgroup: chosen per launch (keys_chunk_tiles)
+constexpr int SK_QCAP = 1024;             // deferred exact-sign candidates per workgroup
+
+constexpr int SK_WAVES = 8;               // waves per workgroup: two workgroups fill the 16 wave slots
+                                          // a CU has at 128 VGPRs (5-wave blocks left 6 of them empty)
+constexpr int SK_MAX_TABLES = 32;
+
+template <int D>
+__global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void simhash_keys_kernel(
+    const uint16_t* __restrict__ x,       // [heads][n][D] bf16 (centred keys; blockIdx.z = kv head)
+    const uint16_t* __restrict__ Wt,      // [KLpad][D]
+    const float* __restrict__ wnorm,      // [KLpad]
+    int64_t n, int K, int L, int tables_per_wg, int tiles_per_wg, int chunk_tiles,
+    int16_t* __restrict__ codes,          // [heads][L][n]
+    unsigned long long* __restrict__ stamp) {
+    constexpr int KSTEPS = D / 16;
+    constexpr int STRIDE = D + 8;
+    constexpr int CPR = D / 8;            // 16-byte chunks per row
+    constexpr int NCH = SH_ROWS * CPR;    // chunks per 32-row tile
+    constexpr int NTHR = 64 * SK_WAVES;
+    constexpr int QN = (NCH + NTHR - 1) / NTHR;   // chunks per thread
+    const int CROWS = chunk_tiles * SH_ROWS;
+    __shared__ __attribute__((aligned(16))) uint16_t s_x[2][SH_ROWS * STRIDE];
+    __shared__ float s_rn[2][SH_ROWS];
+    __shared__ uint32_t s_bits[2][SH_ROWS][SH_MAX_TILES + 1];
+    __shared__ uint32_t s_queue[SK_QCAP];
+    __shared__ int s_qn;
+    extern __shared__ uint32_t s_codes32[];               // int16 [tables_per_wg][CROWS], viewed as u32 for patching
+    int16_t* s_codes = reinterpret_cast<int16_t*>(s_codes32);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int nthr = NTHR;
+    const int table0 = blockIdx.x * tables_per_wg;
+    const int col0 = table0 * K, KL = K * L;   // col0 is NOT tile aligned: Wt is row-per-plane, any start works
+    x += (int64_t)blockIdx.z * n * D;                        // kv head
+    codes += (int64_t)blockIdx.z * L * n;
+    const int64_t row_base = (int64_t)blockIdx.y * CROWS;
+    int nt = (int)((n - row_base + SH_ROWS - 1) / SH_ROWS);
+    if (nt > chunk_tiles) nt = chunk_tiles;
+    if (tid == 0) s_qn = 0;
+    MP_STAMP(stamp, 40);
+
+    const bool has_tile = wave < tiles_per_wg;
+    const int ncol = col0 + wave * 32 + (lane & 31);
+    bf16x8 bfrag[KSTEPS];
+    float wn = -1.f;
+    if (has_tile) {
+        const uint16_t* wrow = Wt + (int64_t)ncol * D + (lane >> 5) * 8;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) bfrag[kk] = *reinterpret_cast<const bf16x8*>(wrow + kk * 16);
+        // planes past this workgroup's tables (the tail of its last tile) belong to the next one
+        wn = (ncol < KL && ncol - col0 < tables_per_wg * K) ? wnorm[ncol] * SH_EPS : -1.f;
+    }
+
+    // Loads are unconditional (addresses clamped to the last row / last chunk): a load under a branch
+    // is followed by s_waitcnt vmcnt(0) at the join, which would serialise the prefetch.  Rows past n
+    // and chunks past NCH compute on duplicates whose results are never stored.
+    auto tile_load = [&](int t, u32x4 (&st)[QN]) {
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            int c = tid + q * nthr;
+            c = c < NCH ? c : NCH - 1;
+            int64_t gr = row_base + (int64_t)t * SH_ROWS + c / CPR;
+            gr = gr < n ? gr : n - 1;
+            st[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + gr * D + (c % CPR) * 8));
+        }
+    };
+    auto tile_store = [&](int buf, const u32x4 (&st)[QN]) {
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            const int c = tid + q * nthr;
+            float ss = 0.f;
+            if (c < NCH) {
+                *reinterpret_cast<u32x4*>(&s_x[buf][(c / CPR) * STRIDE + (c % CPR) * 8]) = st[q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = bf16_lo(st[q][j]), hi = bf16_hi(st[q][j]);
+                    ss = fmaf(lo, lo, fmaf(hi, hi, ss));
+                }
+            }
+            // the CPR chunks of a row sit in CPR consecutive lanes (nthr is a multiple of 64)
+            if (CPR == 16) ss = row16_sum(ss);
+            else if (CPR == 32) { ss = row16_sum(ss); ss += __shfl_xor(ss, 16); }
+            else {
+#pragma unroll
+                for (int sft = 1; sft < CPR; sft <<= 1) ss += __shfl_xor(ss, sft);
+            }
+            if (c < NCH && (c % CPR) == 0)     // upper bound of ||row|| (v_sqrt_f32 is good to 1 ulp)
+                s_rn[buf][c / CPR] = __builtin_amdgcn_sqrtf(ss) * 1.0001f;
+        }
+    };
+    // The epilogue of a tile is what the kernel is bound by (VALU issue, not the matrix pipe), so
+    // it is kept to ~70 instructions per wave: 16 compares give the 32x32 sign matrix in SGPR pairs,
+    // v_writelane moves dword r of it into lane r for ONE LDS store, and the guard band is tested on
+    // min_i |acc_i| against the largest row norm of the tile; only lanes that fail that coarse test
+    // look at their 16 values one by one.
+    auto compute = [&](int t) {                           // MFMA + signs of tile t (LDS half t&1)
+        if (!has_tile) return;
+        const int buf = t & 1;
+        const uint16_t* arow = &s_x[buf][(lane & 31) * STRIDE + (lane >> 5) * 8];
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + kk * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[kk], acc, 0, 0, 0);
+        }
+        // largest row norm of the tile: lanes 0..15 hold rows 0..15, lanes 16..31 rows 16..31
+        const float rn16 = row16_max_nonneg(s_rn[buf][lane & 31]);
+        const float rnmax = __int_as_float(max(__builtin_amdgcn_readlane(__float_as_int(rn16), 0),
+                                               __builtin_amdgcn_readlane(__float_as_int(rn16), 16)));
+        // sign matrix: ballot i holds rows r_i (lanes 0..31) and r_i + 4 (lanes 32..63) of the tile.
+        // v_writelane is issued from inline asm, so the wait states between the compare that writes
+        // an SGPR and the v_writelane that reads it are placed by hand (s_nop 3 per group of 8).
+        uint32_t rowbits = 0u;
+        float amin = 3.0e38f;
+        unsigned long long bm[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            bm[i] = __ballot(acc[i] > 0.f);
+            amin = fminf(amin, fabsf(acc[i]));
+        }
+#define MP_WL4(I)                                                                                  \
+        asm volatile("s_nop 3\n\t"                                                                 \
+                     "v_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %10\n\t"               \
+                     "v_writelane_b32 %0, %3, %11\n\tv_writelane_b32 %0, %4, %12\n\t"              \
+                     "v_writelane_b32 %0, %5, %13\n\tv_writelane_b32 %0, %6, %14\n\t"              \
+                     "v_writelane_b32 %0, %7, %15\n\tv_writelane_b32 %0, %8, %16"                   \
+                     : "+v"(rowbits)                                                               \
+                     : "s"((uint32_t)bm[I]), "s"((uint32_t)(bm[I] >> 32)), "s"((uint32_t)bm[I + 1]), \
+                       "s"((uint32_t)(bm[I + 1] >> 32)), "s"((uint32_t)bm[I + 2]),                 \
+                       "s"((uint32_t)(bm[I + 2] >> 32)), "s"((uint32_t)bm[I + 3]),                 \
+                       "s"((uint32_t)(bm[I + 3] >> 32)),                                           \
+                       "n"(2 * (I)), "n"(2 * (I) + 4), "n"(2 * (I) + 1), "n"(2 * (I) + 5),         \
+                       "n"(2 * (I) + 2), "n"(2 * (I) + 6), "n"(2 * (I) + 3), "n"(2 * (I) + 7));
+        MP_WL4(0) MP_WL4(4) MP_WL4(8) MP_WL4(12)
+#undef MP_WL4
+        if (lane < 32) s_bits[buf][lane][wave] = rowbits;
+        if (amin <= wn * rnmax) {                         // wn < 0 for padding planes: never taken
+            const int64_t r0 = row_base + (int64_t)t * SH_ROWS;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                // guard-band candidate: queue (chunk row, plane offset) for the exact pass at the end
+                if ((r0 + row < n) && fabsf(acc[i]) <= wn * s_rn[buf][row]) {
+                    const int slot = atomicAdd(&s_qn, 1);
+                    if (slot < SK_QCAP) s_queue[slot] = ((uint32_t)(t * SH_ROWS + row) << 16) | (uint32_t)(ncol - col0);
+                }
+            }
+        }
+    };
+    const uint32_t kmask = (1u << K) - 1u;
+    auto pack = [&](int t) {                              // bits of tile t -> LDS code block
+        const int buf = t & 1;
+        for (int p = tid; p < SH_ROWS * tables_per_wg; p += nthr) {
+            const int tb = p / SH_ROWS, row = p % SH_ROWS;
+            const int bp = tb * K, w = bp >> 5, sh = bp & 31;
+            const unsigned long long two = (unsigned long long)s_bits[buf][row][w] |
+                                           ((unsigned long long)s_bits[buf][row][w + 1] << 32);
+            s_codes[tb * CROWS + t * SH_ROWS + row] = (int16_t)((uint32_t)(two >> sh) & kmask);
+        }
+    };
+
+    // __syncthreads() also drains every outstanding global load (s_waitcnt vmcnt(0)), which would
+    // serialise the prefetched tiles behind each barrier; inside the loop only LDS traffic has to be
+    // complete before the barrier (HIP guide, "Pipelining across barriers").
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // prologue: tile 0 staged, tile 1 in registers.  Two register sets: the rows of tile t+2 are
+    // requested while tile t is on the matrix pipe and written to LDS one phase later; with three
+    // workgroups resident per CU that is enough to cover the HBM latency, with ONE barrier per tile.
+    u32x4 s0[QN], s1[QN];
+    tile_load(0, s0);
+    tile_load(1, s1);
+    tile_store(0, s0);
+    __syncthreads();
+    MP_STAMP(stamp, 41);
+#define MP_SK_PHASE(T, LOADSET, STORESET)                                  \
+    if ((T) < nt) {                                                        \
+        tile_load((T) + 2, LOADSET);                                       \
+        compute(T);                                                        \
+        tile_store(((T) + 1) & 1, STORESET);                               \
+        lds_barrier();                                                     \
+        pack(T);                                                           \
+    }
+    for (int t = 0; t < nt; t += 2) {
+        MP_SK_PHASE(t, s0, s1)
+        MP_SK_PHASE(t + 1, s1, s0)
+        if (t == 2) MP_STAMP(stamp, 45);
+    }
+#undef MP_SK_PHASE
+    __syncthreads();
+    MP_STAMP(stamp, 42);
+
+    // exact pass over the queued candidates: one 16-lane group per candidate
+    const int nq = min(s_qn, SK_QCAP);
+    const bool overflow = s_qn > SK_QCAP;
+    for (int e = tid >> 4; e < nq; e += nthr >> 4) {
+        const uint32_t ent = s_queue[e];
+        const int crow = ent >> 16, coff = ent & 0xffffu;
+        const int l16 = tid & 15;
+        double part = 0.0;
+        for (int d8 = l16; d8 < CPR; d8 += 16) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(x + (row_base + crow) * D + d8 * 8);
+            const u32x4 w = *reinterpret_cast<const u32x4*>(Wt + (int64_t)(col0 + coff) * D + d8 * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                part += (double)bf16_lo(a[j]) * (double)bf16_lo(w[j]) + (double)bf16_hi(a[j]) * (double)bf16_hi(w[j]);
+        }
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 4);
+        part += __shfl_xor(part, 8);
+        if (l16 == 0) {
+            const int tb = coff / K, bit = coff % K;
+            const int idx = tb * CROWS + crow;              // int16 index into the code block
+            const uint32_t m = (1u << bit) << (16 * (idx & 1));
+            if (part > 0.0) atomicOr(&s_codes32[idx >> 1], m); else atomicAnd(&s_codes32[idx >> 1], ~m);
+        }
+    }
+    if (overflow) {   // more candidates than the queue holds (adversarial input): every thread re-checks
+                      // its share of the code block exactly -- slow, correct
+        for (int p = tid; p < tables_per_wg * K * (nt * SH_ROWS); p += nthr) {
+            const int coff = p / (nt * SH_ROWS), crow = p % (nt * SH_ROWS);
+            if (col0 + coff >= KL || row_base + crow >= n) continue;
+            double ex = 0.0;
+            for (int d = 0; d < D; ++d)
+                ex += (double)bf16_bits_to_f32(x[(row_base + crow) * D + d]) *
+                      (double)bf16_bits_to_f32(Wt[(int64_t)(col0 + coff) * D + d]);
+            const int tb = coff / K, bit = coff % K, idx = tb * CROWS + crow;
+            const uint32_t m = (1u << bit) << (16 * (idx & 1));
+            if (ex > 0.0) atomicOr(&s_codes32[idx >> 1], m); else atomicAnd(&s_codes32[idx >> 1], ~m);
+        }
+    }
+    __syncthreads();
+    MP_STAMP(stamp, 43);
+
+    // long contiguous stores: row l of codes[L][n], tokens row_base .. row_base + ntok, as 8-byte
+    // groups of four codes aligned on the DESTINATION address (n is arbitrary, so the alignment of
+    // a row start differs from table to table); ragged ends go out as scalars.
+    const int ntok = (int)((n - row_base < (int64_t)nt * SH_ROWS) ? (n - row_base) : (int64_t)nt * SH_ROWS);
+    const int G = CROWS / 4 + 1;
+    for (int tb = wave; tb < tables_per_wg; tb += SK_WAVES) {
+        const int l = table0 + tb;
+        if (l >= L) break;
+        int16_t* dst = codes + (int64_t)l * n + row_base;
+        const int shift = (int)(((8u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 7u)) & 7u) >> 1);
+        const int16_t* src = s_codes + tb * CROWS;
+        for (int g = lane; g < G; g += WAVE) {
+            const int j0 = shift + 4 * (g - 1);
+            const int lo = j0 < 0 ? 0 : j0, hi = (j0 + 4 < ntok) ? j0 + 4 : ntok;
+            if (hi - lo == 4) {
+                uint2 v;
+                v.x = (uint32_t)(uint16_t)src[lo] | ((uint32_t)(uint16_t)src[lo + 1] << 16);
+                v.y = (uint32_t)(uint16_t)src[lo + 2] | ((uint32_t)(uint16_t)src[lo + 3] << 16);
+                *reinterpret_cast<uint2*>(dst + lo) = v;
+            } else {
+                for (int j = lo; j < hi; ++j) dst[j] = src[j];
+            }
+        }
+    }
+    MP_STAMP(stamp, 44);
 }
 
 // ---------------------------------------------------------------- host launchers
@@ -244,11 +517,17 @@ static void simhash_geometry(int K, int& tables_per_wg, int& tiles_per_wg) {
     tiles_per_wg = tiles;
 }
 
+static void simhash_keys_geometry(int K, int& tables_per_wg, int& tiles_per_wg);
+
+// rows of Wt / entries of wnorm: every plane any workgroup of either kernel can touch
 int simhash_padded_cols(int K, int L) {
     int tp, tiles;
     simhash_geometry(K, tp, tiles);
     const int wgs = (L + tp - 1) / tp;
-    return wgs * tiles * 32;
+    int cols = wgs * tiles * 32;
+    simhash_keys_geometry(K, tp, tiles);
+    const int kcols = ((L + tp - 1) / tp - 1) * tp * K + tiles * 32;
+    return cols > kcols ? cols : kcols;
 }
 
 int simhash_supported(int D, int K) {
@@ -267,19 +546,17 @@ hipError_t launch_simhash_prepare(const uint16_t* W, int D, int K, int L, uint16
 
 unsigned long long* g_stamp = nullptr;   // debug phase-timestamp sink (mp_debug_set_stamp_buffer)
 
-template <int MODE>
-static hipError_t launch_simhash_t(const uint16_t* x, const uint16_t* Wt, const float* wnorm,
-                                   int64_t R, int D, int K, int L, int64_t ld_out, void* codes,
-                                   float* qnorm, float* dbg, unsigned grid_y, hipStream_t st) {
+hipError_t launch_simhash_query(const uint16_t* q, const uint16_t* Wt, const float* wnorm, int R,
+                                int D, int K, int L, int32_t* codes, float* qnorm, float* dbg,
+                                hipStream_t st) {
     int tp, tiles;
     simhash_geometry(K, tp, tiles);
-    dim3 grid((L + tp - 1) / tp, grid_y);
+    dim3 grid((L + tp - 1) / tp, (unsigned)((R + SH_ROWS - 1) / SH_ROWS));
     dim3 block(64 * (tiles > 4 ? tiles : 4));
-    unsigned long long* stamp = (MODE == 0) ? g_stamp : nullptr;
 #define MP_SH_CASE(DD)                                                                          \
     if (D == DD) {                                                                              \
-        hipLaunchKernelGGL((simhash_kernel<MODE, DD, (MODE == 1 ? 2 : 1)>), grid, block, 0, st, x, Wt, wnorm, R, K, L, \
-                           tp, tiles, ld_out, codes, qnorm, dbg, stamp);                        \
+        hipLaunchKernelGGL((simhash_query_kernel<DD>), grid, block, 0, st, q, Wt, wnorm,        \
+                           (int64_t)R, K, L, tp, tiles, codes, qnorm, dbg, g_stamp);            \
         return hipGetLastError();                                                               \
     }
     MP_SH_CASE(128)
@@ -289,27 +566,72 @@ static hipError_t launch_simhash_t(const uint16_t* x, const uint16_t* Wt, const 
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_simhash_query(const uint16_t* q, const uint16_t* Wt, const float* wnorm, int R,
-                                int D, int K, int L, int32_t* codes, float* qnorm, float* dbg,
-                                hipStream_t st) {
-    return launch_simhash_t<0>(q, Wt, wnorm, R, D, K, L, L, (void*)codes, qnorm, dbg,
-                               (unsigned)((R + SH_ROWS - 1) / SH_ROWS), st);
+// key-side geometry: a workgroup hashes floor(256 / K) tables (at most SK_MAX_TABLES) with one
+// wave per 32 planes; its plane span starts at table0 * K whatever the alignment.
+static void simhash_keys_geometry(int K, int& tables_per_wg, int& tiles_per_wg) {
+    int tp = (32 * SK_WAVES) / K;
+    if (tp > SK_MAX_TABLES) tp = SK_MAX_TABLES;
+    tables_per_wg = tp;
+    tiles_per_wg = (tp * K + 31) / 32;
 }
 
-// one kv head: keys [n][D] -> codes int16 [L][n]
-hipError_t launch_simhash_keys(const uint16_t* keys, const uint16_t* Wt, const float* wnorm,
-                               int64_t n, int D, int K, int L, int16_t* codes, hipStream_t st) {
-    const int64_t row_tiles = (n + SH_ROWS - 1) / SH_ROWS;
-    const int64_t max_y = 65535;   // gridDim.y limit: chunk the token axis
-    for (int64_t t0 = 0; t0 < row_tiles; t0 += max_y) {
-        const int64_t ny = (row_tiles - t0 < max_y) ? (row_tiles - t0) : max_y;
-        const int64_t off = t0 * SH_ROWS;
-        // codes are [L][n]: row stride n (ld_out), pointers offset by `off` tokens
-        hipError_t e = launch_simhash_t<1>(keys + off * D, Wt, wnorm, n - off, D, K, L, n,
-                                           (void*)(codes + off), nullptr, nullptr, (unsigned)ny, st);
-        if (e != hipSuccess) return e;
+// Tiles per workgroup.  Workgroups are not persistent, so the launch runs in ceil(wgs / slots)
+// rounds of (per-tile time * tiles + fixed prologue/flush time): pick the chunk that minimises
+// that product (the constants are the measured 1.9 us per tile and 7 us per workgroup; only their
+// ratio matters).  The code block [tables][32 * tiles] int16 has to fit in LDS next to a second
+// workgroup.
+static int keys_chunk_tiles(int64_t n, int64_t wgs_x, int tables_per_wg) {
+    int cus = 256;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        cus = prop.multiProcessorCount;
+    const int64_t slots = 2 * (int64_t)cus;
+    const int64_t tiles = (n + SH_ROWS - 1) / SH_ROWS;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int ch = 1; ch <= SK_CH_MAX; ++ch) {
+        if ((size_t)tables_per_wg * ch * SH_ROWS * sizeof(int16_t) > 48u * 1024u) break;
+        if ((tiles + ch - 1) / ch > 65535) continue;
+        const int64_t wgs = ((tiles + ch - 1) / ch) * wgs_x;
+        const double cost = (double)((wgs + slots - 1) / slots) * (1.9 * ch + 7.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = ch; }
     }
-    return hipSuccess;
+    return best;
+}
+
+// keys [heads][n][D] -> codes int16 [heads][L][n]; all kv heads in ONE launch so that the tail
+// round of one head is filled by the next
+hipError_t launch_simhash_keys(const uint16_t* keys, const uint16_t* Wt, const float* wnorm,
+                               int heads, int64_t n, int D, int K, int L, int16_t* codes, hipStream_t st) {
+    int tp, tiles;
+    simhash_keys_geometry(K, tp, tiles);
+    const int wgs_x = (L + tp - 1) / tp;
+    if (heads < 1 || heads > 65535) return hipErrorInvalidValue;
+    static thread_local int64_t memo_n = -1;
+    static thread_local int memo_x = 0, memo_tp = 0, memo_ch = 0;
+    if (memo_n != n || memo_x != wgs_x * heads || memo_tp != tp) {
+        memo_ch = keys_chunk_tiles(n, (int64_t)wgs_x * heads, tp);
+        memo_n = n; memo_x = wgs_x * heads; memo_tp = tp;
+    }
+    const int ch = memo_ch;
+    const int64_t crows = (int64_t)ch * SH_ROWS;
+    const int64_t chunks = (n + crows - 1) / crows;
+    if (chunks > 65535) return hipErrorInvalidValue;
+    dim3 grid(wgs_x, (unsigned)chunks, (unsigned)heads);
+    dim3 block(64 * SK_WAVES);
+    const size_t lds = (size_t)tp * crows * sizeof(int16_t);
+#define MP_SK_CASE(DD)                                                                              \
+    if (D == DD) {                                                                                  \
+        hipLaunchKernelGGL((simhash_keys_kernel<DD>), grid, block, lds, st, keys, Wt, wnorm, n, K,  \
+                           L, tp, tiles, ch, codes, g_stamp);                                       \
+        return hipGetLastError();                                                                   \
+    }
+    MP_SK_CASE(128)
+    MP_SK_CASE(64)
+    MP_SK_CASE(256)
+#undef MP_SK_CASE
+    return hipErrorInvalidValue;
 }
 
 }  // namespace mp
