@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=48)
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
-    ap.add_argument("--table-build", default="sort", choices=["sort", "counting"])
+    ap.add_argument("--table-build", default="counting", choices=["sort", "counting"])
     ap.add_argument("--end-to-end", action="store_true",
                     help="examples/bench.py-style full decode step with synthetic weights (SURVEY 8f-3) "
                          "instead of the hot path alone")

@@ -33,7 +33,7 @@ class LSHSparseAttnServer:
                  max_length: int = 8192,
                  dense_layers=(0, 16, 32, 48, 64), device: str = "cuda:0",
                  dtype=torch.bfloat16, hash_func: torch.Tensor | None = None, seed: int = 7,
-                 table_build: str = "sort"):
+                 table_build: str = "counting"):
         """Mirrors models/attnserver.py:9-57 (the LlamaConfig is replaced by its four numbers).
         hash_func: bf16 [head_dim, K*L]; the reference draws it unseeded (:55), here it is
         seeded or supplied (e.g. broadcast from rank 0, attnserver_dist.py:279)."""

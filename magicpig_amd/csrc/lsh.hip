@@ -65,78 +65,214 @@ __global__ __launch_bounds__(256) void lsh_fill_kernel(
 }
 
 // ---------------------------------------------------------------- device-side table build
-// (replacement of the half-written LSH::fastfill, lsh.cc:93-142): stable counting sort of one
-// (kv head, table) row of UNSORTED codes -> bounds + ascending ids per bucket.
-// One workgroup per row; LDS histogram of NB buckets; the stable scatter walks the row in
-// blocks of blockDim tokens, ranking equal codes inside a block by a match-any ballot.
-__global__ __launch_bounds__(1024) void lsh_build_kernel(
-    const int16_t* __restrict__ codes,   // [Hkv*L][n] unsorted
-    int64_t n, int NB, int64_t M, int2* __restrict__ bounds, int32_t* __restrict__ table,
-    int* __restrict__ err) {
-    extern __shared__ int s_mem[];
-    int* s_cnt = s_mem;            // [NB] histogram, then running cursor
-    int* s_tmp = s_mem + NB;       // scan scratch [blockDim/64 + 2]
-    const int64_t row = blockIdx.x;
-    const int16_t* c = codes + row * n;
-    int2* b = bounds + row * NB;
-    int32_t* dst = table + row * M;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < NB; i += blockDim.x) s_cnt[i] = 0;
+// (replacement of the half-written LSH::fastfill, lsh.cc:93-142, and of the torch.sort +
+// LSH::fill of models/attnserver.py:186-193): stable counting sort of one (kv head, table) row
+// of UNSORTED codes -> bounds + ascending ids per bucket.  One workgroup per row.
+//
+// What it is bound by is the scatter of the ids: written straight to HBM, 4 bytes at a time into
+// NB open bucket frontiers per row, it costs 1.6 ms of a 2.1 ms launch at cfg 1 (more open lines
+// than L2 holds, so every store becomes its own 32-byte sector write).  So the row is sorted in
+// LDS tile by tile (T tokens): every wave owns a contiguous slice of the tile and a private set of
+// NB counters, one block-wide scan turns them into per-wave cursors inside the tile's sorted order,
+// the waves scatter (id, bucket) into an LDS stage without any barrier or cross-wave ordering --
+// inside a wave, 64 consecutive tokens are ranked by a match-any ballot (lane order == token
+// order), which keeps the ids of a bucket ascending -- and the stage is written out by position,
+// so that adjacent lanes write adjacent ids of the same bucket run.
+constexpr int BUILD_LDS_COUNTERS = 32768;   // direct variant: waves = min(16, 32768 / NB)
+
+__device__ __forceinline__ unsigned long long match_any_bits(int v, bool ok, int nbits) {
+    unsigned long long m = __ballot(ok);
+    for (int bit = 0; bit < nbits; ++bit) {
+        const bool one = (v >> bit) & 1;
+        const unsigned long long bm = __ballot(one);
+        m &= one ? bm : ~bm;
+    }
+    return m;
+}
+
+// row histogram with wave-private counters (cnt [nw][NB], zeroed here), then the exclusive scan
+// of the bucket totals: writes bounds, returns each bucket's start through `start_of(i, ex, v)`.
+template <typename F>
+__device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ c, int n, int NB,
+                                                    int* s_cnt, int* s_tmp, int2* __restrict__ b,
+                                                    int* __restrict__ err, F&& start_of) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int i = tid; i < nw * NB; i += blockDim.x) s_cnt[i] = 0;
     __syncthreads();
+    int* mine = s_cnt + wave * NB;
     bool bad = false;
-    for (int64_t k = tid; k < n; k += blockDim.x) {
+#pragma unroll 4
+    for (int k = tid; k < n; k += blockDim.x) {
         const int v = c[k];
         if (v < 0 || v >= NB) bad = true;
-        else atomicAdd(&s_cnt[v], 1);
+        else atomicAdd(&mine[v], 1);
     }
+    (void)lane;
     if (bad) atomicOr(err, 1);
     __syncthreads();
-    // exclusive scan of the histogram -> bucket starts; write bounds
     int carry = 0;
     for (int base = 0; base < NB; base += blockDim.x) {
         const int i = base + tid;
-        const int v = (i < NB) ? s_cnt[i] : 0;
+        int v = 0;
+        if (i < NB)
+            for (int w = 0; w < nw; ++w) v += s_cnt[w * NB + i];
         int total;
         __syncthreads();
         const int ex = block_excl_scan(v, s_tmp, total) + carry;
         if (i < NB) {
             b[i] = (v > 0) ? make_int2(ex, ex + v) : make_int2(0, 0);
-            s_cnt[i] = ex;  // running cursor of bucket i
+            start_of(i, ex, v);
         }
         carry += total;
     }
     __syncthreads();
-    // stable scatter: the row is walked in block-sized tiles; inside a tile the waves take
-    // turns in token order, and equal codes inside a wave are ranked by lane with a match-any
-    // ballot; the wave leader of each code reserves the bucket space with one LDS atomic.
-    const int nw = blockDim.x >> 6, wave = tid >> 6, lane = tid & 63;
-    for (int64_t base = 0; base < n; base += blockDim.x) {
-        for (int w = 0; w < nw; ++w) {
-            if (w == wave) {
-                const int64_t k = base + tid;
-                const bool valid = k < n;
-                const int v = valid ? (int)c[k] : -1;
-                // rank among the lanes of this wave with the same code and a lower lane id
-                unsigned long long peers = 0;
-                {
-                    // match-any by K-bit radix ballots
-                    unsigned long long m = __ballot(valid);
-                    for (int bit = 0; (1 << bit) < NB; ++bit) {
-                        const unsigned long long bm = __ballot((v >> bit) & 1);
-                        m &= ((v >> bit) & 1) ? bm : ~bm;
-                    }
-                    peers = m;
-                }
-                if (valid && v >= 0 && v < NB) {
-                    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
-                    const int leader = __ffsll((long long)peers) - 1;
-                    int start = 0;
-                    if (lane == leader) start = atomicAdd(&s_cnt[v], __popcll(peers));
-                    start = __shfl(start, leader);
-                    dst[start + rank] = (int32_t)k;
-                }
-            }
+}
+
+// LDS: cnt [nw][NB] | gbase [NB] | gdelta [NB] | s_tmp [32] | stage_id [T] | stage_b [T] (u16)
+template <int TPL>   // tokens per lane and tile: T = TPL * blockDim.x
+__global__ __launch_bounds__(1024) void lsh_build_kernel(
+    const int16_t* __restrict__ codes,   // [Hkv*L][n] unsorted
+    int n, int NB, int nbits, int64_t M, int2* __restrict__ bounds, int32_t* __restrict__ table,
+    int* __restrict__ err) {
+    extern __shared__ int s_mem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int T = TPL * blockDim.x;
+    int* s_cnt = s_mem;
+    int* s_gbase = s_cnt + nw * NB;
+    int* s_gdelta = s_gbase + NB;
+    int* s_tmp = s_gdelta + NB;
+    int* s_id = s_tmp + 32;
+    uint16_t* s_b = reinterpret_cast<uint16_t*>(s_id + T);
+    const int64_t row = blockIdx.x;
+    const int16_t* c = codes + row * n;
+    int32_t* dst = table + row * M;
+    build_row_histogram(c, n, NB, s_cnt, s_tmp, bounds + row * NB, err,
+                        [&](int i, int ex, int) { s_gbase[i] = ex; });
+    int* mine = s_cnt + wave * NB;
+    for (int t0 = 0; t0 < n; t0 += T) {
+        // this wave's slice of the tile: tokens w0 + j*64 + lane, j < TPL, kept in registers
+        const int w0 = t0 + wave * (WAVE * TPL);
+        int vq[TPL];
+#pragma unroll
+        for (int j = 0; j < TPL; ++j) {
+            const int kk = w0 + j * WAVE + lane;
+            const int v = (kk < n) ? (int)c[kk] : -1;
+            vq[j] = (v >= 0 && v < NB) ? v : -1;
+        }
+        for (int i = tid; i < nw * NB; i += blockDim.x) s_cnt[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TPL; ++j)
+            if (vq[j] >= 0) atomicAdd(&mine[vq[j]], 1);
+        __syncthreads();
+        // per-wave cursors inside the tile's sorted order; where the tile's run of a bucket goes
+        int carry = 0;
+        for (int base = 0; base < NB; base += blockDim.x) {
+            const int i = base + tid;
+            int v = 0;
+            if (i < NB)
+                for (int w = 0; w < nw; ++w) v += s_cnt[w * NB + i];
+            int total;
             __syncthreads();
+            const int ex = block_excl_scan(v, s_tmp, total) + carry;
+            if (i < NB) {
+                int run = ex;
+                for (int w = 0; w < nw; ++w) {
+                    const int t = s_cnt[w * NB + i];
+                    s_cnt[w * NB + i] = run;
+                    run += t;
+                }
+                const int g = s_gbase[i];
+                s_gdelta[i] = g - ex;
+                s_gbase[i] = g + v;
+            }
+            carry += total;
+        }
+        __syncthreads();
+        const int tile_count = carry;                   // valid tokens of the tile
+#pragma unroll
+        for (int j = 0; j < TPL; ++j) {
+            const int v = vq[j];
+            const bool ok = v >= 0;
+            if (!__ballot(ok)) continue;
+            const unsigned long long peers = match_any_bits(v, ok, nbits);
+            if (ok) {
+                const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+                const int leader = __ffsll((long long)peers) - 1;
+                int start = 0;
+                if (lane == leader) start = atomicAdd(&mine[v], __popcll(peers));
+                start = __shfl(start, leader);
+                s_id[start + rank] = w0 + j * WAVE + lane;
+                s_b[start + rank] = (uint16_t)v;
+            }
+        }
+        __syncthreads();
+        for (int p = tid; p < tile_count; p += blockDim.x) dst[p + s_gdelta[s_b[p]]] = s_id[p];
+        // the next tile's zeroing of s_cnt is ordered after this loop's LDS reads by its barrier;
+        // s_id / s_b are rewritten only after two more barriers
+    }
+}
+
+// Direct variant for NB too large for the staged layout (K >= 14): the row is cut into one
+// contiguous segment per wave and the waves scatter straight to HBM from private cursors.
+__global__ __launch_bounds__(1024) void lsh_build_direct_kernel(
+    const int16_t* __restrict__ codes, int n, int NB, int nbits, int64_t M,
+    int2* __restrict__ bounds, int32_t* __restrict__ table, int* __restrict__ err) {
+    extern __shared__ int s_mem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    int* s_cnt = s_mem;                  // [nw][NB] per-wave histogram, then per-wave cursors
+    int* s_tmp = s_mem + nw * NB;
+    const int64_t row = blockIdx.x;
+    const int16_t* c = codes + row * n;
+    int2* b = bounds + row * NB;
+    int32_t* dst = table + row * M;
+    for (int i = tid; i < nw * NB; i += blockDim.x) s_cnt[i] = 0;
+    __syncthreads();
+    const int seg = (((n + nw - 1) / nw) + 63) & ~63;     // tokens per wave
+    const int k0 = wave * seg, k1 = (k0 + seg < n) ? k0 + seg : n;
+    int* mine = s_cnt + wave * NB;
+    bool bad = false;
+#pragma unroll 4
+    for (int k = k0 + lane; k < k1; k += WAVE) {
+        const int v = c[k];
+        if (v < 0 || v >= NB) bad = true;
+        else atomicAdd(&mine[v], 1);
+    }
+    if (bad) atomicOr(err, 1);
+    __syncthreads();
+    int carry = 0;
+    for (int base = 0; base < NB; base += blockDim.x) {
+        const int i = base + tid;
+        int v = 0;
+        if (i < NB)
+            for (int w = 0; w < nw; ++w) v += s_cnt[w * NB + i];
+        int total;
+        __syncthreads();
+        const int ex = block_excl_scan(v, s_tmp, total) + carry;
+        if (i < NB) {
+            b[i] = (v > 0) ? make_int2(ex, ex + v) : make_int2(0, 0);
+            int run = ex;
+            for (int w = 0; w < nw; ++w) {
+                const int t = s_cnt[w * NB + i];
+                s_cnt[w * NB + i] = run;
+                run += t;
+            }
+        }
+        carry += total;
+    }
+    __syncthreads();
+    for (int k = k0; k < k1; k += WAVE) {
+        const int kk = k + lane;
+        const int v = (kk < k1) ? (int)c[kk] : -1;
+        const bool ok = v >= 0 && v < NB;
+        const unsigned long long peers = match_any_bits(v, ok, nbits);
+        if (ok) {
+            const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+            const int leader = __ffsll((long long)peers) - 1;
+            int start = 0;
+            if (lane == leader) start = atomicAdd(&mine[v], __popcll(peers));
+            start = __shfl(start, leader);
+            dst[start + rank] = kk;
         }
     }
 }
@@ -421,11 +557,51 @@ hipError_t launch_lsh_fill(const int16_t* codes, const int32_t* ids, int rows, i
     return hipGetLastError();
 }
 
+// staged layout per NB (LDS <= 160 KB): waves per row, tokens per lane and tile
+static bool build_staged_geometry(int NB, int& nw, int& tpl, size_t& lds) {
+    if (NB <= 1024)      { nw = 16; tpl = 8; }
+    else if (NB <= 2048) { nw = 8;  tpl = 16; }
+    else if (NB <= 4096) { nw = 4;  tpl = 32; }
+    else if (NB <= 8192) { nw = 2;  tpl = 32; }
+    else return false;
+    const size_t T = (size_t)tpl * 64 * nw;
+    lds = ((size_t)nw * NB + 2 * (size_t)NB + 32 + T) * 4 + T * 2;
+    return lds <= 160u * 1024u;
+}
+
 hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, int64_t M,
                             int2* bounds, int32_t* table, int* err, hipStream_t st) {
-    const size_t lds = (size_t)(NB + 64) * 4;
-    hipLaunchKernelGGL(lsh_build_kernel, dim3(rows), dim3(1024), lds, st, codes, n, NB, M, bounds,
-                       table, err);
+    static bool attr_done = false;
+    if (!attr_done) {
+        const void* fns[] = {reinterpret_cast<const void*>(lsh_build_kernel<8>),
+                             reinterpret_cast<const void*>(lsh_build_kernel<16>),
+                             reinterpret_cast<const void*>(lsh_build_kernel<32>),
+                             reinterpret_cast<const void*>(lsh_build_direct_kernel)};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        attr_done = true;
+    }
+    if (n > INT32_MAX || NB > BUILD_LDS_COUNTERS) return hipErrorInvalidValue;
+    int nbits = 0;
+    while ((1 << nbits) < NB) ++nbits;
+    int nw, tpl;
+    size_t lds;
+    if (build_staged_geometry(NB, nw, tpl, lds)) {
+#define MP_BUILD_CASE(TPL)                                                                         \
+        if (tpl == TPL)                                                                            \
+            hipLaunchKernelGGL(lsh_build_kernel<TPL>, dim3(rows), dim3(64 * nw), lds, st, codes,   \
+                               (int)n, NB, nbits, M, bounds, table, err);
+        MP_BUILD_CASE(8) MP_BUILD_CASE(16) MP_BUILD_CASE(32)
+#undef MP_BUILD_CASE
+        return hipGetLastError();
+    }
+    nw = BUILD_LDS_COUNTERS / NB;
+    if (nw > 16) nw = 16;
+    lds = ((size_t)nw * NB + 64) * 4;
+    hipLaunchKernelGGL(lsh_build_direct_kernel, dim3(rows), dim3(64 * nw), lds, st, codes, (int)n, NB,
+                       nbits, M, bounds, table, err);
     return hipGetLastError();
 }
 

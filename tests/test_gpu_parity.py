@@ -725,6 +725,41 @@ def test_decode_full_window_plus_sparse_merge(mp):
         server.window_server.check()
 
 
+# ------------------------------------------------------------------ device table build
+
+@pytest.mark.parametrize("K,n", [(4, 20011), (10, 20011), (10, 8192), (10, 63), (11, 20011),
+                                 (12, 40000), (13, 9000), (15, 5000)])
+def test_table_build_is_a_stable_sort(mp, K, n):
+    """LSH.fastfill == stable sort + LSH.fill, bit for bit (bounds and ids), for every staged
+    geometry (NB <= 1024 / 2048 / 4096 / 8192) and the direct variant (K >= 14); n spans several
+    LDS tiles and is not a multiple of anything."""
+    Hkv, L, H, B, M = 2, 5, 4, 1, n + 3
+    NB = 1 << K
+    codes_np = synth.randint(700 + K, 0, NB, (Hkv, L, n)).astype(np.int16)
+    codes_np[0, 0, :] = codes_np[0, 0, 0]          # one row with a single bucket
+    codes_np[1, 1, :] = np.arange(n) % min(NB, 7)  # a few heavy buckets
+    codes = torch.from_numpy(codes_np).cuda()
+    a, b = mp.LSH(), mp.LSH()
+    for x in (a, b):
+        x.alloc(K, L, 1, H, Hkv, B, M)
+    a.fastfill(0, 0, codes)
+    sv, si = codes.sort(dim=-1, stable=True)
+    b.fill(0, 0, sv.contiguous(), si.int().contiguous())
+    (ba, ta), (bb, tb) = a.get_tables(0), b.get_tables(0)
+    assert torch.equal(ba, bb)
+    assert torch.equal(ta[..., :n], tb[..., :n])
+
+
+def test_table_build_rejects_codes_out_of_range(mp):
+    K, Hkv, L, n = 6, 1, 3, 500
+    codes = torch.from_numpy(synth.randint(5, 0, 1 << K, (Hkv, L, n)).astype(np.int16)).cuda()
+    codes[0, 1, 17] = 1 << K
+    lsh = mp.LSH()
+    lsh.alloc(K, L, 1, 2, Hkv, 1, n)
+    with pytest.raises(Exception):
+        lsh.fastfill(0, 0, codes)
+
+
 # ------------------------------------------------------------------ BASELINE cfg-1 shape
 
 def test_cfg1_shaped_retrieve_sha(mp):
