@@ -295,7 +295,7 @@ struct HashArgs {
     int D, K, KLpad;
 };
 
-template <bool HASH>
+template <bool HASH, int CH>   // CH = min(16, D / 8): plane chunks kept in registers (HASH only)
 __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
     const int2* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
@@ -310,8 +310,9 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
     int* s_tmp = reinterpret_cast<int*>(s_tail + RT_TAIL_CAP);
     int* s_ntail = s_tmp + 32;
     // HASH only: s_q (normalised query, bf16 pairs) | s_rn | s_bits (sign bits of the K*L planes)
-    uint32_t* s_q = reinterpret_cast<uint32_t*>(                    // rounded up to 16 bytes (ds_read_b128)
-        (reinterpret_cast<uintptr_t>(s_ntail + 4) + 15) & ~static_cast<uintptr_t>(15));
+    // (placed by INDEX, rounded up to 16 bytes for ds_read_b128: a uintptr_t round trip would lose the
+    // LDS address space and turn every read of the query into a flat_load that waits on vmcnt too)
+    uint32_t* s_q = s_u32 + ((2 * words + 2 * Lpad + RT_TAIL_CAP + 32 + 4 + 3) & ~3);
     float* s_rn = reinterpret_cast<float*>(s_q + 128);
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_rn + 4);
 
@@ -327,12 +328,15 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
         const int D = ha.D, KL = ha.K * L;
         const int chunks = D >> 3;                              // 16-byte plane chunks per hyperplane
         const u32x4* Wk4 = reinterpret_cast<const u32x4*>(ha.Wk);
-        // -- the first pass's hyperplane chunks do not depend on q: put them in flight first
-        u32x4 w[16];
-        if (tid < KL) {
+        // -- the first pass's hyperplane chunks do not depend on q: put them in flight first.  All
+        //    plane loads of this prologue are UNCONDITIONAL on clamped indices (columns >= KL of Wk are
+        //    zero): with loads under divergent branches the compiler cannot count what is outstanding
+        //    and waits vmcnt(0) before every use, which serialised the second pass's prefetch.
+        u32x4 w[CH];
+        {
+            const int cc = tid < ha.KLpad ? tid : ha.KLpad - 1;
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (i < chunks) w[i] = Wk4[tid + (int64_t)i * ha.KLpad];
+            for (int i = 0; i < CH; ++i) w[i] = Wk4[cc + (int64_t)i * ha.KLpad];
         }
         // -- normalise the query row: wave 0, D/64 elements per lane (D = 64, 128 or 256)
         if (wave == 0) {
@@ -362,15 +366,21 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
         const u32x4* q4 = reinterpret_cast<const u32x4*>(s_q);
         for (int c0 = 0; c0 < KL; c0 += RT_THREADS) {
             const int c = c0 + tid, cn = c + RT_THREADS;
+            const int cnc = cn < ha.KLpad ? cn : ha.KLpad - 1;
             bool bit = false;
             float acc = 0.f;
+            if (c0 + RT_THREADS < KL) {                              // uniform: another pass follows
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (i < chunks && c < KL) dot8_bf16_chain(acc, q4[i], w[i]);   // q4[i]: LDS broadcast
-                if (i < chunks && cn < KL) w[i] = Wk4[cn + (int64_t)i * ha.KLpad];
+                for (int i = 0; i < CH; ++i) {
+                    dot8_bf16_chain(acc, q4[i], w[i]);              // q4[i]: LDS broadcast
+                    w[i] = Wk4[cnc + (int64_t)i * ha.KLpad];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) dot8_bf16_chain(acc, q4[i], w[i]);
             }
             if (c < KL) {
-                for (int kc = 16; kc < chunks; ++kc)                // head_dim 256: remaining chunks
+                for (int kc = CH; kc < chunks; ++kc)                // head_dim 256: remaining chunks
                     dot8_bf16_chain(acc, q4[kc], Wk4[c + (int64_t)kc * ha.KLpad]);
                 dot_settle(acc);
                 bit = acc > 0.f;
@@ -608,10 +618,13 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
 static hipError_t retrieve_attr_once() {
     static bool attr_done = false;
     if (attr_done) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_retrieve_kernel<false>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_retrieve_kernel<false, 16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_retrieve_kernel<true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 8>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) attr_done = true;
     return e;
@@ -625,7 +638,7 @@ hipError_t launch_lsh_retrieve(const int2* bounds, const int32_t* table, const i
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
     HashArgs ha = {};
-    hipLaunchKernelGGL(lsh_retrieve_kernel<false>, dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+    hipLaunchKernelGGL((lsh_retrieve_kernel<false, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                        st, bounds, table, query, results, nnz, G, L, NB, M, words, Lpad, ha, g_stamp);
     return hipGetLastError();
 }
@@ -641,9 +654,14 @@ hipError_t launch_lsh_hash_retrieve(const int2* bounds, const int32_t* table, co
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
-    hipLaunchKernelGGL(lsh_retrieve_kernel<true>, dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
-                       st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, words,
-                       Lpad, ha, g_stamp);
+    if (D >= 128)
+        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+                           st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, words,
+                           Lpad, ha, g_stamp);
+    else
+        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 8>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+                           st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, words,
+                           Lpad, ha, g_stamp);
     return hipGetLastError();
 }
 
