@@ -328,7 +328,21 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
         const int D = ha.D, KL = ha.K * L;
         const int chunks = D >> 3;                              // 16-byte plane chunks per hyperplane
         const u32x4* Wk4 = reinterpret_cast<const u32x4*>(ha.Wk);
-        // -- the first pass's hyperplane chunks do not depend on q: put them in flight first.  All
+        // -- the query row first (its round trip heads the dependent chain: q -> norm -> LDS -> dots):
+        //    wave 0, D/64 elements per lane (D = 64, 128 or 256)
+        const int per = D >> 6;
+        uint32_t e01 = 0u, e23 = 0u;                             // elements 0,1 | 2,3 of this lane (bf16 pairs)
+        if (wave == 0) {                                         // ONE load per lane, no loop: nothing to wait for here
+            const uint16_t* src = ha.q + h * D + lane * per;
+            if (per == 2) e01 = *reinterpret_cast<const uint32_t*>(src);
+            else if (per == 1) e01 = *src;
+            else {
+                const uint2 t = *reinterpret_cast<const uint2*>(src);
+                e01 = t.x;
+                e23 = t.y;
+            }
+        }
+        // -- the first pass's hyperplane chunks do not depend on q: put them in flight next.  All
         //    plane loads of this prologue are UNCONDITIONAL on clamped indices (columns >= KL of Wk are
         //    zero): with loads under divergent branches the compiler cannot count what is outstanding
         //    and waits vmcnt(0) before every use, which serialised the second pass's prefetch.
@@ -338,14 +352,13 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
 #pragma unroll
             for (int i = 0; i < CH; ++i) w[i] = Wk4[cc + (int64_t)i * ha.KLpad];
         }
-        // -- normalise the query row: wave 0, D/64 elements per lane (D = 64, 128 or 256)
+        // -- normalise the query row
         if (wave == 0) {
-            const int per = D >> 6;
-            const uint16_t* src = ha.q + h * D + lane * per;
-            uint16_t e[4];
+            const uint16_t e[4] = {(uint16_t)(e01 & 0xffffu), (uint16_t)(e01 >> 16),
+                                   (uint16_t)(e23 & 0xffffu), (uint16_t)(e23 >> 16)};
             double ss = 0.0;
-            for (int i = 0; i < per; ++i) {
-                e[i] = src[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                      // elements past `per` are zero
                 const double v = (double)bf16_bits_to_f32(e[i]);
                 ss += v * v;                                   // exact, order-free
             }
@@ -354,7 +367,9 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
             const float nb = bf16_bits_to_f32(f32_to_bf16_rne(nrm));
             if (lane == 0 && ha.qnorm_out != nullptr) ha.qnorm_out[h] = nrm;
             uint16_t* dst = reinterpret_cast<uint16_t*>(s_q) + lane * per;
-            for (int i = 0; i < per; ++i) dst[i] = f32_to_bf16_rne(__fdiv_rn(bf16_bits_to_f32(e[i]), nb));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < per) dst[i] = f32_to_bf16_rne(__fdiv_rn(bf16_bits_to_f32(e[i]), nb));
             // ||nq|| <= ||q||/nb * (1 + 2^-8): every element is rounded to bf16 once (guard bound)
             if (lane == 0) *s_rn = (nrm / nb) * 1.005f;
         }
