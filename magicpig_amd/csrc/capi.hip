@@ -20,6 +20,11 @@ hipError_t launch_simhash_query(const uint16_t*, const uint16_t*, const float*, 
 hipError_t launch_simhash_keys(const uint16_t*, const uint16_t*, const float*, int, int64_t, int,
                                int, int, int16_t*, hipStream_t);
 size_t retrieve_lds_bytes(int64_t M, int L);
+bool lsh_decode_supported(int64_t M, int L, int D);
+hipError_t launch_lsh_decode(const int2*, const int32_t*, const uint16_t*, const uint16_t*, const float*, int,
+                             int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
+                             float*, float2*, int*, uint16_t*, float*, float2*, float*, int, int, int, int,
+                             int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int2*,
                            int32_t*, int*, hipStream_t);
 hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int2*, int32_t*, int*,
@@ -35,7 +40,7 @@ int attn_slices_per_head(int64_t M);
 int attn_supported_head_dim(int D);
 hipError_t launch_attn_sparse(int, bool, bool, const uint16_t*, const float*, const void*, const float*,
                               const int32_t*, const int32_t*, float*, float2*, int*, uint16_t*, float*,
-                              float2*, float*, int, int, int64_t, int, int, int, hipStream_t);
+                              float2*, float*, int, int, int64_t, int, int, int, bool, hipStream_t);
 hipError_t launch_attn_normalize(float*, const int32_t*, const float2*, int, int64_t, hipStream_t);
 hipError_t launch_attn_fill(const uint16_t*, const uint16_t*, const float*, int, int64_t, int,
                             int64_t, uint16_t*, float*, hipStream_t);
@@ -132,6 +137,8 @@ struct mp_attn {
                                    // caller's own device buffer (valid until it changes)
     int score_state = 0;           // 0 none, 1 logits, 2 probabilities
     int grid = 8;                  // workgroups per head of the partial kernel (grid.x)
+    bool head_kernel = false;      // one workgroup per head (attn_head_kernel) instead of split-KV
+    int cus = 256;
 };
 
 extern "C" {
@@ -503,6 +510,10 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             cus = prop.multiProcessorCount;
+        h->cus = cus;
+        // with a head (or more) per CU the split-KV machinery only costs: one workgroup per head
+        h->head_kernel = (BH * 2 >= cus) && (h->D == 64 || h->D == 128);
+        if (const char* e = getenv("MP_ATTN_HEAD")) h->head_kernel = atoi(e) != 0;   // A/B override
         h->grid = (int)((size_t)cus * 4 / BH);
         if (h->grid < 1) h->grid = 1;
         const int cap = (int)((h->M + 255) / 256);          // never more waves than 64-entry slices
@@ -571,7 +582,7 @@ static int attn_run(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint16
     MP_HIP_CHECK(launch_attn_sparse(h->D, dense, query_dtype == MP_DTYPE_BF16, h->kv[layer_id],
                                     h->kn[layer_id], query, qn, ind, nnz, h->part_o, h->part_ml,
                                     h->head_cnt, output, mve, h->head_mz, h->score, BH, h->G, h->M, K, L,
-                                    h->grid, st));
+                                    h->grid, h->head_kernel, st));
     h->lastz = nnz;
     h->score_state = 1;
     return MP_OK;
@@ -704,18 +715,35 @@ int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int 
                "mp_decode_sparse_layer: layer_id out of range");
     hipStream_t st = (hipStream_t)stream;
     const int BH = lsh->B * lsh->H;
-    // a-1 + a-2: models/attnserver.py:264-270 and :299 in ONE launch (the q-hash is the prologue of
-    // the retrieve workgroup of its head; codes and ||q|| are written as by-products)
-    MP_HIP_CHECK(launch_lsh_hash_retrieve(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk,
-                                          s->wnorm, s->D, s->K, s->KLpad, lsh->codes, lsh->qnorm,
-                                          lsh->results, lsh->nnz, BH, lsh->G, lsh->L, lsh->NB, lsh->M,
-                                          st));
-    // a-7..a-12: models/attnserver.py:300
     lsh->lastq = lsh->codes;
     lsh->last_layer = layer_id;
-    int rc = attn_run(attn, layer_id, false, s->K, s->L, output, max_value_expsum, q, MP_DTYPE_BF16,
-                      lsh->qnorm, lsh->results, lsh->nnz, st);
-    if (rc) return rc;
+    static const bool two_launch = getenv("MP_DECODE_TWO_LAUNCH") != nullptr;   // A/B switch
+    if (!two_launch && lsh_decode_supported(lsh->M, lsh->L, s->D)) {
+        // a-1 .. a-12 (models/attnserver.py:264-300) in ONE launch: hash -> retrieve -> attention of a
+        // head inside one workgroup cluster; the selected ids stay in LDS.  Cluster size: spread a
+        // head over several CUs while there are idle ones.
+        int cluster = attn->cus / BH;
+        if (cluster > 8) cluster = 8;
+        if (cluster > attn_slices_per_head(attn->M)) cluster = attn_slices_per_head(attn->M);
+        if (cluster < 1) cluster = 1;
+        if (const char* e = getenv("MP_DECODE_CLUSTER")) cluster = atoi(e) >= 1 ? atoi(e) : cluster;
+        MP_HIP_CHECK(launch_lsh_decode(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk, s->wnorm, s->D,
+                                       s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
+                                       attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
+                                       attn->head_cnt, output, max_value_expsum, attn->head_mz, attn->score,
+                                       attn_slices_per_head(attn->M), cluster, BH, lsh->G, lsh->L, lsh->NB, lsh->M, st));
+        attn->lastz = lsh->nnz;
+        attn->score_state = 1;
+    } else {
+        // two launches: (hash + retrieve), then attention (models/attnserver.py:264-299, :300)
+        MP_HIP_CHECK(launch_lsh_hash_retrieve(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk,
+                                              s->wnorm, s->D, s->K, s->KLpad, lsh->codes, lsh->qnorm,
+                                              lsh->results, lsh->nnz, BH, lsh->G, lsh->L, lsh->NB, lsh->M,
+                                              st));
+        int rc = attn_run(attn, layer_id, false, s->K, s->L, output, max_value_expsum, q, MP_DTYPE_BF16,
+                          lsh->qnorm, lsh->results, lsh->nnz, st);
+        if (rc) return rc;
+    }
     if (nnz_out)
         MP_HIP_CHECK(hipMemcpyAsync(nnz_out, lsh->nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));
     return MP_OK;

@@ -19,6 +19,7 @@
 // ASCENDING token order (the reference emits second-hit order; only set + nnz are defined,
 // library/lsh/test.py:43-56).
 #include "common.h"
+#include "attn_head.h"
 
 namespace mp {
 
@@ -295,11 +296,30 @@ struct HashArgs {
     int D, K, KLpad;
 };
 
-template <bool HASH, int CH>   // CH = min(16, D / 8): plane chunks kept in registers (HASH only)
+// AD > 0 (with HASH) appends the sparse attention of the head to the same launch (attn_head.h): the
+// selected ids never leave the workgroup's LDS.  A head is served by a CLUSTER of 1, 2, 4 or 8
+// workgroups (grid = cluster * BH, block b -> head b % BH, rank b / BH): every member repeats the
+// hash + retrieve of the head (identical bitmaps, the table ids come from L2), keeps the ids of the
+// 32-entry slices rank, rank + cluster, ... and gathers only those; with cluster > 1 the members' states meet
+// through one write-through partial each and an arrival ticket.  cluster = 1 when every CU has a head.
+struct AttnArgs {
+    const uint16_t* kv;      // [B*Hkv][M][2][D]
+    const float* kn;         // [B*Hkv][M]
+    float* part_o;           // [BH][maxs][D]
+    float2* part_ml;         // [BH][maxs]
+    int* head_cnt;           // [BH] arrival tickets, zero between launches
+    uint16_t* out;           // [BH][D] bf16
+    float* mve;              // [2][BH]
+    float2* head_mz;         // [BH]
+    float* score;            // [BH][M] (nullable)
+    int BH, maxs, cap, cluster_log2;   // cap: ids of the LDS stage (multiple of AH_SLICE)
+};
+
+template <bool HASH, int CH, int AD>   // CH = min(16, D / 8): plane chunks kept in registers (HASH only)
 __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
     const int2* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
-    int G, int L, int NB, int64_t M, int words, int Lpad, HashArgs ha,
+    int G, int L, int NB, int64_t M, int words, int Lpad, HashArgs ha, AttnArgs aa,
     unsigned long long* __restrict__ stamp) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_u32[];
     uint32_t* bmA = s_u32;
@@ -313,11 +333,18 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
     // (placed by INDEX, rounded up to 16 bytes for ds_read_b128: a uintptr_t round trip would lose the
     // LDS address space and turn every read of the query into a flat_load that waits on vmcnt too)
     uint32_t* s_q = s_u32 + ((2 * words + 2 * Lpad + RT_TAIL_CAP + 32 + 4 + 3) & ~3);
-    float* s_rn = reinterpret_cast<float*>(s_q + 128);
+    float* s_rn = reinterpret_cast<float*>(s_q + 128);       // [0] guard bound of ||nq||, [1] ||q||
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_rn + 4);
+    // AD only: s_ids [cap] (ids of this workgroup's slices) | s_merge | s_tk
+    int32_t* s_ids = reinterpret_cast<int32_t*>(s_bits + ((((16 * L + 31) >> 5) + 2 * RT_WAVES + 4 + 3) & ~3));
+    float* s_merge = reinterpret_cast<float*>(s_ids + (AD > 0 ? aa.cap : 0));
+    int* s_tk = reinterpret_cast<int*>(s_merge + attn_head_lds_floats(RT_WAVES, AD > 0 ? AD : 2));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t h = blockIdx.x;
+    const int64_t h = (AD > 0) ? (int64_t)(blockIdx.x % aa.BH) : (int64_t)blockIdx.x;
+    const int rank = (AD > 0) ? (int)(blockIdx.x / aa.BH) : 0;
+    const int clog = (AD > 0) ? aa.cluster_log2 : 0;
+    const bool lead = rank == 0;                              // the member that writes codes / ||q|| / results / nnz
     const int64_t g = h / G;
     const int2* bnd = bounds + g * L * NB;
     const int32_t* tab = table + g * L * M;
@@ -365,13 +392,16 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
             ss = wave_sum(ss);
             const float nrm = (float)sqrt((double)(float)ss);
             const float nb = bf16_bits_to_f32(f32_to_bf16_rne(nrm));
-            if (lane == 0 && ha.qnorm_out != nullptr) ha.qnorm_out[h] = nrm;
+            if (lane == 0 && lead && ha.qnorm_out != nullptr) ha.qnorm_out[h] = nrm;
             uint16_t* dst = reinterpret_cast<uint16_t*>(s_q) + lane * per;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < per) dst[i] = f32_to_bf16_rne(__fdiv_rn(bf16_bits_to_f32(e[i]), nb));
             // ||nq|| <= ||q||/nb * (1 + 2^-8): every element is rounded to bf16 once (guard bound)
-            if (lane == 0) *s_rn = (nrm / nb) * 1.005f;
+            if (lane == 0) {
+                s_rn[0] = (nrm / nb) * 1.005f;
+                s_rn[1] = nrm;
+            }
         }
         __syncthreads();
         MP_STAMP(stamp, 22);
@@ -432,7 +462,7 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
                 uint32_t v = s_bits[w] >> sh;
                 if (sh + ha.K > 32) v |= s_bits[w + 1] << (32 - sh);
                 code = (int)(v & ((1u << ha.K) - 1u));
-                ha.codes_out[h * L + l] = code;
+                if (lead) ha.codes_out[h * L + l] = code;
             } else {
                 code = query[h * L + l];
             }
@@ -527,6 +557,11 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
     int total;
     int off = block_excl_scan(cnt, s_tmp, total);
     MP_STAMP(stamp, 20);
+    // AD: the ids of slices rank, rank + cluster, ... stay in LDS; when the list is longer than the
+    // stage holds (cap * cluster ids) every member also writes the (identical) list to HBM and reads
+    // its own copy back.
+    const bool spill = AD > 0 && total > (aa.cap << clog);
+    const bool to_hbm = AD == 0 || lead || spill;
     for (int k = 0; k < wpt; ++k) {
         if (w0 + k >= nsw) break;
         uint32_t bits = bmB[w0 + k];
@@ -534,11 +569,101 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
         while (bits) {
             const int p = __ffs((int)bits) - 1;
             bits &= bits - 1;
-            out[off++] = base + p;
+            if (to_hbm) out[off] = base + p;
+            if (AD > 0) {
+                const int sl = off / AH_SLICE;
+                if ((sl & ((1 << clog) - 1)) == rank) {
+                    const int li = (sl >> clog) * AH_SLICE + (off % AH_SLICE);
+                    if (li < aa.cap) s_ids[li] = base + p;
+                }
+            }
+            ++off;
         }
     }
-    if (tid == 0) nnz[h] = total;
+    if (tid == 0 && lead) nnz[h] = total;
     MP_STAMP(stamp, 21);
+    if (AD == 0) return;
+
+    // ------------------------------------------------------------ fused sparse attention of head h
+    constexpr int ADD = AD > 0 ? AD : 64;
+    uint16_t* out_h = aa.out + h * ADD;
+    if (total == 0) {                       // every member sees the same list
+        if (lead) attn_head_empty<ADD>(out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
+        return;
+    }
+    __syncthreads();                        // s_ids complete; the spilled list drained (vmcnt) and visible in L2
+    MP_STAMP(stamp, 33);
+    auto ids = [&](int k, int j) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (!spill) {
+            v = *reinterpret_cast<const u32x4*>(s_ids + k * AH_SLICE + j);
+        } else {
+            const int64_t j0 = (((int64_t)k << clog) + rank) * AH_SLICE + j;
+            for (int e = 0; e < 4; ++e)
+                v[e] = (j0 + e < M) ? (uint32_t)__builtin_nontemporal_load(out + j0 + e) : 0u;
+        }
+        return v;
+    };
+    float m, Z, o;
+    attn_head_tail<ADD>(aa.kv + g * M * 2 * ADD, aa.kn + g * M, ha.q + h * ADD, s_rn[1], total, M, ha.K, L,
+                        rank, 1 << clog, ids, s_merge, aa.score ? aa.score + h * M : nullptr, stamp, m, Z, o);
+    if (clog == 0) {
+        attn_head_finalize<ADD>(m, Z, o, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
+        MP_STAMP(stamp, 39);
+        return;
+    }
+    // ---- cluster > 1: publish this member's state WRITE-THROUGH (sc1), drain, take an arrival
+    // ticket; the member that draws the last ticket merges (hand-off recipe: cdna_hip_programming.md
+    // G16, as attn_sparse_kernel)
+    const int nmem = 1 << clog;
+    const int64_t pre = h * aa.maxs;
+    if (tid < ADD)
+        __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + tid),
+                           __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(aa.part_ml + pre + rank),
+                           (unsigned long long)__float_as_uint(m) | ((unsigned long long)__float_as_uint(Z) << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        *s_tk = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    MP_STAMP(stamp, 38);
+    if (*s_tk != nmem - 1) return;
+    if (tid == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < ADD) {
+        float mr[8], zr[8], orr[8];
+        float mm = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            mr[u] = -INFINITY;
+            zr[u] = 0.f;
+            orr[u] = 0.f;
+            if (u < nmem) {
+                const unsigned long long pk = __hip_atomic_load(
+                    reinterpret_cast<unsigned long long*>(aa.part_ml + pre + u), __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT);
+                mr[u] = __uint_as_float((uint32_t)pk);
+                zr[u] = __uint_as_float((uint32_t)(pk >> 32));
+                orr[u] = __uint_as_float(__hip_atomic_load(
+                    reinterpret_cast<unsigned int*>(aa.part_o + (pre + u) * ADD + tid), __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT));
+                mm = fmaxf(mm, mr[u]);
+            }
+        }
+        float ZZ = 0.f, oo = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u < nmem && mr[u] != -INFINITY) {
+                const float e = __expf(mr[u] - mm);
+                ZZ = fmaf(e, zr[u], ZZ);
+                oo = fmaf(e, orr[u], oo);
+            }
+        }
+        attn_head_finalize<ADD>(mm, ZZ, oo, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
+    }
+    MP_STAMP(stamp, 39);
 }
 
 // ---------------------------------------------------------------- LSH::get_mask (debug view)
@@ -630,19 +755,26 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     return hipGetLastError();
 }
 
+constexpr int DECODE_ID_CAP = 4096;   // ids of the fused kernel's LDS stage per workgroup (64 slices)
+
+static size_t decode_lds_bytes(int64_t M, int L, int D) {
+    return retrieve_lds_bytes(M, L) + ((size_t)DECODE_ID_CAP + attn_head_lds_floats(RT_WAVES, D) + 16) * 4;
+}
+
 static hipError_t retrieve_attr_once() {
     static bool attr_done = false;
     if (attr_done) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_retrieve_kernel<false, 16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 16>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) attr_done = true;
-    return e;
+    const void* fns[] = {reinterpret_cast<const void*>(lsh_retrieve_kernel<false, 16, 0>),
+                         reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 16, 0>),
+                         reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 8, 0>),
+                         reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 16, 128>),
+                         reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 8, 64>)};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    attr_done = true;
+    return hipSuccess;
 }
 
 hipError_t launch_lsh_retrieve(const int2* bounds, const int32_t* table, const int32_t* query,
@@ -653,12 +785,14 @@ hipError_t launch_lsh_retrieve(const int2* bounds, const int32_t* table, const i
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
     HashArgs ha = {};
-    hipLaunchKernelGGL((lsh_retrieve_kernel<false, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
-                       st, bounds, table, query, results, nnz, G, L, NB, M, words, Lpad, ha, g_stamp);
+    AttnArgs aa = {};
+    hipLaunchKernelGGL((lsh_retrieve_kernel<false, 16, 0>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+                       st, bounds, table, query, results, nnz, G, L, NB, M, words, Lpad, ha, aa, g_stamp);
     return hipGetLastError();
 }
 
-// q-hash fused into the retrieve (mp_decode_sparse_layer): codes and ||q|| are by-products
+// q-hash fused into the retrieve (the two-launch form of mp_decode_sparse_layer): codes and ||q||
+// are by-products
 hipError_t launch_lsh_hash_retrieve(const int2* bounds, const int32_t* table, const uint16_t* q,
                                     const uint16_t* Wk, const float* wnorm, int D, int K, int KLpad,
                                     int32_t* codes_out, float* qnorm_out, int32_t* results,
@@ -669,14 +803,49 @@ hipError_t launch_lsh_hash_retrieve(const int2* bounds, const int32_t* table, co
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
+    AttnArgs aa = {};
     if (D >= 128)
-        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 16, 0>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, words,
-                           Lpad, ha, g_stamp);
+                           Lpad, ha, aa, g_stamp);
     else
-        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 8>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 8, 0>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, words,
-                           Lpad, ha, g_stamp);
+                           Lpad, ha, aa, g_stamp);
+    return hipGetLastError();
+}
+
+// the whole sparse layer in ONE launch (mp_decode_sparse_layer): hash + retrieve + attention.
+// D = 64 or 128; cluster = workgroups per head (1, 2, 4 or 8).
+bool lsh_decode_supported(int64_t M, int L, int D) {
+    return (D == 64 || D == 128) && decode_lds_bytes(M, L, D) <= 160u * 1024u;
+}
+
+hipError_t launch_lsh_decode(const int2* bounds, const int32_t* table, const uint16_t* q,
+                             const uint16_t* Wk, const float* wnorm, int D, int K, int KLpad,
+                             int32_t* codes_out, float* qnorm_out, int32_t* results, int32_t* nnz,
+                             const uint16_t* kv, const float* kn, float* part_o, float2* part_ml,
+                             int* head_cnt, uint16_t* out, float* mve, float2* head_mz, float* score,
+                             int maxs, int cluster, int BH, int G, int L, int NB, int64_t M,
+                             hipStream_t st) {
+    const int words = (int)((M + 31) / 32);
+    const int Lpad = (L + 63) & ~63;
+    hipError_t e = retrieve_attr_once();
+    if (e != hipSuccess) return e;
+    int clog = 0;
+    while ((2 << clog) <= cluster && clog < 3) ++clog;
+    HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
+    AttnArgs aa = {kv, kn, part_o, part_ml, head_cnt, out, mve, head_mz, score, BH, maxs, DECODE_ID_CAP, clog};
+    const dim3 grid((unsigned)BH << clog);
+    const size_t lds = decode_lds_bytes(M, L, D);
+    if (D == 128)
+        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 16, 128>), grid, dim3(RT_THREADS), lds, st, bounds, table,
+                           (const int32_t*)nullptr, results, nnz, G, L, NB, M, words, Lpad, ha, aa, g_stamp);
+    else if (D == 64)
+        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 8, 64>), grid, dim3(RT_THREADS), lds, st, bounds, table,
+                           (const int32_t*)nullptr, results, nnz, G, L, NB, M, words, Lpad, ha, aa, g_stamp);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -48,3 +48,5 @@ seg("partial  [start|prefix|gathers issued|qk+reduce|transform|pv|combine]", [32
 print("kernel-to-kernel (WG0 start to WG0 start): simhash->retrieve %.2f, retrieve->partial %.2f us" % (
     np.median(a[:, 16] - a[:, 0]), np.median(a[:, 32] - a[:, 16])))
 print("nnz mean", float(server.nnz.float().mean()))
+seg("fused decode kernel [start|hash+probe|table streamed|scan|emit|ids staged|K gathers issued|qk|transform|pv|ticket|end]",
+    [16, 17, 19, 20, 21, 33, 34, 35, 36, 37, 38, 39])
