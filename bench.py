@@ -11,8 +11,8 @@ torch.distributed.run and every rank serves its own batch of requests (weak scal
 collective inside the path; RCCL only for the barrier and the max-over-ranks time).
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying
-  roofline      the dominant kernel (attn_sparse_kernel): algorithmic bytes per launch /
-                average dispatch duration from HIP events bound to the dispatches;
+  roofline      the dominant kernel (lsh_decode_kernel, one launch per sparse layer): algorithmic
+                bytes per launch / average launch duration from HIP events on the launch stream;
   cpu_baseline  the reference's own AVX512 path (oracle/_ref, kind "reference") or the oracle
                 port (kind "port") timed on this box's host cores on a bounded sample.
 """
@@ -334,42 +334,35 @@ def main():
     tokens_per_s = world * B * args.steps / dt
     us_per_layer = ms_per_step * 1e3 / NL
 
-    # ---- roofline leg: the dominant kernel alone (attn_sparse_kernel), same workload: per-layer
-    # index lists from a real retrieve pass, then back-to-back launches of ONLY that kernel on the
-    # current stream, bracketed by HIP events recorded on that same stream.
-    server.collect_nnz = True
-    res_l, nnz_l, qn_l = [], [], []
-    q_static.copy_(qs[0])
-    for li in range(NL):
-        codes, qn = server.hasher.query(q_static[li].reshape(BH, D))
-        r_ = torch.zeros((BH, M), dtype=torch.int32, device=dev)
-        z_ = torch.zeros((BH,), dtype=torch.int32, device=dev)
-        server.lsh_retriever.batch_retrieve(li, codes, r_, z_)
-        res_l.append(r_); nnz_l.append(z_); qn_l.append(qn)
+    # ---- roofline leg.  A sparse layer is ONE launch (lsh_decode_kernel: hash -> retrieve -> attention),
+    # so the dominant kernel is the step itself: its average duration is taken from HIP events recorded
+    # on the launch stream around back-to-back launches (graph replays when the step is captured), its
+    # algorithmic bytes are the whole-layer figure of SURVEY.md 8(d).
     prof_reps = 8
-    def partial_pass():
-        for li in range(NL):
-            server.attn_server.attention_wrapper(li, K, Lt, server.output, server.max_value_expsum,
-                                                 q_static[li].reshape(BH, D), qn_l[li], res_l[li], nnz_l[li])
-    partial_pass()
+    q_static.copy_(qs[0])
+    def layer_pass():
+        if graph is not None:
+            graph.replay()
+        else:
+            for li in range(NL):
+                server.decode(q_static[li], li)
+    layer_pass()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(prof_reps):
-        partial_pass()
+        layer_pass()
     e1.record()
     torch.cuda.synchronize()
     n_timed = prof_reps * NL
     k_us = e0.elapsed_time(e1) * 1e3 / n_timed
-    nnz_prof = float(torch.stack(nnz_l).float().mean())
-    del res_l
-    # algorithmic bytes of ONE attn_sparse_kernel launch (DESIGN.md "Algorithmic bytes"):
-    #   per selected token: K row + V row (2*D*2) + key norm (4) + id (4);  per head: q (2*D) + partial
-    bytes_attn = nnz_prof * BH * (4 * D + 8) + BH * (2 * D) + (nnz_prof * BH / 64 + BH) * (D * 4 + 8)
-    achieved = bytes_attn / (k_us * 1e-6) / 1e9
-    # whole-layer algorithmic bytes, SURVEY.md 8(d)
+    # whole-layer algorithmic bytes, SURVEY.md 8(d): per head L bucket probes (8 B), the candidate
+    # ids (4 B), the selected ids (4 B), per selected token K row + V row + key norm + id, q and out;
+    # plus the hyperplanes once per layer
     bytes_layer = BH * (8 * Lt + 4 * cand_mean + 4 * nnz_mean + nnz_mean * (4 * D + 4) + 4 * nnz_mean
                         + 2 * D + 8) + 2 * D * K * Lt + BH * (2 * D + 4 * Lt)
+    achieved = bytes_layer / (k_us * 1e-6) / 1e9
+    fused = os.environ.get("MP_DECODE_TWO_LAUNCH") is None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
     if os.path.exists(tpath):
@@ -377,7 +370,7 @@ def main():
             with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("config") == args.config:
-                traffic = tj.get("attn_sparse_bytes_per_launch")
+                traffic = tj.get("lsh_decode_bytes_per_launch" if fused else "two_launch_bytes_per_layer")
         except Exception:
             traffic = None
 
@@ -394,11 +387,11 @@ def main():
         "sparse_attn_us_per_layer": us_per_layer,
         "observed": {"nnz_per_head": nnz_mean, "candidates_per_head": cand_mean,
                      "selected_fraction": nnz_mean / n, "setup_s": t_setup},
-        "roofline": {"bound": "hbm", "kernel": "attn_sparse_kernel", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "bytes_per_launch": bytes_attn, "avg_launch_us": k_us,
-                     "launches_timed": n_timed,
-                     "layer_bytes": bytes_layer, "layer_frac": bytes_layer / (us_per_layer * 1e-6) / 1e9 / HBM_PEAK_GBS},
+        "roofline": {"bound": "hbm",
+                     "kernel": "lsh_decode_kernel" if fused else "lsh_retrieve_kernel + attn_sparse_kernel",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "bytes_per_launch": bytes_layer, "avg_launch_us": k_us,
+                     "launches_timed": n_timed},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

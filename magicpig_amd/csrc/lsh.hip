@@ -316,10 +316,10 @@ struct AttnArgs {
 };
 
 template <bool HASH, int CH, int AD>   // CH = min(16, D / 8): plane chunks kept in registers (HASH only)
-__global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
+__device__ __forceinline__ void lsh_head_body(
     const int2* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
-    int G, int L, int NB, int64_t M, int words, int Lpad, HashArgs ha, AttnArgs aa,
+    int G, int L, int NB, int64_t M, int words, int Lpad, const HashArgs& ha, const AttnArgs& aa,
     unsigned long long* __restrict__ stamp) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_u32[];
     uint32_t* bmA = s_u32;
@@ -666,6 +666,27 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
     MP_STAMP(stamp, 39);
 }
 
+// LSH::batch_retrieve (optionally with the query hash as its prologue)
+template <bool HASH, int CH>
+__global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
+    const int2* __restrict__ bounds, const int32_t* __restrict__ table,
+    const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
+    int G, int L, int NB, int64_t M, int words, int Lpad, HashArgs ha,
+    unsigned long long* __restrict__ stamp) {
+    const AttnArgs aa = {};
+    lsh_head_body<HASH, CH, 0>(bounds, table, query, results, nnz, G, L, NB, M, words, Lpad, ha, aa, stamp);
+}
+
+// the whole sparse layer of models/attnserver.py:264-300: hash -> retrieve -> attention
+template <int CH, int AD>
+__global__ __launch_bounds__(RT_THREADS) void lsh_decode_kernel(
+    const int2* __restrict__ bounds, const int32_t* __restrict__ table,
+    int32_t* __restrict__ results, int32_t* __restrict__ nnz,
+    int G, int L, int NB, int64_t M, int words, int Lpad, HashArgs ha, AttnArgs aa,
+    unsigned long long* __restrict__ stamp) {
+    lsh_head_body<true, CH, AD>(bounds, table, nullptr, results, nnz, G, L, NB, M, words, Lpad, ha, aa, stamp);
+}
+
 // ---------------------------------------------------------------- LSH::get_mask (debug view)
 // Recomputes min(count, 2) per token for the last query codes; byte counters in global memory,
 // one workgroup per head, atomics on 32-bit words holding 4 counters... kept simple: each
@@ -764,11 +785,11 @@ static size_t decode_lds_bytes(int64_t M, int L, int D) {
 static hipError_t retrieve_attr_once() {
     static bool attr_done = false;
     if (attr_done) return hipSuccess;
-    const void* fns[] = {reinterpret_cast<const void*>(lsh_retrieve_kernel<false, 16, 0>),
-                         reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 16, 0>),
-                         reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 8, 0>),
-                         reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 16, 128>),
-                         reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 8, 64>)};
+    const void* fns[] = {reinterpret_cast<const void*>(lsh_retrieve_kernel<false, 16>),
+                         reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 16>),
+                         reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 8>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -785,9 +806,8 @@ hipError_t launch_lsh_retrieve(const int2* bounds, const int32_t* table, const i
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
     HashArgs ha = {};
-    AttnArgs aa = {};
-    hipLaunchKernelGGL((lsh_retrieve_kernel<false, 16, 0>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
-                       st, bounds, table, query, results, nnz, G, L, NB, M, words, Lpad, ha, aa, g_stamp);
+    hipLaunchKernelGGL((lsh_retrieve_kernel<false, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+                       st, bounds, table, query, results, nnz, G, L, NB, M, words, Lpad, ha, g_stamp);
     return hipGetLastError();
 }
 
@@ -803,15 +823,14 @@ hipError_t launch_lsh_hash_retrieve(const int2* bounds, const int32_t* table, co
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
-    AttnArgs aa = {};
     if (D >= 128)
-        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 16, 0>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, words,
-                           Lpad, ha, aa, g_stamp);
+                           Lpad, ha, g_stamp);
     else
-        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 8, 0>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 8>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, words,
-                           Lpad, ha, aa, g_stamp);
+                           Lpad, ha, g_stamp);
     return hipGetLastError();
 }
 
@@ -839,11 +858,11 @@ hipError_t launch_lsh_decode(const int2* bounds, const int32_t* table, const uin
     const dim3 grid((unsigned)BH << clog);
     const size_t lds = decode_lds_bytes(M, L, D);
     if (D == 128)
-        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 16, 128>), grid, dim3(RT_THREADS), lds, st, bounds, table,
-                           (const int32_t*)nullptr, results, nnz, G, L, NB, M, words, Lpad, ha, aa, g_stamp);
+        hipLaunchKernelGGL((lsh_decode_kernel<16, 128>), grid, dim3(RT_THREADS), lds, st, bounds, table,
+                           results, nnz, G, L, NB, M, words, Lpad, ha, aa, g_stamp);
     else if (D == 64)
-        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 8, 64>), grid, dim3(RT_THREADS), lds, st, bounds, table,
-                           (const int32_t*)nullptr, results, nnz, G, L, NB, M, words, Lpad, ha, aa, g_stamp);
+        hipLaunchKernelGGL((lsh_decode_kernel<8, 64>), grid, dim3(RT_THREADS), lds, st, bounds, table,
+                           results, nnz, G, L, NB, M, words, Lpad, ha, aa, g_stamp);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

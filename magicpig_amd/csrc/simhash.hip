@@ -248,11 +248,11 @@ constexpr int SK_MAX_TABLES = 32;
 
 template <int D>
 __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void simhash_keys_kernel(
-    const uint16_t* __restrict__ x,       // [heads][n][D] bf16 (centred keys; blockIdx.z = kv head)
+    const uint16_t* __restrict__ x,       // [heads][n][D] bf16 (centred keys)
     const uint16_t* __restrict__ Wt,      // [KLpad][D]
     const float* __restrict__ wnorm,      // [KLpad]
-    int64_t n, int K, int L, int tables_per_wg, int tiles_per_wg, int chunk_tiles,
-    int16_t* __restrict__ codes,          // [heads][L][n]
+    int64_t n, int K, int L, int tables_per_wg, int tiles_per_wg, int chunk_tiles, int wgs_x, int chunks,
+    int heads, int16_t* __restrict__ codes,   // [heads][L][n]
     unsigned long long* __restrict__ stamp) {
     constexpr int KSTEPS = D / 16;
     constexpr int STRIDE = D + 8;
@@ -271,11 +271,21 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int nthr = NTHR;
-    const int table0 = blockIdx.x * tables_per_wg;
+    // 1-D grid, XCD-aware: block b runs on XCD b % 8.  The wgs_x workgroups that hash the SAME rows
+    // against different plane spans are given consecutive slots of ONE XCD (b = (q * wgs_x + j) * 8 +
+    // xcd for row chunk 8q + xcd), so the rows come from HBM once and from that XCD's L2 wgs_x - 1
+    // times; with column-fastest numbering they landed on wgs_x different XCDs and HBM served every
+    // copy (PMC: 1.29 GB read per layer at cfg 1 for 0.2 GB of keys).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int colgrp = slot % wgs_x;
+    const int64_t unit = (int64_t)(slot / wgs_x) * 8 + xcd;   // (kv head, row chunk), chunk fastest
+    if (unit >= (int64_t)chunks * heads) return;
+    const int head = (int)(unit / chunks), chunk = (int)(unit % chunks);
+    const int table0 = colgrp * tables_per_wg;
     const int col0 = table0 * K, KL = K * L;   // col0 is NOT tile aligned: Wt is row-per-plane, any start works
-    x += (int64_t)blockIdx.z * n * D;                        // kv head
-    codes += (int64_t)blockIdx.z * L * n;
-    const int64_t row_base = (int64_t)blockIdx.y * CROWS;
+    x += (int64_t)head * n * D;
+    codes += (int64_t)head * L * n;
+    const int64_t row_base = (int64_t)chunk * CROWS;
     int nt = (int)((n - row_base + SH_ROWS - 1) / SH_ROWS);
     if (nt > chunk_tiles) nt = chunk_tiles;
     if (tid == 0) s_qn = 0;
@@ -592,7 +602,6 @@ static int keys_chunk_tiles(int64_t n, int64_t wgs_x, int tables_per_wg) {
     double best_cost = 1e300;
     for (int ch = 1; ch <= SK_CH_MAX; ++ch) {
         if ((size_t)tables_per_wg * ch * SH_ROWS * sizeof(int16_t) > 48u * 1024u) break;
-        if ((tiles + ch - 1) / ch > 65535) continue;
         const int64_t wgs = ((tiles + ch - 1) / ch) * wgs_x;
         const double cost = (double)((wgs + slots - 1) / slots) * (1.9 * ch + 7.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = ch; }
@@ -617,14 +626,16 @@ hipError_t launch_simhash_keys(const uint16_t* keys, const uint16_t* Wt, const f
     const int ch = memo_ch;
     const int64_t crows = (int64_t)ch * SH_ROWS;
     const int64_t chunks = (n + crows - 1) / crows;
-    if (chunks > 65535) return hipErrorInvalidValue;
-    dim3 grid(wgs_x, (unsigned)chunks, (unsigned)heads);
+    const int64_t units = chunks * heads;
+    const int64_t blocks = ((units + 7) / 8) * wgs_x * 8;
+    if (chunks > INT32_MAX || blocks > INT32_MAX) return hipErrorInvalidValue;
+    dim3 grid((unsigned)blocks);
     dim3 block(64 * SK_WAVES);
     const size_t lds = (size_t)tp * crows * sizeof(int16_t);
 #define MP_SK_CASE(DD)                                                                              \
     if (D == DD) {                                                                                  \
         hipLaunchKernelGGL((simhash_keys_kernel<DD>), grid, block, lds, st, keys, Wt, wnorm, n, K,  \
-                           L, tp, tiles, ch, codes, g_stamp);                                       \
+                           L, tp, tiles, ch, wgs_x, (int)chunks, heads, codes, g_stamp);            \
         return hipGetLastError();                                                                   \
     }
     MP_SK_CASE(128)
