@@ -152,6 +152,11 @@ int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream);
  * boundaries of workgroup 0 of the hot kernels (scripts/phase_times.py); NULL switches it off. */
 int mp_debug_set_stamp_buffer(void* dev_u64x64);
 
+/* Debug: 1 if workgroup b of a launch was observed to run on XCD b % 8 on the current device (measured
+ * once per process); this is what lets the cluster hand-off of the fused decode kernel stay inside one
+ * XCD's L2.  0 = not observed, the hand-off writes through to memory instead. */
+int mp_debug_xcd_round_robin(void);
+
 /* ---------------------------------------------------------------- one decode step of one layer
  * The device-resident equivalent of LSHSparseAttnServer.decode lines 264-300
  * (models/attnserver.py): q-hash -> batch_retrieve -> attention_wrapper with codes, results

@@ -72,6 +72,7 @@ def lib() -> C.CDLL:
         "mp_attn_append": ([p, i32, p, p, p, p], i32),
         "mp_attn_check": ([p, p], i32),
         "mp_debug_set_stamp_buffer": ([p], i32),
+        "mp_debug_xcd_round_robin": ([], i32),
         "mp_attn_get_kv": ([p, i32, pp, pp, C.POINTER(i64)], i32),
         "mp_attn_get_key_norm": ([p, i32, pp], i32),
         "mp_attn_get_score": ([p, pp, p], i32),

@@ -60,7 +60,7 @@ template <int D, typename IDS>
 __device__ __forceinline__ void attn_head_tail(
     const uint16_t* __restrict__ kv_g,   // kv rows of this head's kv group: [M][2][D]
     const float* __restrict__ kn_g,      // key norms of the group: [M]
-    const uint16_t* __restrict__ q_h,    // [D] bf16 query of this head
+    const u32x4 qv,                      // this lane's 8 query elements: bf16 q[(lane % LPR)*8 ..]
     float qn_h, int nz, int64_t M, int K, int L, int slice0, int slice_stride, IDS&& ids,
     float* s_merge,                      // LDS, attn_head_lds_floats(NW, D)
     float* __restrict__ score_h,         // [M] transformed logits (nullable)
@@ -71,7 +71,6 @@ __device__ __forceinline__ void attn_head_tail(
     static_assert((64 / LPR) * UPS == AH_SLICE, "a step covers 32 tokens");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int r = lane / LPR, c = lane % LPR;
-    const u32x4 qv = *reinterpret_cast<const u32x4*>(q_h + c * 8);
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
     const uint16_t* kvc = kv_g + c * 8;
 

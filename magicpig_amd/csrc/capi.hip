@@ -21,10 +21,11 @@ hipError_t launch_simhash_keys(const uint16_t*, const uint16_t*, const float*, i
                                int, int, int16_t*, hipStream_t);
 size_t retrieve_lds_bytes(int64_t M, int L);
 bool lsh_decode_supported(int64_t M, int L, int D);
+bool xcd_round_robin_verified();
 hipError_t launch_lsh_decode(const int2*, const int32_t*, const uint16_t*, const uint16_t*, const float*, int,
                              int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
-                             float*, float2*, int*, uint16_t*, float*, float2*, float*, int, int, int, int,
-                             int, int, int64_t, hipStream_t);
+                             float*, float2*, int*, uint16_t*, float*, float2*, float*, int, int, bool, int,
+                             int, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int2*,
                            int32_t*, int*, hipStream_t);
 hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int2*, int32_t*, int*,
@@ -138,6 +139,7 @@ struct mp_attn {
     int score_state = 0;           // 0 none, 1 logits, 2 probabilities
     int grid = 8;                  // workgroups per head of the partial kernel (grid.x)
     bool head_kernel = false;      // one workgroup per head (attn_head_kernel) instead of split-KV
+    bool xcd_rr = false;           // block b -> XCD b % 8 observed on this device (xcd_round_robin_verified)
     int cus = 256;
 };
 
@@ -511,6 +513,7 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             cus = prop.multiProcessorCount;
         h->cus = cus;
+        h->xcd_rr = xcd_round_robin_verified() && getenv("MP_DECODE_AGENT_SCOPE") == nullptr;
         // with a head (or more) per CU the split-KV machinery only costs: one workgroup per head
         h->head_kernel = (BH * 2 >= cus) && (h->D == 64 || h->D == 128);
         if (const char* e = getenv("MP_ATTN_HEAD")) h->head_kernel = atoi(e) != 0;   // A/B override
@@ -670,6 +673,8 @@ int mp_debug_set_stamp_buffer(void* dev_u64x64) {
     return MP_OK;
 }
 
+int mp_debug_xcd_round_robin(void) { return xcd_round_robin_verified() ? 1 : 0; }
+
 int mp_attn_get_kv(mp_attn_t* h, int layer_id, void** key_dev, void** value_dev,
                    int64_t* row_stride_elems) {
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_get_kv: not allocated");
@@ -731,7 +736,8 @@ int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int 
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
                                        attn->head_cnt, output, max_value_expsum, attn->head_mz, attn->score,
-                                       attn_slices_per_head(attn->M), cluster, BH, lsh->G, lsh->L, lsh->NB, lsh->M, st));
+                                       attn_slices_per_head(attn->M), cluster, attn->xcd_rr, BH, lsh->G, lsh->L,
+                                       lsh->NB, lsh->M, st));
         attn->lastz = lsh->nnz;
         attn->score_state = 1;
     } else {

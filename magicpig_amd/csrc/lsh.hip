@@ -313,6 +313,7 @@ struct AttnArgs {
     float2* head_mz;         // [BH]
     float* score;            // [BH][M] (nullable)
     int BH, maxs, cap, cluster_log2;   // cap: ids of the LDS stage (multiple of AH_SLICE)
+    int same_xcd;            // the members of a cluster share one XCD (and its L2): verified by the host
 };
 
 template <bool HASH, int CH, int AD>   // CH = min(16, D / 8): plane chunks kept in registers (HASH only)
@@ -339,6 +340,7 @@ __device__ __forceinline__ void lsh_head_body(
     int32_t* s_ids = reinterpret_cast<int32_t*>(s_bits + ((((16 * L + 31) >> 5) + 2 * RT_WAVES + 4 + 3) & ~3));
     float* s_merge = reinterpret_cast<float*>(s_ids + (AD > 0 ? aa.cap : 0));
     int* s_tk = reinterpret_cast<int*>(s_merge + attn_head_lds_floats(RT_WAVES, AD > 0 ? AD : 2));
+    uint32_t* s_qraw = reinterpret_cast<uint32_t*>(s_tk + 4);   // AD: the raw query row (bf16 pairs), 16-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t h = (AD > 0) ? (int64_t)(blockIdx.x % aa.BH) : (int64_t)blockIdx.x;
@@ -394,9 +396,13 @@ __device__ __forceinline__ void lsh_head_body(
             const float nb = bf16_bits_to_f32(f32_to_bf16_rne(nrm));
             if (lane == 0 && lead && ha.qnorm_out != nullptr) ha.qnorm_out[h] = nrm;
             uint16_t* dst = reinterpret_cast<uint16_t*>(s_q) + lane * per;
+            uint16_t* raw = reinterpret_cast<uint16_t*>(s_qraw) + lane * per;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (i < per) dst[i] = f32_to_bf16_rne(__fdiv_rn(bf16_bits_to_f32(e[i]), nb));
+                if (i < per) {
+                    dst[i] = f32_to_bf16_rne(__fdiv_rn(bf16_bits_to_f32(e[i]), nb));
+                    if (AD > 0) raw[i] = e[i];
+                }
             // ||nq|| <= ||q||/nb * (1 + 2^-8): every element is rounded to bf16 once (guard bound)
             if (lane == 0) {
                 s_rn[0] = (nrm / nb) * 1.005f;
@@ -605,53 +611,96 @@ __device__ __forceinline__ void lsh_head_body(
         return v;
     };
     float m, Z, o;
-    attn_head_tail<ADD>(aa.kv + g * M * 2 * ADD, aa.kn + g * M, ha.q + h * ADD, s_rn[1], total, M, ha.K, L,
+    const u32x4 qv = *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADD / 8)) * 4);
+    attn_head_tail<ADD>(aa.kv + g * M * 2 * ADD, aa.kn + g * M, qv, s_rn[1], total, M, ha.K, L,
                         rank, 1 << clog, ids, s_merge, aa.score ? aa.score + h * M : nullptr, stamp, m, Z, o);
     if (clog == 0) {
         attn_head_finalize<ADD>(m, Z, o, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
         MP_STAMP(stamp, 39);
         return;
     }
-    // ---- cluster > 1: publish this member's state WRITE-THROUGH (sc1), drain, take an arrival
-    // ticket; the member that draws the last ticket merges (hand-off recipe: cdna_hip_programming.md
-    // G16, as attn_sparse_kernel)
+    // ---- cluster > 1: publish this member's state, drain, take an arrival ticket; the member that
+    // draws the last ticket merges (hand-off recipe: cdna_hip_programming.md G16, as
+    // attn_sparse_kernel).  Block b runs on XCD b % 8, so when B*H is a multiple of 8 the members of a
+    // cluster (blocks h, h + BH, ...) share ONE XCD and its L2: the hand-off then only has to bypass the
+    // per-CU L1 (sc0, the workgroup scope of a split workgroup) instead of writing through to the
+    // memory side (sc1), which takes three ~0.6 us L2 round trips instead of three ~1.8 us ones.  The
+    // host enables it only after xcd_round_robin_verified() has seen the placement on this device.
     const int nmem = 1 << clog;
     const int64_t pre = h * aa.maxs;
-    if (tid < ADD)
-        __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + tid),
-                           __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 0)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(aa.part_ml + pre + rank),
-                           (unsigned long long)__float_as_uint(m) | ((unsigned long long)__float_as_uint(Z) << 32),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-        *s_tk = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    MP_STAMP(stamp, 38);
-    if (*s_tk != nmem - 1) return;
-    if (tid == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < ADD) {
-        float mr[8], zr[8], orr[8];
-        float mm = -INFINITY;
+    float mr[8], zr[8], orr[8];
+    if (aa.same_xcd) {
+        constexpr int kSc0 = 1;   // aux bit 0 = sc0 on gfx940+
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+            aa.part_o + pre * ADD, 0, (int)(aa.maxs * ADD * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<float*>(aa.part_ml + pre), 0, (int)(aa.maxs * 8), 0x00020000);
+        if (tid < ADD)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro, (rank * ADD + tid) * 4, 0, kSc0);
+        if (tid == 0) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rm, rank * 8, 0, kSc0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Z), rm, rank * 8 + 4, 0, kSc0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            *s_tk = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        MP_STAMP(stamp, 38);
+        if (*s_tk != nmem - 1) return;
+        if (tid == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (tid < ADD) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            mr[u] = -INFINITY;
-            zr[u] = 0.f;
-            orr[u] = 0.f;
-            if (u < nmem) {
-                const unsigned long long pk = __hip_atomic_load(
-                    reinterpret_cast<unsigned long long*>(aa.part_ml + pre + u), __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT);
-                mr[u] = __uint_as_float((uint32_t)pk);
-                zr[u] = __uint_as_float((uint32_t)(pk >> 32));
-                orr[u] = __uint_as_float(__hip_atomic_load(
-                    reinterpret_cast<unsigned int*>(aa.part_o + (pre + u) * ADD + tid), __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT));
-                mm = fmaxf(mm, mr[u]);
+            for (int u = 0; u < 8; ++u) {
+                mr[u] = -INFINITY;
+                zr[u] = 0.f;
+                orr[u] = 0.f;
+                if (u < nmem) {
+                    mr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, u * 8, 0, kSc0));
+                    zr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, u * 8 + 4, 0, kSc0));
+                    orr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (u * ADD + tid) * 4, 0, kSc0));
+                }
             }
         }
+    } else {
+        if (tid < ADD)
+            __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + tid),
+                               __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(aa.part_ml + pre + rank),
+                               (unsigned long long)__float_as_uint(m) | ((unsigned long long)__float_as_uint(Z) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            *s_tk = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        MP_STAMP(stamp, 38);
+        if (*s_tk != nmem - 1) return;
+        if (tid == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < ADD) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                mr[u] = -INFINITY;
+                zr[u] = 0.f;
+                orr[u] = 0.f;
+                if (u < nmem) {
+                    const unsigned long long pk = __hip_atomic_load(
+                        reinterpret_cast<unsigned long long*>(aa.part_ml + pre + u), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT);
+                    mr[u] = __uint_as_float((uint32_t)pk);
+                    zr[u] = __uint_as_float((uint32_t)(pk >> 32));
+                    orr[u] = __uint_as_float(__hip_atomic_load(
+                        reinterpret_cast<unsigned int*>(aa.part_o + (pre + u) * ADD + tid), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT));
+                }
+            }
+        }
+    }
+    if (tid < ADD) {
+        float mm = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mm = fmaxf(mm, mr[u]);
         float ZZ = 0.f, oo = 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -776,10 +825,47 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     return hipGetLastError();
 }
 
+// ---- where do blocks land?  The cluster hand-off of lsh_decode_kernel may stay inside one XCD's L2
+// only if block b really runs on XCD b % 8.  That is measured, once per process, on the device in
+// use: every block of two probe launches reports its XCC_ID.
+__global__ void xcc_probe_kernel(int* __restrict__ out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
+}
+
+bool xcd_round_robin_verified() {
+    static int state = -1;   // -1 unknown, 0 no, 1 yes
+    if (state >= 0) return state == 1;
+    state = 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(nullptr, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    int* d = nullptr;
+    if (hipMalloc(&d, 2 * 96 * sizeof(int)) != hipSuccess) return false;
+    int hbuf[2 * 96];
+    bool ok = hipMemset(d, 0xff, 2 * 96 * sizeof(int)) == hipSuccess;
+    const int grids[2] = {96, 40};
+    for (int t = 0; t < 2 && ok; ++t) {
+        hipLaunchKernelGGL(xcc_probe_kernel, dim3(grids[t]), dim3(64), 0, 0, d + t * 96);
+        ok = ok && hipGetLastError() == hipSuccess;
+    }
+    ok = ok && hipMemcpy(hbuf, d, sizeof(hbuf), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) return false;
+    for (int t = 0; t < 2; ++t)
+        for (int b = 0; b < grids[t]; ++b) {
+            const int x = hbuf[t * 96 + b];
+            if (x < 0 || x > 15 || x != hbuf[b % 8]) return false;      // same pattern in both launches
+        }
+    for (int a = 0; a < 8; ++a)
+        for (int b = a + 1; b < 8; ++b)
+            if (hbuf[a] == hbuf[b]) return false;                        // 8 distinct XCDs
+    state = 1;
+    return true;
+}
+
 constexpr int DECODE_ID_CAP = 4096;   // ids of the fused kernel's LDS stage per workgroup (64 slices)
 
 static size_t decode_lds_bytes(int64_t M, int L, int D) {
-    return retrieve_lds_bytes(M, L) + ((size_t)DECODE_ID_CAP + attn_head_lds_floats(RT_WAVES, D) + 16) * 4;
+    return retrieve_lds_bytes(M, L) + ((size_t)DECODE_ID_CAP + attn_head_lds_floats(RT_WAVES, D) + 16 + 64) * 4;
 }
 
 static hipError_t retrieve_attr_once() {
@@ -845,7 +931,7 @@ hipError_t launch_lsh_decode(const int2* bounds, const int32_t* table, const uin
                              int32_t* codes_out, float* qnorm_out, int32_t* results, int32_t* nnz,
                              const uint16_t* kv, const float* kn, float* part_o, float2* part_ml,
                              int* head_cnt, uint16_t* out, float* mve, float2* head_mz, float* score,
-                             int maxs, int cluster, int BH, int G, int L, int NB, int64_t M,
+                             int maxs, int cluster, bool same_xcd, int BH, int G, int L, int NB, int64_t M,
                              hipStream_t st) {
     const int words = (int)((M + 31) / 32);
     const int Lpad = (L + 63) & ~63;
@@ -854,7 +940,8 @@ hipError_t launch_lsh_decode(const int2* bounds, const int32_t* table, const uin
     int clog = 0;
     while ((2 << clog) <= cluster && clog < 3) ++clog;
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
-    AttnArgs aa = {kv, kn, part_o, part_ml, head_cnt, out, mve, head_mz, score, BH, maxs, DECODE_ID_CAP, clog};
+    AttnArgs aa = {kv, kn, part_o, part_ml, head_cnt, out, mve, head_mz, score, BH, maxs, DECODE_ID_CAP, clog,
+                   (same_xcd && clog > 0 && BH % 8 == 0) ? 1 : 0};
     const dim3 grid((unsigned)BH << clog);
     const size_t lds = decode_lds_bytes(M, L, D);
     if (D == 128)

@@ -580,6 +580,73 @@ def test_fused_decode_layer(mp, name, table_build):
     assert np.allclose(lse.cpu().numpy().reshape(-1), r["mve"][1])
 
 
+def _fused_server(mp, B, H, Hkv, n, M, D, K, L, seed):
+    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L)
+    server = mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, num_sink_tokens=0,
+                                    num_local_tokens=0, max_length=M, dense_layers=(),
+                                    hash_func=bf16_t(W, "cuda"))
+    for b in range(B):
+        server.hash_code_buffer = server.hasher.keys(bf16_t(keys[b], "cuda"))
+        server.build_table(0, b, n)
+        server.attn_server.fill(0, b, bf16_t(keys[b], "cuda"), bf16_t(vals[b], "cuda"),
+                                torch.from_numpy(kns[b]).cuda())
+    return server, (keys, kns, vals, W, qb)
+
+
+@pytest.mark.parametrize("B,H,Hkv", [(1, 32, 8), (1, 8, 2), (2, 6, 3)])
+def test_fused_decode_cluster_handoff_is_deterministic(mp, B, H, Hkv):
+    """The one-launch decode entry spreads a head over a cluster of workgroups whose states meet
+    through L2 (same-XCD hand-off when B*H is a multiple of 8, write-through otherwise): 40 launches
+    on changing queries, each repeated, must be bit-identical run to run and agree with the
+    two-kernel path (same ids, same math, different summation order)."""
+    n, M, D, K, L = 6000, 6144, 128, 8, 75
+    server, (keys, kns, vals, W, qb) = _fused_server(mp, B, H, Hkv, n, M, D, K, L, 4242)
+    BH = B * H
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    for it in range(20):
+        q = torch.randn((B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16)
+        out1, lse1 = server.decode(q, 0)
+        o1, l1, z1 = out1.clone(), lse1.clone(), server.nnz.clone()
+        out2, lse2 = server.decode(q, 0)
+        assert torch.equal(o1, out2) and torch.equal(l1, lse2)
+        # two-kernel reference of the same step: standalone hash, retrieve, attention_wrapper
+        codes, qn = server.hasher.query(q.reshape(BH, D))
+        res = torch.zeros((BH, M), dtype=torch.int32, device="cuda")
+        nz = torch.zeros((BH,), dtype=torch.int32, device="cuda")
+        server.lsh_retriever.batch_retrieve(0, codes, res, nz)
+        assert torch.equal(nz, z1)
+        o_ref = torch.zeros((BH, D), dtype=torch.bfloat16, device="cuda")
+        mve = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
+        server.attn_server.attention_wrapper(0, K, L, o_ref, mve, q.reshape(BH, D), qn, res, nz)
+        live = (nz > 0).cpu().numpy()
+        a = o1.reshape(BH, D).float().cpu().numpy()[live]
+        b_ = o_ref.float().cpu().numpy()[live]
+        assert np.allclose(a, b_, rtol=2 ** -6, atol=2e-3)
+        assert np.allclose(l1.reshape(-1).cpu().numpy()[live], mve[1].cpu().numpy()[live], atol=2e-3)
+
+
+def test_fused_decode_long_lists_spill_through_hbm(mp):
+    """K = 1 selects almost every token: the id list of a head (~n entries) is far longer than the
+    fused kernel's LDS stage, so every cluster member takes the spill path (list through HBM)."""
+    B, H, Hkv, n, M, D, K, L = 1, 2, 1, 40000, 40960, 128, 1, 40
+    server, _ = _fused_server(mp, B, H, Hkv, n, M, D, K, L, 99)
+    BH = B * H
+    q = torch.randn((B, H, 1, D), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)).to(torch.bfloat16)
+    out, lse = server.decode(q, 0)
+    nz1 = server.nnz.clone()
+    assert int(nz1.min()) > 4096 * 8
+    codes, qn = server.hasher.query(q.reshape(BH, D))
+    res = torch.zeros((BH, M), dtype=torch.int32, device="cuda")
+    nz = torch.zeros((BH,), dtype=torch.int32, device="cuda")
+    server.lsh_retriever.batch_retrieve(0, codes, res, nz)
+    assert torch.equal(nz, nz1)
+    o_ref = torch.zeros((BH, D), dtype=torch.bfloat16, device="cuda")
+    mve = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
+    server.attn_server.attention_wrapper(0, K, L, o_ref, mve, q.reshape(BH, D), qn, res, nz)
+    assert np.allclose(out.reshape(BH, D).float().cpu().numpy(), o_ref.float().cpu().numpy(), rtol=2 ** -6, atol=2e-3)
+    assert np.allclose(lse.reshape(-1).cpu().numpy(), mve[1].cpu().numpy(), atol=2e-3)
+
+
 def test_clear_and_refill(mp):
     """clear() x2 (lsh.cc:293-306, sparse_attention.cc:586-598): after a clear every bucket is empty
     (nnz == 0, out == 0, LSE == -inf), get_mask is all zero, the stores read back as zeros, and a
