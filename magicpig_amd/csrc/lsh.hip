@@ -599,21 +599,25 @@ __device__ __forceinline__ void lsh_head_body(
     }
     __syncthreads();                        // s_ids complete; the spilled list drained (vmcnt) and visible in L2
     MP_STAMP(stamp, 33);
-    auto ids = [&](int k, int j) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (!spill) {
-            v = *reinterpret_cast<const u32x4*>(s_ids + k * AH_SLICE + j);
-        } else {
+    // two instantiations of the tail: the LDS path carries no global load ahead of its gathers
+    float m, Z, o;
+    const u32x4 qv = *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADD / 8)) * 4);
+    float* score_h = aa.score ? aa.score + h * M : nullptr;
+    if (!spill) {
+        auto ids = [&](int k, int j) { return *reinterpret_cast<const u32x4*>(s_ids + k * AH_SLICE + j); };
+        attn_head_tail<ADD>(aa.kv + g * M * 2 * ADD, aa.kn + g * M, qv, s_rn[1], total, M, ha.K, L, rank,
+                            1 << clog, ids, s_merge, score_h, stamp, m, Z, o);
+    } else {
+        auto ids = [&](int k, int j) {
+            u32x4 v = {0u, 0u, 0u, 0u};
             const int64_t j0 = (((int64_t)k << clog) + rank) * AH_SLICE + j;
             for (int e = 0; e < 4; ++e)
                 v[e] = (j0 + e < M) ? (uint32_t)__builtin_nontemporal_load(out + j0 + e) : 0u;
-        }
-        return v;
-    };
-    float m, Z, o;
-    const u32x4 qv = *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADD / 8)) * 4);
-    attn_head_tail<ADD>(aa.kv + g * M * 2 * ADD, aa.kn + g * M, qv, s_rn[1], total, M, ha.K, L,
-                        rank, 1 << clog, ids, s_merge, aa.score ? aa.score + h * M : nullptr, stamp, m, Z, o);
+            return v;
+        };
+        attn_head_tail<ADD>(aa.kv + g * M * 2 * ADD, aa.kn + g * M, qv, s_rn[1], total, M, ha.K, L, rank,
+                            1 << clog, ids, s_merge, score_h, stamp, m, Z, o);
+    }
     if (clog == 0) {
         attn_head_finalize<ADD>(m, Z, o, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
         MP_STAMP(stamp, 39);
