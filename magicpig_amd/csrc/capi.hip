@@ -728,7 +728,7 @@ int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int 
         // head inside one workgroup cluster; the selected ids stay in LDS.  Cluster size: spread a
         // head over several CUs while there are idle ones.
         int cluster = attn->cus / BH;
-        if (cluster > 8) cluster = 8;
+        if (cluster > 8) cluster = 8;     // measured: 16 and 32 members lose more in the hand-off and in L2 plane traffic than they gain
         if (cluster > attn_slices_per_head(attn->M)) cluster = attn_slices_per_head(attn->M);
         if (cluster < 1) cluster = 1;
         if (const char* e = getenv("MP_DECODE_CLUSTER")) cluster = atoi(e) >= 1 ? atoi(e) : cluster;
