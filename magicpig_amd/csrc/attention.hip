@@ -378,7 +378,7 @@ __global__ __launch_bounds__(1024) void attn_head_kernel(
     MP_STAMP(stamp, 33);
     float m, Z, o;
     const u32x4 qv = *reinterpret_cast<const u32x4*>(query + (int64_t)h * D + (threadIdx.x % (D / 8)) * 8);
-    attn_head_tail<D>(kv + g * M * 2 * D, kn + g * M, qv, qnorm[h], nz, M, K, L, 0, 1,
+    attn_head_tail<D, 16>(kv + g * M * 2 * D, kn + g * M, qv, qnorm[h], nz, M, K, L, 0, 1,
                       ids, s_merge, score ? score + (int64_t)h * M : nullptr, stamp, m, Z, o);
     attn_head_finalize<D>(m, Z, o, out + (int64_t)h * D, mve, BH, h, head_mz);
     MP_STAMP(stamp, 39);

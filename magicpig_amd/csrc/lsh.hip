@@ -605,7 +605,7 @@ __device__ __forceinline__ void lsh_head_body(
     float* score_h = aa.score ? aa.score + h * M : nullptr;
     if (!spill) {
         auto ids = [&](int k, int j) { return *reinterpret_cast<const u32x4*>(s_ids + k * AH_SLICE + j); };
-        attn_head_tail<ADD>(aa.kv + g * M * 2 * ADD, aa.kn + g * M, qv, s_rn[1], total, M, ha.K, L, rank,
+        attn_head_tail<ADD, RT_WAVES>(aa.kv + g * M * 2 * ADD, aa.kn + g * M, qv, s_rn[1], total, M, ha.K, L, rank,
                             1 << clog, ids, s_merge, score_h, stamp, m, Z, o);
     } else {
         auto ids = [&](int k, int j) {
@@ -615,7 +615,7 @@ __device__ __forceinline__ void lsh_head_body(
                 v[e] = (j0 + e < M) ? (uint32_t)__builtin_nontemporal_load(out + j0 + e) : 0u;
             return v;
         };
-        attn_head_tail<ADD>(aa.kv + g * M * 2 * ADD, aa.kn + g * M, qv, s_rn[1], total, M, ha.K, L, rank,
+        attn_head_tail<ADD, RT_WAVES>(aa.kv + g * M * 2 * ADD, aa.kn + g * M, qv, s_rn[1], total, M, ha.K, L, rank,
                             1 << clog, ids, s_merge, score_h, stamp, m, Z, o);
     }
     if (clog == 0) {
