@@ -122,13 +122,17 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
     return v;
 }
+// Inclusive prefix sum over the 64 lanes with DPP operands (six VALU adds; the shuffle form costs
+// six ds_bpermute round trips): Hillis-Steele inside each row of 16 by row_shr 1/2/4/8 (lanes
+// shifted in from outside the row read the identity), then row_bcast:15 carries a row's total into
+// rows 1 and 3 and row_bcast:31 carries lanes 0..31's total into rows 2 and 3.
 __device__ __forceinline__ int wave_incl_scan(int v) {
-    const int l = lane_id();
-#pragma unroll
-    for (int s = 1; s < WAVE; s <<= 1) {
-        int t = __shfl_up(v, s);
-        if (l >= s) v += t;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
 

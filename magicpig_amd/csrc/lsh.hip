@@ -115,8 +115,10 @@ __device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ 
     for (int base = 0; base < NB; base += blockDim.x) {
         const int i = base + tid;
         int v = 0;
-        if (i < NB)
-            for (int w = 0; w < nw; ++w) v += s_cnt[w * NB + i];
+        if (i < NB) {
+#pragma unroll
+            for (int w = 0; w < 16; ++w) v += (w < nw) ? s_cnt[w * NB + i] : 0;   // independent LDS reads
+        }
         int total;
         __syncthreads();
         const int ex = block_excl_scan(v, s_tmp, total) + carry;
@@ -171,17 +173,21 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
         for (int base = 0; base < NB; base += blockDim.x) {
             const int i = base + tid;
             int v = 0;
-            if (i < NB)
-                for (int w = 0; w < nw; ++w) v += s_cnt[w * NB + i];
+            int cw[16];                                   // the waves' counts of bucket i: ONE batch of LDS reads
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                cw[w] = (i < NB && w < nw) ? s_cnt[w * NB + i] : 0;
+                v += cw[w];
+            }
             int total;
             __syncthreads();
             const int ex = block_excl_scan(v, s_tmp, total) + carry;
             if (i < NB) {
                 int run = ex;
-                for (int w = 0; w < nw; ++w) {
-                    const int t = s_cnt[w * NB + i];
-                    s_cnt[w * NB + i] = run;
-                    run += t;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) {
+                    if (w < nw) s_cnt[w * NB + i] = run;
+                    run += cw[w];
                 }
                 const int g = s_gbase[i];
                 s_gdelta[i] = g - ex;
