@@ -79,15 +79,56 @@ __device__ __forceinline__ void dot_settle(float& acc) { asm("s_nop 3" : "+v"(ac
 // ---------------------------------------------------------------- wave / block primitives
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
+// Wave-wide reductions: four DPP row rotations leave every lane of a 16-lane row with the row's
+// result, four v_readlane + three scalar-operand ops join the rows.  The shuffle form is six dependent
+// ds_bpermute round trips (~0.25 us on a critical path).
+template <int N>
+__device__ __forceinline__ float dpp_ror_f(float v) {
+    const int x = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x120 + N, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
-    return v;
+    v = fmaxf(v, dpp_ror_f<8>(v));
+    v = fmaxf(v, dpp_ror_f<4>(v));
+    v = fmaxf(v, dpp_ror_f<2>(v));
+    v = fmaxf(v, dpp_ror_f<1>(v));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
-    return v;
+    v += dpp_ror_f<8>(v);
+    v += dpp_ror_f<4>(v);
+    v += dpp_ror_f<2>(v);
+    v += dpp_ror_f<1>(v);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
+}
+template <int N>
+__device__ __forceinline__ double dpp_ror_d(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const int lo = (int)(uint32_t)u, hi = (int)(uint32_t)(u >> 32);
+    const uint32_t rl = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, 0x120 + N, 0xf, 0xf, true);
+    const uint32_t rh = (uint32_t)__builtin_amdgcn_update_dpp(hi, hi, 0x120 + N, 0xf, 0xf, true);
+    return __longlong_as_double((long long)((unsigned long long)rl | ((unsigned long long)rh << 32)));
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const unsigned long long u = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+    return __longlong_as_double((long long)((unsigned long long)lo | ((unsigned long long)hi << 32)));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_ror_d<8>(v);
+    v += dpp_ror_d<4>(v);
+    v += dpp_ror_d<2>(v);
+    v += dpp_ror_d<1>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 // Reductions over the 16 lanes of a DPP row (lanes 16r .. 16r+15) by row rotation: four VALU
 // instructions with a DPP operand instead of four ds_bpermute round trips; every lane of the
@@ -116,11 +157,6 @@ __device__ __forceinline__ float row16_max_nonneg(float f) {
     v = max(v, dpp_row_ror<2>(v));
     v = max(v, dpp_row_ror<1>(v));
     return __int_as_float((int)v);
-}
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
-    return v;
 }
 // Inclusive prefix sum over the 64 lanes with DPP operands (six VALU adds; the shuffle form costs
 // six ds_bpermute round trips): Hillis-Steele inside each row of 16 by row_shr 1/2/4/8 (lanes
