@@ -159,10 +159,12 @@ int mp_debug_xcd_round_robin(void);
 
 /* ---------------------------------------------------------------- one decode step of one layer
  * The device-resident equivalent of LSHSparseAttnServer.decode lines 264-300
- * (models/attnserver.py): q-hash -> batch_retrieve -> attention_wrapper with codes, results
- * and nnz kept in HBM.  q bf16 [B*H, D] device; output bf16 [B*H, D] device;
- * max_value_expsum f32 [2, B*H] device.  nnz_out (optional, device int32 [B*H]) receives the
- * per-head selected-token counts for statistics. */
+ * (models/attnserver.py): q-hash -> batch_retrieve -> attention_wrapper as ONE kernel launch
+ * (head_dim 64 or 128; other shapes and very long max_length run it as two launches): the selected
+ * ids stay on chip, while codes, results and nnz are still written to the handles' HBM buffers as
+ * by-products (get_mask / get_score keep working).  q bf16 [B*H, D] device; output bf16 [B*H, D]
+ * device; max_value_expsum f32 [2, B*H] device.  nnz_out (optional, device int32 [B*H]) receives
+ * the per-head selected-token counts for statistics. */
 int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int layer_id,
                            const uint16_t* q, uint16_t* output, float* max_value_expsum,
                            int32_t* nnz_out, mp_stream_t stream);
