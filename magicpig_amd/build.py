@@ -40,8 +40,8 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"),
-               os.path.join(os.path.dirname(HERE), "include", "magicpig_hip.h")]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "magicpig_hip.h"))
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
