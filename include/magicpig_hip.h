@@ -169,6 +169,18 @@ int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int 
                            const uint16_t* q, uint16_t* output, float* max_value_expsum,
                            int32_t* nnz_out, mp_stream_t stream);
 
+/* The same launch with the static window of the layer folded in (models/attnserver.py:281-308, after
+ * the step's k, v have been appended with mp_attn_append): `window` is a second KV store holding the
+ * sink + local + generated tokens, window_len int32 [B*H] (device) the number of its rows that are
+ * live for each head.  Exact attention over those rows joins the softmax of the sampled tokens, which
+ * is what BatchDecodeWithPagedKVCacheWrapper.run_return_lse (:293-296) followed by
+ * flashinfer.merge_state (:305-308) computes; output is the merged hidden state, max_value_expsum[1]
+ * the base-2 LSE over both parts.  MP_ERR_UNSUPPORTED when the one-launch form does not exist for the
+ * shape (then: mp_attn_full on the window + mp_decode_sparse_layer + mp_merge_state). */
+int mp_decode_layer_window(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn_t* window,
+                           int layer_id, const uint16_t* q, const int32_t* window_len, uint16_t* output,
+                           float* max_value_expsum, int32_t* nnz_out, mp_stream_t stream);
+
 /* ---------------------------------------------------------------- LSE merge
  * Replaces flashinfer.merge_state as called at models/attnserver.py:308 (base-2 LSEs):
  * v = (2^sa va + 2^sb vb) / 2^s, s = log2(2^sa + 2^sb).  va, vb, v bf16 [R, D]; sa, sb, s f32 [R]

@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libmagicpig_hip.so")
 
 MP_OK = 0
+ERR_UNSUPPORTED = 5
 MEM_HOST, MEM_DEVICE = 0, 1
 DTYPE_BF16, DTYPE_F32 = 0, 1
 
@@ -77,6 +78,7 @@ def lib() -> C.CDLL:
         "mp_attn_get_key_norm": ([p, i32, pp], i32),
         "mp_attn_get_score": ([p, pp, p], i32),
         "mp_decode_sparse_layer": ([p, p, p, i32, p, p, p, p, p], i32),
+        "mp_decode_layer_window": ([p, p, p, p, i32, p, p, p, p, p, p], i32),
         "mp_merge_state": ([p, p, p, p, i32, i32, p, p, p], i32),
     }
     for name, (args, res) in sig.items():

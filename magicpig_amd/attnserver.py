@@ -155,6 +155,31 @@ class LSHSparseAttnServer:
                                sparse_out, sparse_lse)                                 # :302-308
         return hidden.reshape(B, 1, H * D)
 
+    def decode_full_fused(self, query_states: torch.Tensor, key_states: torch.Tensor,
+                          value_states: torch.Tensor, layer_idx: int) -> torch.Tensor:
+        """decode_full in two launches instead of four: the append, then ONE kernel in which the exact
+        attention over the static window joins the softmax of the LSH-sampled tokens
+        (mp_decode_layer_window) -- no window partial, no merge_state.  Falls back to decode_full when
+        the one-launch form does not exist for the shape."""
+        B, H, Hkv, D = self.batch_size, self.num_attention_heads, self.num_key_value_heads, self.head_dim
+        q = query_states.reshape(B * H, D)
+        L.expect(q, torch.bfloat16, (B * H, D), "query_states")
+        k = (key_states.reshape(B, Hkv, 1, D) - self.avg_k[layer_idx]).reshape(B, Hkv, D).contiguous()
+        v = value_states.reshape(B, Hkv, D).contiguous()
+        self.window_server.append(layer_idx, k, v, self.kv_last_page_len - 1)
+        rc = L.lib().mp_decode_layer_window(
+            self.hasher._h, self.lsh_retriever._h, self.attn_server._h, self.window_server._h, layer_idx,
+            L.ptr(q), L.ptr(self.window_nnz), L.ptr(self.output), L.ptr(self.max_value_expsum),
+            L.ptr(self.nnz if self.collect_nnz else None), L.current_stream(q))
+        if rc == L.ERR_UNSUPPORTED:
+            self.window_server.full_attention(layer_idx, self.window_out, self.window_mve, q, self.window_nnz)
+            sparse_out, sparse_lse = self.decode(query_states, layer_idx)
+            hidden, _ = self.merge(self.window_out.view(B, H, D), self.window_mve[1].view(B, H),
+                                   sparse_out, sparse_lse)
+            return hidden.reshape(B, 1, H * D)
+        L.check(rc)
+        return self.output.view(B, 1, H * D)
+
     @staticmethod
     def merge(gpu_hidden_states, gpu_lse, cpu_hidden_states, cpu_lse):
         """flashinfer.merge_state as used at models/attnserver.py:308 (base-2 LSEs)."""

@@ -46,8 +46,6 @@ constexpr int AH_SLICE = 32;   // entries of the index list per wave step
 // AH_SLICE = 32 consecutive entries); wave w takes k = w, w + NW, ...
 // IDS: callable (int k, int j) -> u32x4 holding entries j .. j+3 of the workgroup's k-th slice
 // (entries past nz are never used, but the call must not fault).
-// On return threads tid < D hold the workgroup's merged state: m (max logit), Z (sum of exp(z - m))
-// and o = sum_j exp(z_j - m) V[j][tid]; m = -inf, Z = 0 when the workgroup had no slice.
 //
 // A step gathers the K row AND the V row of 32 tokens (64 VGPRs in flight, all that a lane of a
 // 1024-thread workgroup can spare): LPR = D/8 lanes cover a row, a load instruction fetches
@@ -56,15 +54,35 @@ constexpr int AH_SLICE = 32;   // entries of the index list per wave step
 // of the UPS partial dot products over the LPR lanes of a row group ends one step early (st = 2) and
 // finishes with an all-reduce, so lanes c and c^1 both hold the score of slot r*UPS + (c >> 1): the
 // importance transform runs twice per token (VALU is idle anyway), sums count even lanes only.
-template <int D, int NW, typename IDS>   // NW: upper bound of the workgroup's waves (blockDim.x / 64 <= NW)
-__device__ __forceinline__ void attn_head_tail(
+
+// a wave's running softmax state over the slices it has folded in
+struct AhState {
+    float m, l, o0, o1;   // max logit, sum of exp(z - m), this lane's <= 2 elements of sum exp(z - m) V
+    int d0;               // first element of o[] this lane holds
+};
+__device__ __forceinline__ AhState ah_state_init(int lane, int lpr) {
+    AhState st;
+    st.m = -INFINITY;
+    st.l = 0.f;
+    st.o0 = 0.f;
+    st.o1 = 0.f;
+    st.d0 = (lane % lpr) * 8;
+    return st;
+}
+
+// Fold the workgroup's slices of one index list into the waves' states.  DENSE: the list is
+// 0 .. nz-1 itself and the logit is q.k / sqrt(D) with no importance transform (full_attention,
+// sparse_attention.cc:988-1037; the static window of models/attnserver.py:293-296) -- `ids`, `kn_g`,
+// `qn_h`, K and L are not used.
+template <int D, int NW, bool DENSE, typename IDS>   // NW: upper bound of the workgroup's waves (blockDim.x / 64 <= NW)
+__device__ __forceinline__ void attn_head_fold(
+    AhState& st,
     const uint16_t* __restrict__ kv_g,   // kv rows of this head's kv group: [M][2][D]
     const float* __restrict__ kn_g,      // key norms of the group: [M]
     const u32x4 qv,                      // this lane's 8 query elements: bf16 q[(lane % LPR)*8 ..]
     float qn_h, int nz, int64_t M, int K, int L, int slice0, int slice_stride, IDS&& ids,
-    float* s_merge,                      // LDS, attn_head_lds_floats(NW, D)
     float* __restrict__ score_h,         // [M] transformed logits (nullable)
-    unsigned long long* __restrict__ stamp, float& m_out, float& Z_out, float& o_out) {
+    unsigned long long* __restrict__ stamp) {
     constexpr int LPR = D / 8;           // lanes per row (16 B each)
     constexpr int UPS = LPR / 2;         // load steps per slice
     constexpr int VPL = (LPR == 16) ? 2 : 1;
@@ -74,15 +92,15 @@ __device__ __forceinline__ void attn_head_tail(
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
     const uint16_t* kvc = kv_g + c * 8;
 
-    float m_run = -INFINITY, l_run = 0.f, o_run[2] = {0.f, 0.f};
-    int d0 = c * 8;
     for (int k = wave;; k += nw) {
         const int64_t s = (int64_t)slice0 + (int64_t)slice_stride * k;
         if (s * AH_SLICE >= nz) break;
         const int jb = (int)s * AH_SLICE;
         u32x4 idv[UPS / 4];
+        if (!DENSE) {
 #pragma unroll
-        for (int v = 0; v < UPS / 4; ++v) idv[v] = ids(k, r * UPS + v * 4);
+            for (int v = 0; v < UPS / 4; ++v) idv[v] = ids(k, r * UPS + v * 4);
+        }
         const int slot_my = r * UPS + (c >> 1);
         const int j_my = jb + slot_my;
         const bool valid_my = j_my < nz;
@@ -91,13 +109,13 @@ __device__ __forceinline__ void attn_head_tail(
         // first token, which is always a selected one: their weight is forced to 0, and every load
         // stays unconditional -- loads under a branch would make the compiler drain vmcnt at every
         // join.  Rows are read once and never reused: non-temporal loads.
-        const int id_first = __builtin_amdgcn_readfirstlane((int)idv[0][0]);
+        const int id_first = DENSE ? jb : __builtin_amdgcn_readfirstlane((int)idv[0][0]);
         const int id_safe = (id_first >= 0 && (int64_t)id_first < M) ? id_first : 0;
         u32x4 kreg[UPS], vreg[UPS];
         int id_my = 0;
 #pragma unroll
         for (int u = 0; u < UPS; ++u) {
-            int id_u = (int)idv[u / 4][u % 4];
+            int id_u = DENSE ? (jb + r * UPS + u) : (int)idv[u / 4][u % 4];
             const bool valid_u = (jb + r * UPS + u) < nz;
             if (!valid_u || id_u < 0 || (int64_t)id_u >= M) id_u = id_safe;
             if (u == (c >> 1)) id_my = id_u;
@@ -105,8 +123,9 @@ __device__ __forceinline__ void attn_head_tail(
             kreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row));
             vreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row + D));
         }
-        const float kn_my = kn_g[id_my];
-        if (k == wave) MP_STAMP(stamp, 34);
+        float kn_my = 1.f;
+        if (!DENSE) kn_my = kn_g[id_my];
+        if (!DENSE && k == wave) MP_STAMP(stamp, 34);
 
         // ---- q . K partials, reduce-scatter over the row group down to pairs, then all-reduce
         float part[UPS];
@@ -118,36 +137,40 @@ __device__ __forceinline__ void attn_head_tail(
             part[u] = a;
         }
 #pragma unroll
-        for (int st = LPR / 2; st >= 2; st >>= 1) {
-            const bool upper = (c & st) != 0;
+        for (int stp = LPR / 2; stp >= 2; stp >>= 1) {
+            const bool upper = (c & stp) != 0;
 #pragma unroll
-            for (int u = 0; u < st / 2; ++u) {
-                const float send = upper ? part[u] : part[u + st / 2];
-                const float keep = upper ? part[u + st / 2] : part[u];
-                part[u] = keep + __shfl_xor(send, st);
+            for (int u = 0; u < stp / 2; ++u) {
+                const float send = upper ? part[u] : part[u + stp / 2];
+                const float keep = upper ? part[u + stp / 2] : part[u];
+                part[u] = keep + __shfl_xor(send, stp);
             }
         }
         const float sc = part[0] + __shfl_xor(part[0], 1);   // = q . K[id_my] on lanes c and c^1
-        if (k == wave) MP_STAMP(stamp, 35);
+        if (!DENSE && k == wave) MP_STAMP(stamp, 35);
 
         // ---- importance-sampling transform (transform_kernel, sparse_attention.cc:164-184);
         // cancellation-free weight and cos clamp as in attn_sparse_kernel
         float z = -INFINITY;
         if (valid_my) {
-            float cs = sc / (qn_h * kn_my);
-            cs = fminf(1.f, fmaxf(-1.f, cs));
-            const float theta = acosf(cs);
-            const float proba = 1.f - theta * 0.31830988618379067f;
-            const float p = powi_u(proba, K);
-            const float lm1 = (float)(L - 1);
-            const float w = -expm1f(lm1 * log1pf(-p) + log1pf(lm1 * p));
-            z = sc * inv_sqrt_d - logf(w + 1e-4f);
+            if (DENSE) {
+                z = sc * inv_sqrt_d;
+            } else {
+                float cs = sc / (qn_h * kn_my);
+                cs = fminf(1.f, fmaxf(-1.f, cs));
+                const float theta = acosf(cs);
+                const float proba = 1.f - theta * 0.31830988618379067f;
+                const float p = powi_u(proba, K);
+                const float lm1 = (float)(L - 1);
+                const float w = -expm1f(lm1 * log1pf(-p) + log1pf(lm1 * p));
+                z = sc * inv_sqrt_d - logf(w + 1e-4f);
+            }
             if (score_h != nullptr && (c & 1) == 0) score_h[j_my] = z;
         }
         const float m_w = wave_max(z);
         const float p_my = valid_my ? __expf(z - m_w) : 0.f;    // slice non-empty => m_w finite
         const float l_w = wave_sum((c & 1) ? 0.f : p_my);
-        if (k == wave) MP_STAMP(stamp, 36);
+        if (!DENSE && k == wave) MP_STAMP(stamp, 36);
 
         // ---- P . V
         float acc[8];
@@ -166,25 +189,33 @@ __device__ __forceinline__ void attn_head_tail(
         rs_step_h<8, 32>(acc, lane, doff);
         rs_step_h<4, 16>(acc, lane, doff);
         if (LPR == 8) rs_step_h<2, 8>(acc, lane, doff);
-        d0 = c * 8 + doff;
-        if (k == wave) MP_STAMP(stamp, 37);
+        st.d0 = c * 8 + doff;
+        if (!DENSE && k == wave) MP_STAMP(stamp, 37);
 
         // ---- fold the slice into the wave's running state
-        const float m_new = fmaxf(m_run, m_w);
-        const float a = __expf(m_run - m_new), b = __expf(m_w - m_new);   // exp(-inf) = 0 on the first slice
-        l_run = fmaf(a, l_run, b * l_w);
-        o_run[0] = fmaf(a, o_run[0], b * acc[0]);
-        if (VPL == 2) o_run[1] = fmaf(a, o_run[1], b * acc[1]);
-        m_run = m_new;
+        const float m_new = fmaxf(st.m, m_w);
+        const float a = __expf(st.m - m_new), b = __expf(m_w - m_new);   // exp(-inf) = 0 on the first slice
+        st.l = fmaf(a, st.l, b * l_w);
+        st.o0 = fmaf(a, st.o0, b * acc[0]);
+        if (VPL == 2) st.o1 = fmaf(a, st.o1, b * acc[1]);
+        st.m = m_new;
     }
+}
 
-    // ---- the waves' states meet in LDS
+// The waves' states meet in LDS (one barrier).  On return threads tid < D hold the workgroup's
+// merged state: m (max logit), Z (sum of exp(z - m)) and o = sum_j exp(z_j - m) V[j][tid];
+// m = -inf, Z = 0 when the workgroup had no slice.
+template <int D, int NW>
+__device__ __forceinline__ void attn_head_merge(const AhState& st, float* s_merge, float& m_out,
+                                                float& Z_out, float& o_out) {
+    constexpr int VPL = (D / 8 == 16) ? 2 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     float* mine = s_merge + wave * (D + 2);
-    mine[d0] = o_run[0];
-    if (VPL == 2) mine[d0 + 1] = o_run[1];
+    mine[st.d0] = st.o0;
+    if (VPL == 2) mine[st.d0 + 1] = st.o1;
     if (lane == 0) {
-        mine[D] = m_run;
-        mine[D + 1] = l_run;
+        mine[D] = st.m;
+        mine[D + 1] = st.l;
     }
     __syncthreads();
     m_out = -INFINITY;
@@ -217,6 +248,18 @@ __device__ __forceinline__ void attn_head_tail(
         Z_out = Z;
         o_out = o;
     }
+}
+
+// fold the slices of ONE sparse list, then merge (attn_head_kernel)
+template <int D, int NW, typename IDS>
+__device__ __forceinline__ void attn_head_tail(
+    const uint16_t* __restrict__ kv_g, const float* __restrict__ kn_g, const u32x4 qv, float qn_h, int nz,
+    int64_t M, int K, int L, int slice0, int slice_stride, IDS&& ids, float* s_merge,
+    float* __restrict__ score_h, unsigned long long* __restrict__ stamp, float& m_out, float& Z_out,
+    float& o_out) {
+    AhState st = ah_state_init(threadIdx.x & 63, D / 8);
+    attn_head_fold<D, NW, false>(st, kv_g, kn_g, qv, qn_h, nz, M, K, L, slice0, slice_stride, ids, score_h, stamp);
+    attn_head_merge<D, NW>(st, s_merge, m_out, Z_out, o_out);
 }
 
 // threads tid < D: out = o / Z as bf16 (RNE); max_value_expsum[0] = m*log2e, [1] = log2 Z + m*log2e

@@ -24,8 +24,8 @@ bool lsh_decode_supported(int64_t M, int L, int D);
 bool xcd_round_robin_verified();
 hipError_t launch_lsh_decode(const int2*, const int32_t*, const uint16_t*, const uint16_t*, const float*, int,
                              int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
-                             float*, float2*, int*, uint16_t*, float*, float2*, float*, int, int, bool, int,
-                             int, int, int, int64_t, hipStream_t);
+                             float*, float2*, int*, uint16_t*, float*, float2*, float*, int, int, bool,
+                             const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int2*,
                            int32_t*, int*, hipStream_t);
 hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int2*, int32_t*, int*,
@@ -706,24 +706,34 @@ int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream) {
 
 // =================================================================== fused decode step
 
-int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int layer_id,
-                           const uint16_t* q, uint16_t* output, float* max_value_expsum,
-                           int32_t* nnz_out, mp_stream_t stream) {
-    MP_REQUIRE(s && s->Wt, MP_ERR_STATE, "mp_decode_sparse_layer: SimHash planes not set");
-    MP_REQUIRE(lsh && lsh->allocated && attn && attn->allocated, MP_ERR_STATE,
-               "mp_decode_sparse_layer: handles not allocated");
-    MP_REQUIRE(q && output && max_value_expsum, MP_ERR_INVALID, "mp_decode_sparse_layer: null argument");
+// shared by mp_decode_sparse_layer (win == nullptr) and mp_decode_layer_window
+static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn_t* win, int layer_id,
+                        const uint16_t* q, const int32_t* win_len, uint16_t* output, float* max_value_expsum,
+                        int32_t* nnz_out, hipStream_t st, const char* who) {
+    const std::string w(who);
+    MP_REQUIRE(s && s->Wt, MP_ERR_STATE, w + ": SimHash planes not set");
+    MP_REQUIRE(lsh && lsh->allocated && attn && attn->allocated, MP_ERR_STATE, w + ": handles not allocated");
+    MP_REQUIRE(q && output && max_value_expsum, MP_ERR_INVALID, w + ": null argument");
     MP_REQUIRE(lsh->B == attn->B && lsh->H == attn->H && lsh->Hkv == attn->Hkv && lsh->M == attn->M &&
                    s->K == lsh->K && s->L == lsh->L && s->D == attn->D,
-               MP_ERR_INVALID, "mp_decode_sparse_layer: handles disagree on B/H/Hkv/M/K/L/D");
+               MP_ERR_INVALID, w + ": handles disagree on B/H/Hkv/M/K/L/D");
     MP_REQUIRE(layer_id >= 0 && layer_id < lsh->layers && layer_id < attn->layers, MP_ERR_INVALID,
-               "mp_decode_sparse_layer: layer_id out of range");
-    hipStream_t st = (hipStream_t)stream;
+               w + ": layer_id out of range");
     const int BH = lsh->B * lsh->H;
     lsh->lastq = lsh->codes;
     lsh->last_layer = layer_id;
     static const bool two_launch = getenv("MP_DECODE_TWO_LAUNCH") != nullptr;   // A/B switch
-    if (!two_launch && lsh_decode_supported(lsh->M, lsh->L, s->D)) {
+    const bool fused = !two_launch && lsh_decode_supported(lsh->M, lsh->L, s->D);
+    if (win != nullptr) {
+        MP_REQUIRE(win->allocated && win_len, MP_ERR_INVALID, w + ": window store not allocated / null win_len");
+        MP_REQUIRE(win->B == attn->B && win->H == attn->H && win->Hkv == attn->Hkv && win->D == attn->D &&
+                       layer_id < win->layers,
+                   MP_ERR_INVALID, w + ": window store disagrees on B/H/Hkv/D/layers");
+        MP_REQUIRE(fused, MP_ERR_UNSUPPORTED,
+                   w + ": the one-launch form is not available for this shape; use full_attention + "
+                       "mp_decode_sparse_layer + mp_merge_state");
+    }
+    if (fused) {
         // a-1 .. a-12 (models/attnserver.py:264-300) in ONE launch: hash -> retrieve -> attention of a
         // head inside one workgroup cluster; the selected ids stay in LDS.  Cluster size: spread a
         // head over several CUs while there are idle ones.
@@ -736,8 +746,9 @@ int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int 
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
                                        attn->head_cnt, output, max_value_expsum, attn->head_mz, attn->score,
-                                       attn_slices_per_head(attn->M), cluster, attn->xcd_rr, BH, lsh->G, lsh->L,
-                                       lsh->NB, lsh->M, st));
+                                       attn_slices_per_head(attn->M), cluster, attn->xcd_rr,
+                                       win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
+                                       lsh->L, lsh->NB, lsh->M, st));
         attn->lastz = lsh->nnz;
         attn->score_state = 1;
     } else {
@@ -753,6 +764,21 @@ int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int 
     if (nnz_out)
         MP_HIP_CHECK(hipMemcpyAsync(nnz_out, lsh->nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));
     return MP_OK;
+}
+
+int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int layer_id,
+                           const uint16_t* q, uint16_t* output, float* max_value_expsum,
+                           int32_t* nnz_out, mp_stream_t stream) {
+    return decode_layer(s, lsh, attn, nullptr, layer_id, q, nullptr, output, max_value_expsum, nnz_out,
+                        (hipStream_t)stream, "mp_decode_sparse_layer");
+}
+
+int mp_decode_layer_window(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn_t* window,
+                           int layer_id, const uint16_t* q, const int32_t* window_len, uint16_t* output,
+                           float* max_value_expsum, int32_t* nnz_out, mp_stream_t stream) {
+    MP_REQUIRE(window != nullptr, MP_ERR_INVALID, "mp_decode_layer_window: null window store");
+    return decode_layer(s, lsh, attn, window, layer_id, q, window_len, output, max_value_expsum, nnz_out,
+                        (hipStream_t)stream, "mp_decode_layer_window");
 }
 
 // =================================================================== LSE merge

@@ -320,9 +320,16 @@ struct AttnArgs {
     float* score;            // [BH][M] (nullable)
     int BH, maxs, cap, cluster_log2;   // cap: ids of the LDS stage (multiple of AH_SLICE)
     int same_xcd;            // the members of a cluster share one XCD (and its L2): verified by the host
+    // optional static window (models/attnserver.py:281-308): exact attention over the first win_len[h]
+    // rows of a second KV store joins the same softmax, which IS flashinfer.merge_state of the two parts
+    const uint16_t* win_kv;  // [B*Hkv][win_M][2][D] or nullptr
+    const int32_t* win_len;  // [BH]
+    int64_t win_M;
 };
 
-template <bool HASH, int CH, int AD>   // CH = min(16, D / 8): plane chunks kept in registers (HASH only)
+template <bool HASH, int CH, int AD, bool WIN>   // CH = min(16, D / 8): plane chunks kept in registers (HASH only);
+                                                 // WIN: fold the static window in (its own instantiation, so the
+                                                 // plain decode kernel carries none of its code)
 __device__ __forceinline__ void lsh_head_body(
     const int2* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
@@ -599,30 +606,53 @@ __device__ __forceinline__ void lsh_head_body(
     // ------------------------------------------------------------ fused sparse attention of head h
     constexpr int ADD = AD > 0 ? AD : 64;
     uint16_t* out_h = aa.out + h * ADD;
-    if (total == 0) {                       // every member sees the same list
+    int wlen = 0;
+    if (WIN && aa.win_kv != nullptr) {
+        wlen = aa.win_len[h];
+        wlen = wlen < 0 ? 0 : (wlen > aa.win_M ? (int)aa.win_M : wlen);
+    }
+    if (total == 0 && wlen == 0) {          // every member sees the same list
         if (lead) attn_head_empty<ADD>(out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
         return;
     }
     __syncthreads();                        // s_ids complete; the spilled list drained (vmcnt) and visible in L2
     MP_STAMP(stamp, 33);
-    // two instantiations of the tail: the LDS path carries no global load ahead of its gathers
+    // two instantiations of the sparse fold: the LDS path carries no global load ahead of its gathers
     float m, Z, o;
     const u32x4 qv = *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADD / 8)) * 4);
     float* score_h = aa.score ? aa.score + h * M : nullptr;
-    if (!spill) {
-        auto ids = [&](int k, int j) { return *reinterpret_cast<const u32x4*>(s_ids + k * AH_SLICE + j); };
-        attn_head_tail<ADD, RT_WAVES>(aa.kv + g * M * 2 * ADD, aa.kn + g * M, qv, s_rn[1], total, M, ha.K, L, rank,
-                            1 << clog, ids, s_merge, score_h, stamp, m, Z, o);
+    const uint16_t* kv_g = aa.kv + g * M * 2 * ADD;
+    const float* kn_g = aa.kn + g * M;
+    auto ids_lds = [&](int k, int j) { return *reinterpret_cast<const u32x4*>(s_ids + k * AH_SLICE + j); };
+    auto ids_hbm = [&](int k, int j) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        const int64_t j0 = (((int64_t)k << clog) + rank) * AH_SLICE + j;
+        for (int e = 0; e < 4; ++e)
+            v[e] = (j0 + e < M) ? (uint32_t)__builtin_nontemporal_load(out + j0 + e) : 0u;
+        return v;
+    };
+    if (!WIN) {                             // fold + merge as one straight path per id source
+        if (!spill)
+            attn_head_tail<ADD, RT_WAVES>(kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, rank, 1 << clog, ids_lds,
+                                          s_merge, score_h, stamp, m, Z, o);
+        else
+            attn_head_tail<ADD, RT_WAVES>(kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, rank, 1 << clog, ids_hbm,
+                                          s_merge, score_h, stamp, m, Z, o);
     } else {
-        auto ids = [&](int k, int j) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            const int64_t j0 = (((int64_t)k << clog) + rank) * AH_SLICE + j;
-            for (int e = 0; e < 4; ++e)
-                v[e] = (j0 + e < M) ? (uint32_t)__builtin_nontemporal_load(out + j0 + e) : 0u;
-            return v;
-        };
-        attn_head_tail<ADD, RT_WAVES>(aa.kv + g * M * 2 * ADD, aa.kn + g * M, qv, s_rn[1], total, M, ha.K, L, rank,
-                            1 << clog, ids, s_merge, score_h, stamp, m, Z, o);
+        AhState st = ah_state_init(lane, ADD / 8);
+        if (!spill)
+            attn_head_fold<ADD, RT_WAVES, false>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, rank, 1 << clog,
+                                                 ids_lds, score_h, stamp);
+        else
+            attn_head_fold<ADD, RT_WAVES, false>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, rank, 1 << clog,
+                                                 ids_hbm, score_h, stamp);
+        if (wlen > 0) {                     // the static window: dense slices (k runs from `wave` again, so the
+                                            // waves that got no sparse slice of this member are served first)
+            auto none = [](int, int) { return u32x4{0u, 0u, 0u, 0u}; };
+            attn_head_fold<ADD, RT_WAVES, true>(st, aa.win_kv + g * aa.win_M * 2 * ADD, nullptr, qv, 1.f, wlen,
+                                                aa.win_M, 0, 0, rank, 1 << clog, none, nullptr, stamp);
+        }
+        attn_head_merge<ADD, RT_WAVES>(st, s_merge, m, Z, o);
     }
     if (clog == 0) {
         attn_head_finalize<ADD>(m, Z, o, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
@@ -733,17 +763,17 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
     int G, int L, int NB, int64_t M, int words, int Lpad, HashArgs ha,
     unsigned long long* __restrict__ stamp) {
     const AttnArgs aa = {};
-    lsh_head_body<HASH, CH, 0>(bounds, table, query, results, nnz, G, L, NB, M, words, Lpad, ha, aa, stamp);
+    lsh_head_body<HASH, CH, 0, false>(bounds, table, query, results, nnz, G, L, NB, M, words, Lpad, ha, aa, stamp);
 }
 
 // the whole sparse layer of models/attnserver.py:264-300: hash -> retrieve -> attention
-template <int CH, int AD>
+template <int CH, int AD, bool WIN>
 __global__ __launch_bounds__(RT_THREADS) void lsh_decode_kernel(
     const int2* __restrict__ bounds, const int32_t* __restrict__ table,
     int32_t* __restrict__ results, int32_t* __restrict__ nnz,
     int G, int L, int NB, int64_t M, int words, int Lpad, HashArgs ha, AttnArgs aa,
     unsigned long long* __restrict__ stamp) {
-    lsh_head_body<true, CH, AD>(bounds, table, nullptr, results, nnz, G, L, NB, M, words, Lpad, ha, aa, stamp);
+    lsh_head_body<true, CH, AD, WIN>(bounds, table, nullptr, results, nnz, G, L, NB, M, words, Lpad, ha, aa, stamp);
 }
 
 // ---------------------------------------------------------------- LSH::get_mask (debug view)
@@ -884,8 +914,10 @@ static hipError_t retrieve_attr_once() {
     const void* fns[] = {reinterpret_cast<const void*>(lsh_retrieve_kernel<false, 16>),
                          reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 16>),
                          reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 8>),
-                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128>),
-                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64>)};
+                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, false>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, false>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, true>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, true>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -941,7 +973,8 @@ hipError_t launch_lsh_decode(const int2* bounds, const int32_t* table, const uin
                              int32_t* codes_out, float* qnorm_out, int32_t* results, int32_t* nnz,
                              const uint16_t* kv, const float* kn, float* part_o, float2* part_ml,
                              int* head_cnt, uint16_t* out, float* mve, float2* head_mz, float* score,
-                             int maxs, int cluster, bool same_xcd, int BH, int G, int L, int NB, int64_t M,
+                             int maxs, int cluster, bool same_xcd, const uint16_t* win_kv,
+                             const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
                              hipStream_t st) {
     const int words = (int)((M + 31) / 32);
     const int Lpad = (L + 63) & ~63;
@@ -951,18 +984,21 @@ hipError_t launch_lsh_decode(const int2* bounds, const int32_t* table, const uin
     while ((2 << clog) <= cluster && clog < 3) ++clog;
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
     AttnArgs aa = {kv, kn, part_o, part_ml, head_cnt, out, mve, head_mz, score, BH, maxs, DECODE_ID_CAP, clog,
-                   (same_xcd && clog > 0 && BH % 8 == 0) ? 1 : 0};
+                   (same_xcd && clog > 0 && BH % 8 == 0) ? 1 : 0, win_kv, win_len, win_M};
     const dim3 grid((unsigned)BH << clog);
     const size_t lds = decode_lds_bytes(M, L, D);
-    if (D == 128)
-        hipLaunchKernelGGL((lsh_decode_kernel<16, 128>), grid, dim3(RT_THREADS), lds, st, bounds, table,
-                           results, nnz, G, L, NB, M, words, Lpad, ha, aa, g_stamp);
-    else if (D == 64)
-        hipLaunchKernelGGL((lsh_decode_kernel<8, 64>), grid, dim3(RT_THREADS), lds, st, bounds, table,
-                           results, nnz, G, L, NB, M, words, Lpad, ha, aa, g_stamp);
-    else
-        return hipErrorInvalidValue;
-    return hipGetLastError();
+#define MP_DECODE_CASE(DD, CHH, WW)                                                                         \
+    if (D == DD && (win_kv != nullptr) == WW) {                                                             \
+        hipLaunchKernelGGL((lsh_decode_kernel<CHH, DD, WW>), grid, dim3(RT_THREADS), lds, st, bounds, table, \
+                           results, nnz, G, L, NB, M, words, Lpad, ha, aa, g_stamp);                        \
+        return hipGetLastError();                                                                           \
+    }
+    MP_DECODE_CASE(128, 16, false)
+    MP_DECODE_CASE(128, 16, true)
+    MP_DECODE_CASE(64, 8, false)
+    MP_DECODE_CASE(64, 8, true)
+#undef MP_DECODE_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_lsh_mask(const int2* bounds, const int32_t* table, const int32_t* query,

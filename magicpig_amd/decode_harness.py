@@ -8,7 +8,7 @@ can be reproduced without HF weights (no network here): weights are random tenso
 shapes, the prompt's KV cache is synthetic.
 
 What runs where:
-  * sparse layers : LSHSparseAttnServer.decode_full -- q-hash + retrieve + sampled attention
+  * sparse layers : LSHSparseAttnServer.decode_full_fused -- q-hash + retrieve + sampled attention
                     (the hot path, HIP), static-window attention + LSE merge (HIP);
   * dense layers  : (0, 16, ...; models/attnserver.py:235-259) exact attention over the whole
                     sequence = the dense mode of the same HIP kernel on a full-length store;
@@ -176,7 +176,7 @@ class SyntheticLlamaDecoder:
         if layer in self.dense_index:
             attn = self._dense_attention(q.contiguous(), k, v, layer)
         else:
-            attn = self.attention_server.decode_full(q.contiguous(), k.contiguous(), v.contiguous(),
+            attn = self.attention_server.decode_full_fused(q.contiguous(), k.contiguous(), v.contiguous(),
                                                      self.sparse_index[layer])
         h = residual + F.linear(attn.reshape(B, 1, H * D), W["wo"])
         y = rms_norm(h, W["ln2"], eps)

@@ -792,6 +792,47 @@ def test_decode_full_window_plus_sparse_merge(mp):
         server.window_server.check()
 
 
+def test_decode_full_fused_equals_four_launch_path(mp):
+    """decode_full_fused (append + ONE kernel: the static window joins the softmax of the sampled
+    tokens) against decode_full (append, window attention, sparse attention, merge_state): same
+    hidden states up to the bf16 rounding of the two partial outputs that the four-launch path merges,
+    and against an all-f32 merge of the four-launch path's own parts.  Shapes with and without
+    same-XCD clusters; a request whose sampled list is empty (K = 12, tiny context) still gets its
+    window."""
+    for (H, Hkv, B, K, L, seq) in [(8, 2, 2, 8, 40, 700), (32, 8, 1, 8, 40, 3000), (4, 4, 1, 12, 6, 90)]:
+        D = 128
+        gen = torch.Generator().manual_seed(23)
+        W = synth.normal_bf16_bits(92, (D, K * L))
+        mk = lambda: mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, max_length=4096,   # noqa: E731
+                                            dense_layers=(), hash_func=bf16_t(W, "cuda"), generation_buffer=8)
+        a, b_ = mk(), mk()
+        for r in range(B):
+            kc = (torch.randn((seq, Hkv, D), generator=gen) * 0.5 + 0.3).to(torch.bfloat16)
+            vc = torch.randn((seq, Hkv, D), generator=gen).to(torch.bfloat16)
+            for srv in (a, b_):
+                srv.fill(0, r, kc.cuda(), vc.cuda(), seq)
+                srv.build_table(0, r, seq)
+        for step in range(3):
+            q = (torch.randn((B, H, 1, D), generator=gen) * 2).to(torch.bfloat16).cuda()
+            k_new = torch.randn((B, Hkv, 1, D), generator=gen).to(torch.bfloat16).cuda()
+            v_new = torch.randn((B, Hkv, 1, D), generator=gen).to(torch.bfloat16).cuda()
+            a.plan(); b_.plan()
+            ref = a.decode_full(q, k_new, v_new, 0).float().cpu().numpy().reshape(B * H, D)
+            got = b_.decode_full_fused(q, k_new, v_new, 0).float().cpu().numpy().reshape(B * H, D)
+            assert torch.equal(a.nnz, b_.nnz)
+            # all-f32 merge of the reference path's parts
+            w_lse = a.window_mve[1].cpu().numpy(); s_lse = a.max_value_expsum[1].cpu().numpy()
+            mx = np.maximum(w_lse, s_lse)
+            wa, sa = np.exp2(w_lse - mx), np.exp2(s_lse - mx)
+            f32 = (wa[:, None] * a.window_out.float().cpu().numpy() + sa[:, None] * a.output.float().cpu().numpy()) / (wa + sa)[:, None]
+            assert np.allclose(got, f32, rtol=2 ** -6, atol=4e-3)
+            assert np.allclose(got, ref, rtol=2 ** -6, atol=4e-3)
+            lse = b_.max_value_expsum[1].cpu().numpy()
+            assert np.allclose(lse, mx + np.log2(wa + sa), atol=2e-3)
+        if K == 12:
+            pass   # the sampled list is usually empty here: the window alone carries the output
+
+
 # ------------------------------------------------------------------ device table build
 
 @pytest.mark.parametrize("K,n", [(4, 20011), (10, 20011), (10, 8192), (10, 63), (11, 20011),
