@@ -625,6 +625,38 @@ def test_fused_decode_cluster_handoff_is_deterministic(mp, B, H, Hkv):
         assert np.allclose(l1.reshape(-1).cpu().numpy()[live], mve[1].cpu().numpy()[live], atol=2e-3)
 
 
+@pytest.mark.parametrize("B,H,Hkv,D,K,L,n,M", [
+    (1, 4, 2, 64, 4, 1100, 600, 640),        # more tables than threads in a workgroup, head_dim 64
+    (2, 8, 8, 128, 15, 12, 3000, 3001),      # widest codes, odd max_length, no GQA
+    (3, 6, 2, 64, 9, 33, 2000, 2048),        # B*H not a multiple of 8: agent-scope hand-off, head_dim 64
+    (1, 1, 1, 128, 6, 50, 70, 64 * 3),       # one head, a list shorter than the cluster
+])
+def test_fused_decode_unusual_shapes_equal_two_kernel_path(mp, B, H, Hkv, D, K, L, n, M):
+    """The one-launch decode entry against hash -> batch_retrieve -> attention_wrapper on the same
+    stores: identical codes, nnz and ids; outputs equal up to summation order."""
+    server, _ = _fused_server(mp, B, H, Hkv, n, M, D, K, L, 1000 + K)
+    BH = B * H
+    gen = torch.Generator(device="cuda").manual_seed(K * L)
+    for it in range(3):
+        q = torch.randn((B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16)
+        out, lse = server.decode(q, 0)
+        nz1 = server.nnz.clone()
+        codes, qn = server.hasher.query(q.reshape(BH, D))
+        res = torch.zeros((BH, M), dtype=torch.int32, device="cuda")
+        nz = torch.zeros((BH,), dtype=torch.int32, device="cuda")
+        server.lsh_retriever.batch_retrieve(0, codes, res, nz)
+        assert torch.equal(nz, nz1)
+        o_ref = torch.zeros((BH, D), dtype=torch.bfloat16, device="cuda")
+        mve = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
+        server.attn_server.attention_wrapper(0, K, L, o_ref, mve, q.reshape(BH, D), qn, res, nz)
+        live = (nz > 0).cpu().numpy()
+        dead = ~live
+        a = out.reshape(BH, D).float().cpu().numpy()
+        assert np.allclose(a[live], o_ref.float().cpu().numpy()[live], rtol=2 ** -6, atol=2e-3)
+        assert np.all(a[dead] == 0) and np.all(np.isneginf(lse.reshape(-1).cpu().numpy()[dead]))
+        assert np.allclose(lse.reshape(-1).cpu().numpy()[live], mve[1].cpu().numpy()[live], atol=2e-3)
+
+
 def test_fused_decode_long_lists_spill_through_hbm(mp):
     """K = 1 selects almost every token: the id list of a head (~n entries) is far longer than the
     fused kernel's LDS stage, so every cluster member takes the spill path (list through HBM)."""
