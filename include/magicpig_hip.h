@@ -137,6 +137,11 @@ int mp_attn_clear(mp_attn_t* h, mp_stream_t stream);  /* sparse_attention.cc:586
  * is computed on the fly.  A position >= max_length is reported by mp_attn_check (MP_ERR_DATA). */
 int mp_attn_append(mp_attn_t* h, int layer_id, const uint16_t* k, const uint16_t* v,
                    const int32_t* pos, mp_stream_t stream);
+/* The same with the two torch lines in front of it folded in (models/attnserver.py:267, 281-290):
+ * the stored key is bf16(k - centre) (centre = the request's avg_k, bf16 [B, Hkv, D]) and the row is
+ * pos[b] + pos_delta (the reference appends at kv_last_page_len - 1 after plan() incremented it). */
+int mp_attn_append_centred(mp_attn_t* h, int layer_id, const uint16_t* k, const uint16_t* v,
+                           const uint16_t* centre, const int32_t* pos, int pos_delta, mp_stream_t stream);
 int mp_attn_check(mp_attn_t* h, mp_stream_t stream);
 /* get_key_cache / get_value_cache / get_key_norm, sparse_attention.cc:1213-1233: device
  * pointers into the handle's storage.  K and V rows are INTERLEAVED per token in HBM

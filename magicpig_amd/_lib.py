@@ -71,6 +71,7 @@ def lib() -> C.CDLL:
         "mp_attn_full": ([p, i32, p, p, p, i32, p, i32, p], i32),
         "mp_attn_clear": ([p, p], i32),
         "mp_attn_append": ([p, i32, p, p, p, p], i32),
+        "mp_attn_append_centred": ([p, i32, p, p, p, p, i32, p], i32),
         "mp_attn_check": ([p, p], i32),
         "mp_debug_set_stamp_buffer": ([p], i32),
         "mp_debug_xcd_round_robin": ([], i32),

@@ -164,9 +164,10 @@ class LSHSparseAttnServer:
         B, H, Hkv, D = self.batch_size, self.num_attention_heads, self.num_key_value_heads, self.head_dim
         q = query_states.reshape(B * H, D)
         L.expect(q, torch.bfloat16, (B * H, D), "query_states")
-        k = (key_states.reshape(B, Hkv, 1, D) - self.avg_k[layer_idx]).reshape(B, Hkv, D).contiguous()
+        k = key_states.reshape(B, Hkv, D).contiguous()
         v = value_states.reshape(B, Hkv, D).contiguous()
-        self.window_server.append(layer_idx, k, v, self.kv_last_page_len - 1)
+        self.window_server.append_centred(layer_idx, k, v, self.avg_k[layer_idx].view(B, Hkv, D),
+                                          self.kv_last_page_len, -1)
         rc = L.lib().mp_decode_layer_window(
             self.hasher._h, self.lsh_retriever._h, self.attn_server._h, self.window_server._h, layer_idx,
             L.ptr(q), L.ptr(self.window_nnz), L.ptr(self.output), L.ptr(self.max_value_expsum),

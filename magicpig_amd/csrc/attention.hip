@@ -421,11 +421,13 @@ __global__ void attn_fill_kernel(const uint16_t* __restrict__ k, const uint16_t*
 // flashinfer.append_paged_kv_cache as used at models/attnserver.py:281-290: write this step's
 // (k, v) of every request at row pos[b] of its kv heads.  k, v: bf16 [B][Hkv][D].
 __global__ void attn_append_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
-                                   const int32_t* __restrict__ pos, int Hkv, int D, int64_t M,
-                                   uint16_t* __restrict__ kv, float* __restrict__ kn, int* __restrict__ err) {
+                                   const int32_t* __restrict__ pos, int pos_delta,
+                                   const uint16_t* __restrict__ centre,   // [B*Hkv][D] bf16 or nullptr
+                                   int Hkv, int D, int64_t M, uint16_t* __restrict__ kv,
+                                   float* __restrict__ kn, int* __restrict__ err) {
     const int b = blockIdx.x / Hkv;
     const int64_t unit = blockIdx.x;                 // b*Hkv + kv head
-    const int p = pos[b];
+    const int p = pos[b] + pos_delta;
     if (p < 0 || (int64_t)p >= M) {                  // window full: report, never write out of bounds
         if (threadIdx.x == 0) atomicOr(err, 2);
         return;
@@ -433,8 +435,18 @@ __global__ void attn_append_kernel(const uint16_t* __restrict__ k, const uint16_
     const int cpr = D / 8;
     double ss = 0.0;
     if ((int)threadIdx.x < cpr) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(k + unit * D + threadIdx.x * 8);
+        u32x4 a = *reinterpret_cast<const u32x4*>(k + unit * D + threadIdx.x * 8);
         const u32x4 c = *reinterpret_cast<const u32x4*>(v + unit * D + threadIdx.x * 8);
+        if (centre != nullptr) {                     // k - avg_k as torch computes it on bf16 tensors:
+                                                     // f32 subtraction, RNE back to bf16 (attnserver.py:267)
+            const u32x4 m = *reinterpret_cast<const u32x4*>(centre + unit * D + threadIdx.x * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = f32_to_bf16_rne(bf16_lo(a[j]) - bf16_lo(m[j]));
+                const uint32_t hi = f32_to_bf16_rne(bf16_hi(a[j]) - bf16_hi(m[j]));
+                a[j] = lo | (hi << 16);
+            }
+        }
         uint16_t* dst = kv + (unit * M + p) * 2 * D + threadIdx.x * 8;
         *reinterpret_cast<u32x4*>(dst) = a;
         *reinterpret_cast<u32x4*>(dst + D) = c;
@@ -538,9 +550,11 @@ hipError_t launch_attn_fill(const uint16_t* k, const uint16_t* v, const float* k
     return hipGetLastError();
 }
 
-hipError_t launch_attn_append(const uint16_t* k, const uint16_t* v, const int32_t* pos, int B, int Hkv,
-                              int D, int64_t M, uint16_t* kv, float* kn, int* err, hipStream_t st) {
-    hipLaunchKernelGGL(attn_append_kernel, dim3(B * Hkv), dim3(64), 0, st, k, v, pos, Hkv, D, M, kv, kn, err);
+hipError_t launch_attn_append(const uint16_t* k, const uint16_t* v, const int32_t* pos, int pos_delta,
+                              const uint16_t* centre, int B, int Hkv, int D, int64_t M, uint16_t* kv, float* kn,
+                              int* err, hipStream_t st) {
+    hipLaunchKernelGGL(attn_append_kernel, dim3(B * Hkv), dim3(64), 0, st, k, v, pos, pos_delta, centre, Hkv, D,
+                       M, kv, kn, err);
     return hipGetLastError();
 }
 

@@ -47,7 +47,7 @@ hipError_t launch_attn_fill(const uint16_t*, const uint16_t*, const float*, int,
                             int64_t, uint16_t*, float*, hipStream_t);
 hipError_t launch_merge_state(const uint16_t*, const float*, const uint16_t*, const float*, int,
                               int, uint16_t*, float*, hipStream_t);
-hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, int, int, int, int64_t,
+hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, int, const uint16_t*, int, int, int, int64_t,
                               uint16_t*, float*, int*, hipStream_t);
 
 extern unsigned long long* g_stamp;
@@ -554,14 +554,26 @@ int mp_attn_fill(mp_attn_t* h, int layer_id, int request_id, const uint16_t* k, 
     return MP_OK;
 }
 
+static int attn_append(mp_attn_t* h, int layer_id, const uint16_t* k, const uint16_t* v, const int32_t* pos,
+                       int pos_delta, const uint16_t* centre, hipStream_t st, const char* who) {
+    const std::string w(who);
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, w + ": not allocated");
+    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, w + ": layer_id out of range");
+    MP_REQUIRE(k && v && pos, MP_ERR_INVALID, w + ": null argument");
+    MP_HIP_CHECK(launch_attn_append(k, v, pos, pos_delta, centre, h->B, h->Hkv, h->D, h->M, h->kv[layer_id],
+                                    h->kn[layer_id], h->err, st));
+    return MP_OK;
+}
+
 int mp_attn_append(mp_attn_t* h, int layer_id, const uint16_t* k, const uint16_t* v,
                    const int32_t* pos, mp_stream_t stream) {
-    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_append: not allocated");
-    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_attn_append: layer_id out of range");
-    MP_REQUIRE(k && v && pos, MP_ERR_INVALID, "mp_attn_append: null argument");
-    MP_HIP_CHECK(launch_attn_append(k, v, pos, h->B, h->Hkv, h->D, h->M, h->kv[layer_id], h->kn[layer_id],
-                                    h->err, (hipStream_t)stream));
-    return MP_OK;
+    return attn_append(h, layer_id, k, v, pos, 0, nullptr, (hipStream_t)stream, "mp_attn_append");
+}
+
+int mp_attn_append_centred(mp_attn_t* h, int layer_id, const uint16_t* k, const uint16_t* v,
+                           const uint16_t* centre, const int32_t* pos, int pos_delta, mp_stream_t stream) {
+    MP_REQUIRE(centre != nullptr, MP_ERR_INVALID, "mp_attn_append_centred: null centre");
+    return attn_append(h, layer_id, k, v, pos, pos_delta, centre, (hipStream_t)stream, "mp_attn_append_centred");
 }
 
 int mp_attn_check(mp_attn_t* h, mp_stream_t stream) {

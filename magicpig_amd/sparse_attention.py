@@ -98,6 +98,19 @@ class SparseAttentionServer:
             raise ValueError("append takes CUDA tensors")
         L.check(L.lib().mp_attn_append(self._h, layer_id, L.ptr(k), L.ptr(v), L.ptr(pos), L.current_stream(k)))
 
+    def append_centred(self, layer_id: int, k: torch.Tensor, v: torch.Tensor, centre: torch.Tensor,
+                       pos: torch.Tensor, pos_delta: int = 0) -> None:
+        """append() with `k - centre` (bf16 semantics of models/attnserver.py:267) and the row offset
+        folded into the same launch.  centre bf16 [B, Hkv, D]."""
+        L.expect(k, torch.bfloat16, (self.B, self.Hkv, self.D), "k")
+        L.expect(v, torch.bfloat16, (self.B, self.Hkv, self.D), "v")
+        L.expect(centre, torch.bfloat16, (self.B, self.Hkv, self.D), "centre")
+        L.expect(pos, torch.int32, (self.B,), "pos")
+        if not (k.is_cuda and v.is_cuda and pos.is_cuda and centre.is_cuda):
+            raise ValueError("append_centred takes CUDA tensors")
+        L.check(L.lib().mp_attn_append_centred(self._h, layer_id, L.ptr(k), L.ptr(v), L.ptr(centre), L.ptr(pos),
+                                               pos_delta, L.current_stream(k)))
+
     def check(self) -> None:
         """Raise if a device-side validation failed since the last check (append past max_length)."""
         L.check(L.lib().mp_attn_check(self._h, L.current_stream()))
