@@ -866,16 +866,19 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
 }
 
 // ---- where do blocks land?  The cluster hand-off of lsh_decode_kernel may stay inside one XCD's L2
-// only if block b really runs on XCD b % 8.  That is measured, once per process, on the device in
-// use: every block of two probe launches reports its XCC_ID.
+// only if block b really runs on XCD b % 8.  That is measured, once per process and device: every
+// block of two probe launches reports its XCC_ID.
 __global__ void xcc_probe_kernel(int* __restrict__ out) {
     if (threadIdx.x == 0) out[blockIdx.x] = (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
 }
 
 bool xcd_round_robin_verified() {
-    static int state = -1;   // -1 unknown, 0 no, 1 yes
-    if (state >= 0) return state == 1;
-    state = 0;
+    static int states[64];   // per device: 0 unknown, 1 no, 2 yes
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    int& state = states[dev];
+    if (state != 0) return state == 2;
+    state = 1;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(nullptr, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
     int* d = nullptr;
@@ -898,7 +901,7 @@ bool xcd_round_robin_verified() {
     for (int a = 0; a < 8; ++a)
         for (int b = a + 1; b < 8; ++b)
             if (hbuf[a] == hbuf[b]) return false;                        // 8 distinct XCDs
-    state = 1;
+    state = 2;
     return true;
 }
 
