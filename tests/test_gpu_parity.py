@@ -657,6 +657,59 @@ def test_fused_decode_unusual_shapes_equal_two_kernel_path(mp, B, H, Hkv, D, K, 
         assert np.allclose(lse.reshape(-1).cpu().numpy()[live], mve[1].cpu().numpy()[live], atol=2e-3)
 
 
+def test_cfg1_shaped_fused_decode_properties(mp):
+    """BASELINE cfg 1 shape (B=1, H=32, Hkv=8, n=97 932, M=98 304, K=10, L=150), one layer, through
+    size-independent properties: (1) the one-launch entry equals hash -> batch_retrieve ->
+    attention_wrapper on the same stores (codes, nnz, ids bit for bit; outputs up to summation order);
+    (2) attention_wrapper is a function of the SET of selected ids: a shuffled id list gives the same
+    output; (3) scaling V by 2 scales the output by 2 exactly and leaves the LSE unchanged."""
+    B, H, Hkv, D, K, L, n, M = 1, 32, 8, 128, 10, 150, 97932, 98304
+    BH = B * H
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(5)
+    W = torch.randn((D, K * L), device=dev, generator=gen).to(torch.bfloat16)
+    server = mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, num_sink_tokens=0,
+                                    num_local_tokens=0, max_length=M, dense_layers=(), hash_func=W)
+    kc = torch.randn((n, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
+    vc = torch.randn((n, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
+    server.fill(0, 0, kc, vc, n)
+    server.build_table(0, 0, n)
+    q = torch.randn((B, H, 1, D), device=dev, generator=gen).to(torch.bfloat16)
+    out, lse = server.decode(q, 0)
+    out, lse, nz1 = out.clone(), lse.clone(), server.nnz.clone()
+    codes, qn = server.hasher.query(q.reshape(BH, D))
+    res = torch.zeros((BH, M), dtype=torch.int32, device=dev)
+    nz = torch.zeros((BH,), dtype=torch.int32, device=dev)
+    server.lsh_retriever.batch_retrieve(0, codes, res, nz)
+    assert torch.equal(nz, nz1) and int(nz.min()) > 500
+    o_ref = torch.zeros((BH, D), dtype=torch.bfloat16, device=dev)
+    mve = torch.zeros((2, BH), dtype=torch.float32, device=dev)
+    aw = server.attn_server.attention_wrapper
+    aw(0, K, L, o_ref, mve, q.reshape(BH, D), qn, res, nz)
+    assert np.allclose(out.reshape(BH, D).float().cpu().numpy(), o_ref.float().cpu().numpy(), rtol=2 ** -6, atol=2e-3)
+    assert np.allclose(lse.reshape(-1).cpu().numpy(), mve[1].cpu().numpy(), atol=2e-3)
+    # (2) permutation of the list
+    res2 = res.clone()
+    for h in range(BH):
+        k_ = int(nz[h])
+        perm = torch.randperm(k_, device=dev, generator=gen)
+        res2[h, :k_] = res[h, :k_][perm]
+    o2 = torch.zeros_like(o_ref)
+    mve2 = torch.zeros_like(mve)
+    aw(0, K, L, o2, mve2, q.reshape(BH, D), qn, res2, nz)
+    assert np.allclose(o2.float().cpu().numpy(), o_ref.float().cpu().numpy(), rtol=2 ** -6, atol=2e-3)
+    assert np.allclose(mve2[1].cpu().numpy(), mve[1].cpu().numpy(), atol=2e-3)
+    # (3) V -> 2 V (exact in bf16): out -> 2 out bit for bit in f32 before rounding, so bf16(out) doubles exactly
+    server.attn_server.fill(0, 0, (kc[:n].transpose(0, 1) - server.avg_k[0][0]).contiguous(),
+                            (vc[:n].transpose(0, 1) * 2).contiguous(),
+                            (kc[:n].transpose(0, 1) - server.avg_k[0][0]).norm(p=2, dim=-1).float())
+    o3 = torch.zeros_like(o_ref)
+    mve3 = torch.zeros_like(mve)
+    aw(0, K, L, o3, mve3, q.reshape(BH, D), qn, res, nz)
+    assert torch.equal(o3.float(), o_ref.float() * 2)
+    assert torch.equal(mve3, mve)
+
+
 def test_fused_decode_long_lists_spill_through_hbm(mp):
     """K = 1 selects almost every token: the id list of a head (~n entries) is far longer than the
     fused kernel's LDS stage, so every cluster member takes the spill path (list through HBM)."""
