@@ -21,7 +21,7 @@ k = torch.randn((NL, B, Hkv, 1, D), device=dev).to(torch.bfloat16)
 v = torch.randn((NL, B, Hkv, 1, D), device=dev).to(torch.bfloat16)
 def run(fn, reps=30):
     g = torch.cuda.CUDAGraph()
-    server.kv_last_page_len.fill_(69); server.plan_static = True
+    server.kv_last_page_len.fill_(69)
     server.window_nnz.fill_(69)
     s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
