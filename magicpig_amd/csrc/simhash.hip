@@ -230,13 +230,13 @@ __global__ __launch_bounds__(1024) void simhash_query_kernel(
 // span in registers for the whole kernel -- and walks chunk_tiles consecutive 32-row tiles:
 //   * the rows of tile t+2 are requested while tile t is on the matrix pipe and tile t+1 is being
 //     written to the other half of a double-buffered LDS stage: ONE barrier per tile;
-//   * the 32x32 sign matrix of a tile leaves the wave as one LDS store (see `compute`) and is
-//     packed to K-bit codes into an LDS code block that is stored at the end as long runs of
-//     every [L][n] row;
+//   * the 32x32 sign matrix of a tile leaves the wave as one LDS store (see `compute`) into the
+//     chunk's bit matrix [32 * chunk_tiles rows][9 words]; the K-bit codes are cut out of it at
+//     the end and stored as long runs of every [L][n] row;
 //   * guard-band candidates are NOT resolved inline (any stall would hold all waves at the
 //     barrier): they are queued in LDS and resolved together at the end, one 16-lane group per
 //     candidate (exact f64 dot product of the row and the plane, both re-read from L2), patching
-//     the code block before it is stored.
+//     the bit matrix before the codes are cut out.
 // What bounds it is VALU issue, not the matrix pipe: ~200 vector instructions per wave and tile
 // against 8 MFMAs, which is why the epilogue is written the way it is.
 constexpr int SK_CH_MAX = 32;             // 32-row tiles per workgroup: chosen per launch (keys_chunk_tiles)
@@ -263,11 +263,11 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
     const int CROWS = chunk_tiles * SH_ROWS;
     __shared__ __attribute__((aligned(16))) uint16_t s_x[2][SH_ROWS * STRIDE];
     __shared__ float s_rn[2][SH_ROWS];
-    __shared__ uint32_t s_bits[2][SH_ROWS][SH_MAX_TILES + 1];
+    constexpr int BW = SK_WAVES + 1;      // words of the sign matrix per row: one per wave + one of slack
     __shared__ uint32_t s_queue[SK_QCAP];
     __shared__ int s_qn;
-    extern __shared__ uint32_t s_codes32[];               // int16 [tables_per_wg][CROWS], viewed as u32 for patching
-    int16_t* s_codes = reinterpret_cast<int16_t*>(s_codes32);
+    extern __shared__ uint32_t s_rowbits[];               // sign matrix of the whole chunk: [CROWS][BW] (bit c of
+                                                          // word w of row r <- plane col0 + 32 w + c)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int nthr = NTHR;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
                        "n"(2 * (I) + 2), "n"(2 * (I) + 6), "n"(2 * (I) + 3), "n"(2 * (I) + 7));
         MP_WL4(0) MP_WL4(4) MP_WL4(8) MP_WL4(12)
 #undef MP_WL4
-        if (lane < 32) s_bits[buf][lane][wave] = rowbits;
+        if (lane < 32) s_rowbits[(t * SH_ROWS + lane) * BW + wave] = rowbits;
         if (amin <= wn * rnmax) {                         // wn < 0 for padding planes: never taken
             const int64_t r0 = row_base + (int64_t)t * SH_ROWS;
 #pragma unroll
@@ -402,17 +402,6 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
         }
     };
     const uint32_t kmask = (1u << K) - 1u;
-    auto pack = [&](int t) {                              // bits of tile t -> LDS code block
-        const int buf = t & 1;
-        for (int p = tid; p < SH_ROWS * tables_per_wg; p += nthr) {
-            const int tb = p / SH_ROWS, row = p % SH_ROWS;
-            const int bp = tb * K, w = bp >> 5, sh = bp & 31;
-            const unsigned long long two = (unsigned long long)s_bits[buf][row][w] |
-                                           ((unsigned long long)s_bits[buf][row][w + 1] << 32);
-            s_codes[tb * CROWS + t * SH_ROWS + row] = (int16_t)((uint32_t)(two >> sh) & kmask);
-        }
-    };
-
     // __syncthreads() also drains every outstanding global load (s_waitcnt vmcnt(0)), which would
     // serialise the prefetched tiles behind each barrier; inside the loop only LDS traffic has to be
     // complete before the barrier (HIP guide, "Pipelining across barriers").
@@ -432,7 +421,6 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
         compute(T);                                                        \
         tile_store(((T) + 1) & 1, STORESET);                               \
         lds_barrier();                                                     \
-        pack(T);                                                           \
     }
     for (int t = 0; t < nt; t += 2) {
         MP_SK_PHASE(t, s0, s1)
@@ -463,14 +451,13 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
         part += __shfl_xor(part, 4);
         part += __shfl_xor(part, 8);
         if (l16 == 0) {
-            const int tb = coff / K, bit = coff % K;
-            const int idx = tb * CROWS + crow;              // int16 index into the code block
-            const uint32_t m = (1u << bit) << (16 * (idx & 1));
-            if (part > 0.0) atomicOr(&s_codes32[idx >> 1], m); else atomicAnd(&s_codes32[idx >> 1], ~m);
+            uint32_t* wd = &s_rowbits[crow * BW + (coff >> 5)];
+            const uint32_t m = 1u << (coff & 31);
+            if (part > 0.0) atomicOr(wd, m); else atomicAnd(wd, ~m);
         }
     }
     if (overflow) {   // more candidates than the queue holds (adversarial input): every thread re-checks
-                      // its share of the code block exactly -- slow, correct
+                      // its share of the bit matrix exactly -- slow, correct
         for (int p = tid; p < tables_per_wg * K * (nt * SH_ROWS); p += nthr) {
             const int coff = p / (nt * SH_ROWS), crow = p % (nt * SH_ROWS);
             if (col0 + coff >= KL || row_base + crow >= n) continue;
@@ -478,9 +465,9 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
             for (int d = 0; d < D; ++d)
                 ex += (double)bf16_bits_to_f32(x[(row_base + crow) * D + d]) *
                       (double)bf16_bits_to_f32(Wt[(int64_t)(col0 + coff) * D + d]);
-            const int tb = coff / K, bit = coff % K, idx = tb * CROWS + crow;
-            const uint32_t m = (1u << bit) << (16 * (idx & 1));
-            if (ex > 0.0) atomicOr(&s_codes32[idx >> 1], m); else atomicAnd(&s_codes32[idx >> 1], ~m);
+            uint32_t* wd = &s_rowbits[crow * BW + (coff >> 5)];
+            const uint32_t m = 1u << (coff & 31);
+            if (ex > 0.0) atomicOr(wd, m); else atomicAnd(wd, ~m);
         }
     }
     __syncthreads();
@@ -490,23 +477,30 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
     // groups of four codes aligned on the DESTINATION address (n is arbitrary, so the alignment of
     // a row start differs from table to table); ragged ends go out as scalars.
     const int ntok = (int)((n - row_base < (int64_t)nt * SH_ROWS) ? (n - row_base) : (int64_t)nt * SH_ROWS);
+    // the K-bit code of (row j, table tb) is cut out of the row's bits here, once per code, instead of
+    // once per tile into an intermediate block of codes
     const int G = CROWS / 4 + 1;
     for (int tb = wave; tb < tables_per_wg; tb += SK_WAVES) {
         const int l = table0 + tb;
         if (l >= L) break;
         int16_t* dst = codes + (int64_t)l * n + row_base;
         const int shift = (int)(((8u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 7u)) & 7u) >> 1);
-        const int16_t* src = s_codes + tb * CROWS;
+        const int bp = tb * K, bw = bp >> 5, sh = bp & 31;
+        auto code_at = [&](int j) -> uint32_t {
+            const uint32_t* rw = s_rowbits + j * BW + bw;
+            const unsigned long long two = (unsigned long long)rw[0] | ((unsigned long long)rw[1] << 32);
+            return (uint32_t)(two >> sh) & kmask;
+        };
         for (int g = lane; g < G; g += WAVE) {
             const int j0 = shift + 4 * (g - 1);
             const int lo = j0 < 0 ? 0 : j0, hi = (j0 + 4 < ntok) ? j0 + 4 : ntok;
             if (hi - lo == 4) {
                 uint2 v;
-                v.x = (uint32_t)(uint16_t)src[lo] | ((uint32_t)(uint16_t)src[lo + 1] << 16);
-                v.y = (uint32_t)(uint16_t)src[lo + 2] | ((uint32_t)(uint16_t)src[lo + 3] << 16);
+                v.x = code_at(lo) | (code_at(lo + 1) << 16);
+                v.y = code_at(lo + 2) | (code_at(lo + 3) << 16);
                 *reinterpret_cast<uint2*>(dst + lo) = v;
             } else {
-                for (int j = lo; j < hi; ++j) dst[j] = src[j];
+                for (int j = lo; j < hi; ++j) dst[j] = (int16_t)code_at(j);
             }
         }
     }
@@ -588,7 +582,7 @@ static void simhash_keys_geometry(int K, int& tables_per_wg, int& tiles_per_wg) 
 // Tiles per workgroup.  Workgroups are not persistent, so the launch runs in ceil(wgs / slots)
 // rounds of (per-tile time * tiles + fixed prologue/flush time): pick the chunk that minimises
 // that product (the constants are the measured 1.9 us per tile and 7 us per workgroup; only their
-// ratio matters).  The code block [tables][32 * tiles] int16 has to fit in LDS next to a second
+// ratio matters).  The chunk's sign matrix [32 * tiles][9] words has to fit in LDS next to a second
 // workgroup.
 static int keys_chunk_tiles(int64_t n, int64_t wgs_x, int tables_per_wg) {
     int cus = 256;
@@ -601,7 +595,7 @@ static int keys_chunk_tiles(int64_t n, int64_t wgs_x, int tables_per_wg) {
     int best = 1;
     double best_cost = 1e300;
     for (int ch = 1; ch <= SK_CH_MAX; ++ch) {
-        if ((size_t)tables_per_wg * ch * SH_ROWS * sizeof(int16_t) > 48u * 1024u) break;
+        if ((size_t)ch * SH_ROWS * (SK_WAVES + 1) * sizeof(uint32_t) > 48u * 1024u) break;
         const int64_t wgs = ((tiles + ch - 1) / ch) * wgs_x;
         const double cost = (double)((wgs + slots - 1) / slots) * (1.9 * ch + 7.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = ch; }
@@ -631,7 +625,7 @@ hipError_t launch_simhash_keys(const uint16_t* keys, const uint16_t* Wt, const f
     if (chunks > INT32_MAX || blocks > INT32_MAX) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks);
     dim3 block(64 * SK_WAVES);
-    const size_t lds = (size_t)tp * crows * sizeof(int16_t);
+    const size_t lds = (size_t)crows * (SK_WAVES + 1) * sizeof(uint32_t);   // the chunk's sign matrix
 #define MP_SK_CASE(DD)                                                                              \
     if (D == DD) {                                                                                  \
         hipLaunchKernelGGL((simhash_keys_kernel<DD>), grid, block, lds, st, keys, Wt, wnorm, n, K,  \
