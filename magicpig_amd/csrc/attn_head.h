@@ -110,14 +110,15 @@ __device__ __forceinline__ void attn_head_fold(
         // stays unconditional -- loads under a branch would make the compiler drain vmcnt at every
         // join.  Rows are read once and never reused: non-temporal loads.
         const int id_first = DENSE ? jb : __builtin_amdgcn_readfirstlane((int)idv[0][0]);
-        const int id_safe = (id_first >= 0 && (int64_t)id_first < M) ? id_first : 0;
+        const uint32_t M32 = (uint32_t)M;                               // max_length <= 2^22
+        const int id_safe = ((uint32_t)id_first < M32) ? id_first : 0;
         u32x4 kreg[UPS], vreg[UPS];
         int id_my = 0;
 #pragma unroll
         for (int u = 0; u < UPS; ++u) {
             int id_u = DENSE ? (jb + r * UPS + u) : (int)idv[u / 4][u % 4];
             const bool valid_u = (jb + r * UPS + u) < nz;
-            if (!valid_u || id_u < 0 || (int64_t)id_u >= M) id_u = id_safe;
+            if (!valid_u || (uint32_t)id_u >= M32) id_u = id_safe;
             if (u == (c >> 1)) id_my = id_u;
             const uint16_t* row = kvc + (int64_t)id_u * 2 * D;
             kreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row));

@@ -508,8 +508,9 @@ __device__ __forceinline__ void lsh_head_body(
 
     // stream the probed buckets: wave w owns tables w, w+16, ...; per round it keeps RT_GROUP
     // buckets x 2 chunks of 64 ids (<= 128 ids per bucket) in flight, then applies them
+    const uint32_t M32 = (uint32_t)M;                                   // M <= 2^22 (mp_lsh_alloc)
     auto apply = [&](int32_t t) {
-        if (t >= 0 && (int64_t)t < M) {
+        if ((uint32_t)t < M32) {                                        // one unsigned compare: 0 <= t < M
             const uint32_t bit = 1u << (t & 31);
             const uint32_t old = atomicOr(&bmA[t >> 5], bit);           // first hit: 0 -> 1
             if (old & bit) atomicOr(&bmB[t >> 5], bit);                 // any later hit: -> 2
