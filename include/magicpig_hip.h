@@ -180,7 +180,9 @@ int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int 
  * live for each head.  Exact attention over those rows joins the softmax of the sampled tokens, which
  * is what BatchDecodeWithPagedKVCacheWrapper.run_return_lse (:293-296) followed by
  * flashinfer.merge_state (:305-308) computes; output is the merged hidden state, max_value_expsum[1]
- * the base-2 LSE over both parts.  MP_ERR_UNSUPPORTED when the one-launch form does not exist for the
+ * the base-2 LSE over both parts (mp_attn_get_score after this call gives each sampled token's share of
+ * that merged softmax, so a head's scores sum to the sampled part's weight, not to 1).
+ * MP_ERR_UNSUPPORTED when the one-launch form does not exist for the
  * shape (then: mp_attn_full on the window + mp_decode_sparse_layer + mp_merge_state). */
 int mp_decode_layer_window(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn_t* window,
                            int layer_id, const uint16_t* q, const int32_t* window_len, uint16_t* output,
