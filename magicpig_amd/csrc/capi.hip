@@ -753,7 +753,11 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         if (cluster > 8) cluster = 8;     // measured: 16 and 32 members lose more in the hand-off and in L2 plane traffic than they gain
         if (cluster > attn_slices_per_head(attn->M)) cluster = attn_slices_per_head(attn->M);
         if (cluster < 1) cluster = 1;
-        if (const char* e = getenv("MP_DECODE_CLUSTER")) cluster = atoi(e) >= 1 ? atoi(e) : cluster;
+        static const int cluster_override = [] {           // A/B switch, read once
+            const char* e = getenv("MP_DECODE_CLUSTER");
+            return e ? atoi(e) : 0;
+        }();
+        if (cluster_override >= 1) cluster = cluster_override;
         MP_HIP_CHECK(launch_lsh_decode(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk, s->wnorm, s->D,
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
