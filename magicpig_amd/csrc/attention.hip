@@ -31,30 +31,6 @@ extern unsigned long long* g_stamp;   // simhash.hip
 constexpr int AT_THREADS = 256;
 constexpr int AT_WAVES = AT_THREADS / 64;
 
-__device__ __forceinline__ float powi(float b, int e) {
-    float r = 1.f;
-    while (e) {          // e is wave-uniform
-        if (e & 1) r *= b;
-        b *= b;
-        e >>= 1;
-    }
-    return r;
-}
-
-// one reduce-scatter step over lanes l and l^ST: N values -> N/2 values per lane
-template <int N, int ST>
-__device__ __forceinline__ void rs_step(float (&v)[8], int lane, int& doff) {
-    constexpr int half = N / 2;
-    const bool upper = (lane & ST) != 0;
-#pragma unroll
-    for (int i = 0; i < half; ++i) {
-        const float send = upper ? v[i] : v[i + half];
-        const float keep = upper ? v[i + half] : v[i];
-        v[i] = keep + __shfl_xor(send, ST);
-    }
-    doff += upper ? half : 0;
-}
-
 // D: head_dim (64 or 128); DENSE: ids are 0..nnz-1 and no importance transform (full_attention);
 // QBF16: query is bf16 (the reference's __AVX512BF16__ family) else f32.
 //
@@ -219,7 +195,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_sparse_kernel(
                                                        // a bf16-rounded norm makes cos > 1)
                 const float theta = acosf(cs);
                 const float proba = 1.f - theta * 0.31830988618379067f;
-                const float p = powi(proba, K);
+                const float p = powi_u(proba, K);
                 // w = 1 - (1-p)^(L-1) (L p + 1 - p) = P[>= 2 of L tables collide].  The reference
                 // evaluates this literally in f32 (two powf and a subtraction from 1), which loses
                 // ~3 digits to cancellation wherever w ~ 1e-4; here the same quantity is computed
@@ -253,9 +229,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_sparse_kernel(
         // reduce-scatter over the RPL row groups: lane (r, c) ends with VPL = 8/RPL outputs,
         // elements d0 .. d0+VPL-1 of o[D]
         int doff = 0;
-        rs_step<8, 32>(acc, lane, doff);
-        rs_step<4, 16>(acc, lane, doff);
-        if (LPR == 8) rs_step<2, 8>(acc, lane, doff);
+        rs_step_h<8, 32>(acc, lane, doff);
+        rs_step_h<4, 16>(acc, lane, doff);
+        if (LPR == 8) rs_step_h<2, 8>(acc, lane, doff);
         constexpr int VPL = (LPR == 16) ? 2 : 1;
         const int d0 = c * 8 + doff;
         MP_STAMP(stamp, 37);
