@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--config", default="cfg1", choices=sorted(CONFIGS))
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=192)
+    ap.add_argument("--cpu-steps", type=int, default=2048)
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--table-build", default="counting", choices=["sort", "counting"])
     ap.add_argument("--end-to-end", action="store_true",
