@@ -72,3 +72,24 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f
                 assert not re.search(r"#\s*include[^\n]*oracle", text), f
                 assert "mp_oracle" not in text and "libmp_oracle" not in text, f
+
+
+def test_plain_c_client_compiles_and_links(tmp_path):
+    """include/magicpig_hip.h is valid C11 and every call of tests/c_client/client.c resolves
+    against the built library (compile + link only: running it needs a GPU, tests/test_gpu_c_client.py)."""
+    import shutil
+    import subprocess
+
+    from magicpig_amd.build import build
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    lib = build()
+    exe = str(tmp_path / "client")
+    r = subprocess.run(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "c_client", "client.c"), "-o", exe,
+                        "-L", os.path.dirname(lib), "-lmagicpig_hip", "-Wl,-rpath," + os.path.dirname(lib),
+                        "-Wl,--allow-shlib-undefined"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(exe)
