@@ -371,8 +371,8 @@ def main():
         try:
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("config") == args.config:
-                traffic = tj.get("lsh_decode_bytes_per_launch" if fused else "two_launch_bytes_per_layer")
+            key = "lsh_decode_bytes_per_launch" if fused else "two_launch_bytes_per_layer"
+            traffic = (tj.get(key) or {}).get(args.config)
         except Exception:
             traffic = None
 
