@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2048)
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # tests: control flow on CPU / gloo
     ap.add_argument("--table-build", default="counting", choices=["sort", "counting"])
     ap.add_argument("--end-to-end", action="store_true",
                     help="examples/bench.py-style full decode step with synthetic weights (SURVEY 8f-3) "
@@ -221,6 +222,44 @@ def end_to_end(args, cfg, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def dry_run(args, rank, world):
+    """The launch contract without a GPU (tests/test_sharding_gloo.py): RANK / WORLD_SIZE / MASTER_*
+    from the environment, process group, hyperplane broadcast, barrier-bracketed timed region,
+    max over ranks, ONE JSON line from rank 0 -- with a sleep standing in for the kernels."""
+    from magicpig_amd import sharding
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    cfg = CONFIGS[args.config]
+    gen0 = torch.Generator(device="cpu").manual_seed(7 + rank)
+    hash_func = torch.randn((cfg["D"], cfg["K"] * cfg["L"]), generator=gen0).to(torch.bfloat16)
+    hash_func = sharding.sync_hash_func(hash_func, src=0)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))          # ranks differ: the slowest one sets the time
+    sync_all()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "value": world * cfg["B"] * args.steps / dt, "unit": "tokens/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "planes_checksum": int(hash_func.view(torch.int16).to(torch.int64).sum())}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 # ---------------------------------------------------------------------------- main
 
 def main():
@@ -232,6 +271,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    if args.dry_run:
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

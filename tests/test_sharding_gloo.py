@@ -103,3 +103,34 @@ def test_two_rank_sharded_decode_equals_unsharded(mode):
             got, t = ret[r]
             assert np.array_equal(got.view(np.uint16), ref), (mode, r)     # bit-identical: units are independent
             assert t == 2.0                                                 # max over ranks
+
+
+def test_bench_launch_contract_two_ranks_dry_run():
+    """bench.py under `python -m torch.distributed.run --nproc-per-node 2` (the driver's N > 1 launch)
+    with --dry-run: process group from the environment, hyperplanes broadcast from rank 0, barrier +
+    max-over-ranks timing, exactly ONE JSON line (rank 0), n_gpus = 2 and the slowest rank's time."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "20", "--warmup", "2", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 2
+    assert d["ms_per_step"] >= 1.9            # rank 1 sleeps 2 ms per step: max over ranks
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "1",
+                             "--dry-run"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert single.returncode == 0, single.stderr[-2000:]
+    d1 = json.loads([ln for ln in single.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["planes_checksum"] == d["planes_checksum"]   # rank 0's planes everywhere
