@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # tests: control flow on CPU / gloo
     ap.add_argument("--table-build", default="counting", choices=["sort", "counting"])
+    ap.add_argument("--two-launch", action="store_true",
+                    help="A/B: the decode entry as (hash + retrieve) then attention instead of one launch")
     ap.add_argument("--end-to-end", action="store_true",
                     help="examples/bench.py-style full decode step with synthetic weights (SURVEY 8f-3) "
                          "instead of the hot path alone")
@@ -287,6 +289,8 @@ def main():
     from magicpig_amd import sharding
 
     cfg = CONFIGS[args.config]
+    if args.two_launch:
+        L.set_option("decode_two_launch", 1)
     if args.end_to_end:
         return end_to_end(args, cfg, rank, world, dev, dist)
     B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
@@ -405,7 +409,7 @@ def main():
     bytes_layer = BH * (8 * Lt + 4 * cand_mean + 4 * nnz_mean + nnz_mean * (4 * D + 4) + 4 * nnz_mean
                         + 2 * D + 8) + 2 * D * K * Lt + BH * (2 * D + 4 * Lt)
     achieved = bytes_layer / (k_us * 1e-6) / 1e9
-    fused = os.environ.get("MP_DECODE_TWO_LAUNCH") is None
+    fused = not args.two_launch
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
     if os.path.exists(tpath):

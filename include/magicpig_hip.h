@@ -19,8 +19,11 @@
  *   - `stream` is a hipStream_t (NULL = default stream); work is enqueued asynchronously for
  *     MP_MEM_DEVICE arguments, synchronously completed for MP_MEM_HOST arguments;
  *   - all state (tables, KV, norms, scratch) lives in HBM of the device that was current at
- *     alloc time and is owned by the handle, as the reference objects own theirs
- *     (lsh.cc:29-42, sparse_attention.cc:529-544);
+ *     alloc time (mp_simhash_set_planes for the hasher) and is owned by the handle, as the
+ *     reference objects own theirs (lsh.cc:29-42, sparse_attention.cc:529-544); every call on a
+ *     handle switches to that device for its duration and restores the caller's current device,
+ *     `stream` must be a stream of the handle's device, and the handles of one
+ *     mp_decode_* call must live on the same device (MP_ERR_INVALID otherwise);
  *   - bf16 travels as uint16_t; h = b*H + head is the request-major query-head index,
  *     g = h / (H/Hkv) its kv-head unit (lsh.cc:251, sparse_attention.cc:773);
  *   - one call at a time per handle (the reference's scratch is per object too,
@@ -161,6 +164,20 @@ int mp_debug_set_stamp_buffer(void* dev_u64x64);
  * once per process); this is what lets the cluster hand-off of the fused decode kernel stay inside one
  * XCD's L2.  0 = not observed, the hand-off writes through to memory instead. */
 int mp_debug_xcd_round_robin(void);
+
+/* Debug: A/B switches for measurements and tests, process-wide, read at every call (never needed in
+ * production; unknown names return MP_ERR_INVALID):
+ *   "decode_two_launch"  0/1   mp_decode_sparse_layer as (hash + retrieve) then attention: two launches
+ *   "decode_cluster"     0 = auto, n = workgroups per head of the one-launch decode (clamped to [1, 8])
+ *   "decode_agent_scope" 0/1   cluster hand-off through memory even where the XCD placement was observed
+ *   "attn_head_kernel"   -1 = auto, 0 = split-KV kernel with the in-launch ticket merge, 1 = one workgroup per head
+ *   "attn_gx"            0 = auto, n = split-KV workgroups per head */
+int mp_debug_set_option(const char* name, int value);
+int mp_debug_get_option(const char* name, int* value);
+
+/* Debug (test hook): route the raw MFMA accumulators of the following mp_simhash_query calls on `s` to a
+ * device buffer f32 [R, K*L] (NULL switches it off) so that the exact-sign guard band can be validated. */
+int mp_simhash_debug_acc(mp_simhash_t* s, float* dev_buf);
 
 /* ---------------------------------------------------------------- one decode step of one layer
  * The device-resident equivalent of LSHSparseAttnServer.decode lines 264-300

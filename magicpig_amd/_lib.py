@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
         "mp_attn_check": ([p, p], i32),
         "mp_debug_set_stamp_buffer": ([p], i32),
         "mp_debug_xcd_round_robin": ([], i32),
+        "mp_debug_set_option": ([C.c_char_p, i32], i32),
+        "mp_debug_get_option": ([C.c_char_p, C.POINTER(i32)], i32),
         "mp_attn_get_kv": ([p, i32, pp, pp, C.POINTER(i64)], i32),
         "mp_attn_get_key_norm": ([p, i32, pp], i32),
         "mp_attn_get_score": ([p, pp, p], i32),
@@ -95,6 +97,17 @@ def check(rc: int) -> None:
         raise MagicPigError(rc, lib().mp_last_error().decode("utf-8", "replace"))
 
 
+def set_option(name: str, value: int) -> None:
+    """A/B switches of the library (include/magicpig_hip.h: mp_debug_set_option)."""
+    check(lib().mp_debug_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(lib().mp_debug_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
 # ---------------------------------------------------------------- tensor plumbing
 
 def mem_kind(t: torch.Tensor) -> int:
@@ -107,22 +120,31 @@ def ptr(t) -> C.c_void_p:
     return C.c_void_p(t.data_ptr())
 
 
-def current_stream(ref: torch.Tensor | None = None) -> C.c_void_p:
-    """hipStream_t of torch's current stream (so torch events / graphs see our launches)."""
+def current_stream(ref: torch.Tensor | None = None, device: int | None = None) -> C.c_void_p:
+    """hipStream_t of torch's current stream (so torch events / graphs see our launches) on the device of
+    `ref` when it is a CUDA tensor, else on `device` (the handle's own device), else on the current one."""
     if torch.cuda.is_available():
-        dev = ref.device if (ref is not None and ref.is_cuda) else None
+        dev = ref.device if (ref is not None and ref.is_cuda) else device
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     return C.c_void_p(None)
 
 
-def expect(t: torch.Tensor, dtype, shape, name: str) -> torch.Tensor:
-    """The reference casts raw data_ptr() with no checks; we check instead."""
+def current_device() -> int:
+    """Index of the current GPU (0 when there is none: the C ABI then fails with MP_ERR_HIP)."""
+    return torch.cuda.current_device() if torch.cuda.is_available() else 0
+
+
+def expect(t: torch.Tensor, dtype, shape, name: str, same_numel_ok: bool = False) -> torch.Tensor:
+    """The reference casts raw data_ptr() with no checks; we check instead: dtype, the
+    EXACT shape and contiguity.  same_numel_ok is for the one argument the reference's callers pass in two
+    layouts of the same memory (the query: [B*H, D] at models/attnserver.py:274, [B, H, 1, D] in
+    library/sparse_attention/test.py:44)."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor")
     if dtype is not None and t.dtype != dtype:
         raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
     if shape is not None and tuple(t.shape) != tuple(shape):
-        if t.numel() != int(torch.Size(shape).numel()):
+        if not (same_numel_ok and t.numel() == int(torch.Size(shape).numel())):
             raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
     if not t.is_contiguous():
         raise ValueError(f"{name}: tensor must be contiguous")

@@ -77,6 +77,7 @@ class LSHSparseAttnServer:
             self.window_server.alloc(num_layers, num_attention_heads, num_key_value_heads, head_dim,
                                      batch_size, self.length)
         self.kv_last_page_len = torch.zeros((batch_size,), dtype=torch.int32, device=self.device)
+        self._window_rows = [0] * batch_size          # host mirror of kv_last_page_len (overflow check in plan())
         self.window_nnz = torch.zeros((BH,), dtype=torch.int32, device=self.device)
         self.window_out = torch.zeros((BH, head_dim), dtype=torch.bfloat16, device=self.device)
         self.window_mve = torch.zeros((2, BH), dtype=torch.float32, device=self.device)
@@ -100,7 +101,7 @@ class LSHSparseAttnServer:
             wkey = wkey.contiguous()
             self.window_server.fill(layer_idx, request_id, wkey, wval.contiguous(),
                                     wkey.norm(p=2, dim=-1).float())
-        self.kv_last_page_len[request_id] = s + l
+        self.set_window_rows(request_id, s + l)
         # key SimHash (:159-168) -> int16 [Hkv, L, n] on device
         self.hash_code_buffer = self.hasher.keys(offload_key)
         self.attn_server.fill(layer_idx, request_id, offload_key, offload_value, kn)
@@ -122,7 +123,11 @@ class LSHSparseAttnServer:
     def decode(self, query_states: torch.Tensor, layer_idx: int):
         """models/attnserver.py:264-300 on one device: returns (cpu_hidden_states bf16 [B, H, D],
         cpu_lse f32 [B, H]) -- the two operands the reference hands to flashinfer.merge_state
-        (:305-308) -- for the offloaded part of the context."""
+        (:305-308) -- for the offloaded part of the context.
+
+        Both are VIEWS of this server's persistent output buffers (as the reference's self.output_cuda /
+        self.max_value_expsum_cuda are, :302-304): the next decode* call of any layer overwrites them.
+        Clone them to keep per-layer results."""
         BH = self.batch_size * self.num_attention_heads
         q = query_states.reshape(BH, self.head_dim)
         L.expect(q, torch.bfloat16, (BH, self.head_dim), "query_states")
@@ -134,15 +139,42 @@ class LSHSparseAttnServer:
         lse = self.max_value_expsum[1].view(self.batch_size, self.num_attention_heads)
         return out, lse
 
+    def set_window_rows(self, request_id: int, rows: int) -> None:
+        """Number of live rows of request `request_id`'s static window (device counter + host mirror)."""
+        if not 0 <= rows <= self.length:
+            raise ValueError(f"window of request {request_id}: {rows} rows do not fit the {self.length} allocated")
+        self.kv_last_page_len[request_id] = rows
+        self._window_rows[request_id] = rows
+
+    def account_steps(self, steps: int) -> None:
+        """Host-side bookkeeping for callers that advance the device counter WITHOUT calling plan() on the
+        host -- a hipGraph that captured plan() and is replayed `steps` times (or, with steps = -1, the
+        capture itself, which runs plan() on the host but executes nothing on the device).  Raises like
+        plan() when the replays would overflow the window."""
+        rows = [r + steps for r in self._window_rows]
+        full = [b for b, r in enumerate(rows) if r > self.length]
+        if full:
+            raise L.MagicPigError(6, f"static window full: request(s) {full} would hold more than {self.length} rows")
+        self._window_rows = rows
+
     def plan(self) -> None:
-        """models/attnserver.py:196-198: one more token in every request's window this step."""
+        """models/attnserver.py:196-198: one more token in every request's window this step.  The static
+        window holds sink + local + generation_buffer rows (:25): a step past that raises here -- the
+        reference would index past its FlashInfer pages (kv_last_page_len > page_size)."""
+        full = [b for b, r in enumerate(self._window_rows) if r + 1 > self.length]
+        if full:
+            raise L.MagicPigError(6, f"static window full: request(s) {full} already hold {self.length} rows "
+                                     "(num_sink_tokens + num_local_tokens + generation_buffer); "
+                                     "raise generation_buffer")
+        self._window_rows = [r + 1 for r in self._window_rows]
         self.kv_last_page_len += 1
         self.window_nnz.copy_(self.kv_last_page_len.repeat_interleave(self.num_attention_heads))
 
     def decode_full(self, query_states: torch.Tensor, key_states: torch.Tensor,
                     value_states: torch.Tensor, layer_idx: int) -> torch.Tensor:
         """models/attnserver.py:261-312 (sparse-layer branch) entirely on the device: returns
-        hidden_states bf16 [B, 1, H*D].  Call plan() once per step before the first layer."""
+        hidden_states bf16 [B, 1, H*D] (a fresh tensor).  Call plan() once per step before the first layer;
+        plan() raises once the static window (sink + local + generation_buffer rows) is full."""
         B, H, Hkv, D = self.batch_size, self.num_attention_heads, self.num_key_value_heads, self.head_dim
         q = query_states.reshape(B * H, D)
         k = (key_states.reshape(B, Hkv, 1, D) - self.avg_k[layer_idx]).reshape(B, Hkv, D).contiguous()
@@ -160,7 +192,8 @@ class LSHSparseAttnServer:
         """decode_full in two launches instead of four: the append, then ONE kernel in which the exact
         attention over the static window joins the softmax of the LSH-sampled tokens
         (mp_decode_layer_window) -- no window partial, no merge_state.  Falls back to decode_full when
-        the one-launch form does not exist for the shape."""
+        the one-launch form does not exist for the shape.  The result is a VIEW of the persistent output
+        buffer (overwritten by the next decode* call); plan() guards the window's capacity."""
         B, H, Hkv, D = self.batch_size, self.num_attention_heads, self.num_key_value_heads, self.head_dim
         q = query_states.reshape(B * H, D)
         L.expect(q, torch.bfloat16, (B * H, D), "query_states")
@@ -192,8 +225,9 @@ class LSHSparseAttnServer:
         R = va.shape[0]
         v = torch.empty_like(va)
         s = torch.empty_like(sa)
-        L.check(L.lib().mp_merge_state(L.ptr(va), L.ptr(sa), L.ptr(vb), L.ptr(sb), R, D, L.ptr(v),
-                                       L.ptr(s), L.current_stream(va)))
+        with torch.cuda.device(va.device):               # mp_merge_state has no handle: launch where the data is
+            L.check(L.lib().mp_merge_state(L.ptr(va), L.ptr(sa), L.ptr(vb), L.ptr(sb), R, D, L.ptr(v),
+                                           L.ptr(s), L.current_stream(va)))
         return v.view_as(gpu_hidden_states), s.view_as(gpu_lse)
 
     def clear(self) -> None:
@@ -204,6 +238,7 @@ class LSHSparseAttnServer:
         for i in range(self.num_layers):
             self.avg_k[i].zero_()
         self.kv_last_page_len.zero_()
+        self._window_rows = [0] * self.batch_size
         self.window_nnz.zero_()
         self.lsh_retriever.clear()
         self.attn_server.clear()

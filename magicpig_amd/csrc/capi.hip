@@ -1,4 +1,5 @@
 // capi.hip -- the C ABI declared in include/magicpig_hip.h: handle state in HBM + launches.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,6 +61,49 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+// ---- debug / A-B options (mp_debug_set_option): process-wide, read at call time
+struct DebugOptions {
+    std::atomic<int> decode_two_launch{0};   // 1: hash+retrieve launch, then attention launch
+    std::atomic<int> decode_cluster{0};      // 0 = auto, else workgroups per head (clamped to [1, min(8, slices)])
+    std::atomic<int> decode_agent_scope{0};  // 1: cluster hand-off through memory even when the XCD placement was observed
+    std::atomic<int> attn_head_kernel{-1};   // -1 = auto, 0 = split-KV kernel, 1 = one workgroup per head
+    std::atomic<int> attn_gx{0};             // 0 = auto, else split-KV workgroups per head
+};
+static DebugOptions g_opt;
+
+static std::atomic<int>* debug_option(const char* name) {
+    if (!name) return nullptr;
+    if (!strcmp(name, "decode_two_launch")) return &g_opt.decode_two_launch;
+    if (!strcmp(name, "decode_cluster")) return &g_opt.decode_cluster;
+    if (!strcmp(name, "decode_agent_scope")) return &g_opt.decode_agent_scope;
+    if (!strcmp(name, "attn_head_kernel")) return &g_opt.attn_head_kernel;
+    if (!strcmp(name, "attn_gx")) return &g_opt.attn_gx;
+    return nullptr;
+}
+
+// ---- every handle remembers the device that was current when its state was allocated; entry points
+// switch to it for the duration of the call (allocations, launches and memsets then target the owning
+// device whatever the caller's current device is) and restore the caller's device on return
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define MP_ON_DEVICE(h) ::mp::DeviceGuard _device_guard((h) ? (h)->device : -1)
+
+static int current_device() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev;
+}
+
 // ---- small RAII device buffer for staging host arguments
 struct DevBuf {
     void* p = nullptr;
@@ -96,6 +140,7 @@ using namespace mp;
 // =================================================================== handle state
 
 struct mp_simhash {
+    int device = -1;          // device of the planes (current device at mp_simhash_set_planes)
     int D = 0, K = 0, L = 0, KLpad = 0;
     uint16_t* Wt = nullptr;   // [KLpad][D]        plane-major  (MFMA B operand)
     uint16_t* Wk = nullptr;   // [D/8][KLpad][8]   chunk-major  (hash fused into the retrieve)
@@ -104,6 +149,7 @@ struct mp_simhash {
 };
 
 struct mp_lsh {
+    int device = -1;               // device of all state (current device at mp_lsh_alloc)
     bool allocated = false;
     int K = 0, L = 0, NB = 0, layers = 0, H = 0, Hkv = 0, B = 0, G = 0;
     int64_t M = 0;
@@ -122,6 +168,7 @@ struct mp_lsh {
 };
 
 struct mp_attn {
+    int device = -1;               // device of all state (current device at mp_attn_alloc)
     bool allocated = false;
     int layers = 0, H = 0, Hkv = 0, D = 0, B = 0, G = 0;
     int64_t M = 0;
@@ -159,6 +206,7 @@ int mp_simhash_create(mp_simhash_t** out) {
 }
 
 int mp_simhash_destroy(mp_simhash_t* s) {
+    MP_ON_DEVICE(s);
     if (!s) return MP_OK;
     if (s->Wt) (void)hipFree(s->Wt);
     if (s->Wk) (void)hipFree(s->Wk);
@@ -174,6 +222,8 @@ int mp_simhash_set_planes(mp_simhash_t* s, int D, int K, int L, const uint16_t* 
     MP_REQUIRE(simhash_supported(D, K), MP_ERR_UNSUPPORTED,
                "mp_simhash_set_planes: need head_dim % 16 == 0, head_dim <= 256, 1 <= K <= 15");
     hipStream_t st = (hipStream_t)stream;
+    MP_ON_DEVICE(s);                                   // re-setting planes keeps the handle's device
+    if (s->device < 0) s->device = current_device();
     if (s->Wt) { (void)hipFree(s->Wt); s->Wt = nullptr; }
     if (s->Wk) { (void)hipFree(s->Wk); s->Wk = nullptr; }
     if (s->wnorm) { (void)hipFree(s->wnorm); s->wnorm = nullptr; }
@@ -191,8 +241,8 @@ int mp_simhash_set_planes(mp_simhash_t* s, int D, int K, int L, const uint16_t* 
     return MP_OK;
 }
 
-// test hook (not in the public header): route raw MFMA accumulators of the next query calls to
-// a device buffer f32 [R][K*L] so the guard band can be validated against an exact reference.
+// test hook: route raw MFMA accumulators of the next query calls to a device buffer f32 [R][K*L] so
+// the guard band can be validated against an exact reference.
 int mp_simhash_debug_acc(mp_simhash_t* s, float* dev_buf) {
     MP_REQUIRE(s, MP_ERR_INVALID, "mp_simhash_debug_acc: null handle");
     s->dbg_acc = dev_buf;
@@ -201,6 +251,7 @@ int mp_simhash_debug_acc(mp_simhash_t* s, float* dev_buf) {
 
 int mp_simhash_query(mp_simhash_t* s, const uint16_t* q, int R, int32_t* codes, float* qnorm,
                      int mem, mp_stream_t stream) {
+    MP_ON_DEVICE(s);
     MP_REQUIRE(s && s->Wt, MP_ERR_STATE, "mp_simhash_query: planes not set");
     MP_REQUIRE(q && codes && R >= 1, MP_ERR_INVALID, "mp_simhash_query: bad argument");
     hipStream_t st = (hipStream_t)stream;
@@ -224,6 +275,7 @@ int mp_simhash_query(mp_simhash_t* s, const uint16_t* q, int R, int32_t* codes, 
 
 int mp_simhash_keys(mp_simhash_t* s, const uint16_t* keys, int Hkv, int64_t n, int16_t* codes,
                     int mem, mp_stream_t stream) {
+    MP_ON_DEVICE(s);
     MP_REQUIRE(s && s->Wt, MP_ERR_STATE, "mp_simhash_keys: planes not set");
     MP_REQUIRE(keys && codes && Hkv >= 1 && n >= 1, MP_ERR_INVALID, "mp_simhash_keys: bad argument");
     hipStream_t st = (hipStream_t)stream;
@@ -268,6 +320,7 @@ static void lsh_free(mp_lsh_t* h) {
 }
 
 int mp_lsh_destroy(mp_lsh_t* h) {
+    MP_ON_DEVICE(h);
     if (!h) return MP_OK;
     lsh_free(h);
     delete h;
@@ -288,6 +341,7 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
                "mp_lsh_alloc: max_length must be in [1, 2^22]");
     MP_REQUIRE(retrieve_lds_bytes(max_length, L) <= 160 * 1024, MP_ERR_UNSUPPORTED,
                "mp_lsh_alloc: collision bitmaps for max_length do not fit the 160 KiB LDS");
+    h->device = current_device();
     h->K = K; h->L = L; h->NB = 1 << K; h->layers = num_layers;
     h->H = num_attention_heads; h->Hkv = num_key_value_heads; h->B = batch_size;
     h->G = h->H / h->Hkv; h->M = max_length;
@@ -333,6 +387,7 @@ static int lsh_read_err(mp_lsh_t* h, hipStream_t st, const char* who) {
 
 int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted_codes,
                 const int32_t* sorted_ids, int64_t n, int mem, mp_stream_t stream) {
+    MP_ON_DEVICE(h);
     int rc = lsh_check_slot(h, layer_id, request_id, n, "mp_lsh_fill");
     if (rc) return rc;
     MP_REQUIRE(sorted_codes && sorted_ids, MP_ERR_INVALID, "mp_lsh_fill: null argument");
@@ -353,6 +408,7 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
 
 int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes, int64_t n,
                  int mem, mp_stream_t stream) {
+    MP_ON_DEVICE(h);
     int rc = lsh_check_slot(h, layer_id, request_id, n, "mp_lsh_build");
     if (rc) return rc;
     MP_REQUIRE(codes, MP_ERR_INVALID, "mp_lsh_build: null argument");
@@ -370,6 +426,7 @@ int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes
 
 int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32_t* results,
                           int32_t* nnz, int mem, mp_stream_t stream) {
+    MP_ON_DEVICE(h);
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_lsh_batch_retrieve: not allocated");
     MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_lsh_batch_retrieve: layer_id out of range");
     MP_REQUIRE(query && results && nnz, MP_ERR_INVALID, "mp_lsh_batch_retrieve: null argument");
@@ -400,6 +457,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
 }
 
 int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream) {
+    MP_ON_DEVICE(h);
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_lsh_clear: not allocated");
     hipStream_t st = (hipStream_t)stream;
     const size_t groups = (size_t)h->B * h->Hkv;
@@ -412,6 +470,7 @@ int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream) {
 }
 
 int mp_lsh_get_mask(mp_lsh_t* h, int8_t* mask, int mem, mp_stream_t stream) {
+    MP_ON_DEVICE(h);
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_lsh_get_mask: not allocated");
     MP_REQUIRE(mask, MP_ERR_INVALID, "mp_lsh_get_mask: null argument");
     hipStream_t st = (hipStream_t)stream;
@@ -467,6 +526,7 @@ static void attn_free(mp_attn_t* h) {
 }
 
 int mp_attn_destroy(mp_attn_t* h) {
+    MP_ON_DEVICE(h);
     if (!h) return MP_OK;
     attn_free(h);
     delete h;
@@ -485,6 +545,7 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
                MP_ERR_INVALID, "mp_attn_alloc: bad head/layer/batch counts");
     MP_REQUIRE((int64_t)batch_size * num_attention_heads <= 16384, MP_ERR_UNSUPPORTED,
                "mp_attn_alloc: more than 16384 query heads per call");
+    h->device = current_device();
     h->layers = num_layers; h->H = num_attention_heads; h->Hkv = num_key_value_heads;
     h->D = head_dim; h->B = batch_size; h->G = h->H / h->Hkv; h->M = max_length;
     const size_t groups = (size_t)h->B * h->Hkv, BH = (size_t)h->B * h->H;
@@ -513,18 +574,13 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             cus = prop.multiProcessorCount;
         h->cus = cus;
-        h->xcd_rr = xcd_round_robin_verified() && getenv("MP_DECODE_AGENT_SCOPE") == nullptr;
+        h->xcd_rr = xcd_round_robin_verified();
         // with a head (or more) per CU the split-KV machinery only costs: one workgroup per head
         h->head_kernel = (BH * 2 >= cus) && (h->D == 64 || h->D == 128);
-        if (const char* e = getenv("MP_ATTN_HEAD")) h->head_kernel = atoi(e) != 0;   // A/B override
         h->grid = (int)((size_t)cus * 4 / BH);
         if (h->grid < 1) h->grid = 1;
         const int cap = (int)((h->M + 255) / 256);          // never more waves than 64-entry slices
         if (h->grid > cap) h->grid = cap;
-        if (const char* e = getenv("MP_ATTN_GX")) {         // tuning override (scripts/gather_probe.py)
-            const int v = atoi(e);
-            if (v >= 1) h->grid = v;
-        }
     }
     h->allocated = true;
     return MP_OK;
@@ -532,6 +588,7 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
 
 int mp_attn_fill(mp_attn_t* h, int layer_id, int request_id, const uint16_t* k, const uint16_t* v,
                  const float* kn, int64_t n, int mem, mp_stream_t stream) {
+    MP_ON_DEVICE(h);
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_fill: not allocated");
     MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_attn_fill: layer_id out of range");
     MP_REQUIRE(request_id >= 0 && request_id < h->B, MP_ERR_INVALID, "mp_attn_fill: request_id out of range");
@@ -556,6 +613,7 @@ int mp_attn_fill(mp_attn_t* h, int layer_id, int request_id, const uint16_t* k, 
 
 static int attn_append(mp_attn_t* h, int layer_id, const uint16_t* k, const uint16_t* v, const int32_t* pos,
                        int pos_delta, const uint16_t* centre, hipStream_t st, const char* who) {
+    MP_ON_DEVICE(h);
     const std::string w(who);
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, w + ": not allocated");
     MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, w + ": layer_id out of range");
@@ -577,6 +635,7 @@ int mp_attn_append_centred(mp_attn_t* h, int layer_id, const uint16_t* k, const 
 }
 
 int mp_attn_check(mp_attn_t* h, mp_stream_t stream) {
+    MP_ON_DEVICE(h);
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_check: not allocated");
     hipStream_t st = (hipStream_t)stream;
     int flag = 0;
@@ -594,10 +653,14 @@ static int attn_run(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint16
                     float* mve, const void* query, int query_dtype, const float* qn,
                     const int32_t* ind, const int32_t* nnz, hipStream_t st) {
     const int BH = h->B * h->H;
+    bool head_kernel = h->head_kernel;                       // A/B overrides (mp_debug_set_option)
+    if (const int o = g_opt.attn_head_kernel.load(); o >= 0) head_kernel = o != 0 && (h->D == 64 || h->D == 128);
+    int grid = h->grid;
+    if (const int o = g_opt.attn_gx.load(); o >= 1) grid = o;
     MP_HIP_CHECK(launch_attn_sparse(h->D, dense, query_dtype == MP_DTYPE_BF16, h->kv[layer_id],
                                     h->kn[layer_id], query, qn, ind, nnz, h->part_o, h->part_ml,
                                     h->head_cnt, output, mve, h->head_mz, h->score, BH, h->G, h->M, K, L,
-                                    h->grid, h->head_kernel, st));
+                                    grid, head_kernel, st));
     h->lastz = nnz;
     h->score_state = 1;
     return MP_OK;
@@ -607,6 +670,7 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
                       float* mve, const void* query, int query_dtype, const float* qn,
                       const int32_t* ind, const int32_t* nnz, int mem, hipStream_t st,
                       const char* who) {
+    MP_ON_DEVICE(h);
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, std::string(who) + ": not allocated");
     MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, std::string(who) + ": layer_id out of range");
     MP_REQUIRE(output && mve && query && nnz && (dense || (qn && ind)), MP_ERR_INVALID,
@@ -666,6 +730,7 @@ int mp_attn_full(mp_attn_t* h, int layer_id, uint16_t* output, float* max_value_
 }
 
 int mp_attn_clear(mp_attn_t* h, mp_stream_t stream) {
+    MP_ON_DEVICE(h);
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_clear: not allocated");
     hipStream_t st = (hipStream_t)stream;
     const size_t groups = (size_t)h->B * h->Hkv, BH = (size_t)h->B * h->H;
@@ -687,6 +752,20 @@ int mp_debug_set_stamp_buffer(void* dev_u64x64) {
 
 int mp_debug_xcd_round_robin(void) { return xcd_round_robin_verified() ? 1 : 0; }
 
+int mp_debug_set_option(const char* name, int value) {
+    std::atomic<int>* o = debug_option(name);
+    MP_REQUIRE(o != nullptr, MP_ERR_INVALID, std::string("mp_debug_set_option: unknown option '") + (name ? name : "(null)") + "'");
+    o->store(value);
+    return MP_OK;
+}
+
+int mp_debug_get_option(const char* name, int* value) {
+    std::atomic<int>* o = debug_option(name);
+    MP_REQUIRE(o != nullptr && value != nullptr, MP_ERR_INVALID, "mp_debug_get_option: unknown option or null value");
+    *value = o->load();
+    return MP_OK;
+}
+
 int mp_attn_get_kv(mp_attn_t* h, int layer_id, void** key_dev, void** value_dev,
                    int64_t* row_stride_elems) {
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_get_kv: not allocated");
@@ -705,6 +784,7 @@ int mp_attn_get_key_norm(mp_attn_t* h, int layer_id, void** kn_dev) {
 }
 
 int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream) {
+    MP_ON_DEVICE(h);
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_get_score: not allocated");
     MP_REQUIRE(score_dev, MP_ERR_INVALID, "mp_attn_get_score: null argument");
     hipStream_t st = (hipStream_t)stream;
@@ -723,8 +803,11 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
                         const uint16_t* q, const int32_t* win_len, uint16_t* output, float* max_value_expsum,
                         int32_t* nnz_out, hipStream_t st, const char* who) {
     const std::string w(who);
+    MP_ON_DEVICE(attn);
     MP_REQUIRE(s && s->Wt, MP_ERR_STATE, w + ": SimHash planes not set");
     MP_REQUIRE(lsh && lsh->allocated && attn && attn->allocated, MP_ERR_STATE, w + ": handles not allocated");
+    MP_REQUIRE(s->device == attn->device && lsh->device == attn->device && (!win || win->device == attn->device),
+               MP_ERR_INVALID, w + ": the handles live on different devices");
     MP_REQUIRE(q && output && max_value_expsum, MP_ERR_INVALID, w + ": null argument");
     MP_REQUIRE(lsh->B == attn->B && lsh->H == attn->H && lsh->Hkv == attn->Hkv && lsh->M == attn->M &&
                    s->K == lsh->K && s->L == lsh->L && s->D == attn->D,
@@ -734,7 +817,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
     const int BH = lsh->B * lsh->H;
     lsh->lastq = lsh->codes;
     lsh->last_layer = layer_id;
-    static const bool two_launch = getenv("MP_DECODE_TWO_LAUNCH") != nullptr;   // A/B switch
+    const bool two_launch = g_opt.decode_two_launch.load() != 0;                // A/B switch
     const bool fused = !two_launch && lsh_decode_supported(lsh->M, lsh->L, s->D);
     if (win != nullptr) {
         MP_REQUIRE(win->allocated && win_len, MP_ERR_INVALID, w + ": window store not allocated / null win_len");
@@ -753,16 +836,16 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         if (cluster > 8) cluster = 8;     // measured: 16 and 32 members lose more in the hand-off and in L2 plane traffic than they gain
         if (cluster > attn_slices_per_head(attn->M)) cluster = attn_slices_per_head(attn->M);
         if (cluster < 1) cluster = 1;
-        static const int cluster_override = [] {           // A/B switch, read once
-            const char* e = getenv("MP_DECODE_CLUSTER");
-            return e ? atoi(e) : 0;
-        }();
-        if (cluster_override >= 1) cluster = cluster_override;
+        if (const int o = g_opt.decode_cluster.load(); o >= 1) {      // A/B switch, clamped like the default
+            cluster = o > 8 ? 8 : o;
+            if (cluster > attn_slices_per_head(attn->M)) cluster = attn_slices_per_head(attn->M);
+        }
         MP_HIP_CHECK(launch_lsh_decode(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk, s->wnorm, s->D,
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
                                        attn->head_cnt, output, max_value_expsum, attn->head_mz, attn->score,
-                                       attn_slices_per_head(attn->M), cluster, attn->xcd_rr,
+                                       attn_slices_per_head(attn->M), cluster,
+                                       attn->xcd_rr && g_opt.decode_agent_scope.load() == 0,
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
                                        lsh->L, lsh->NB, lsh->M, st));
         attn->lastz = lsh->nnz;

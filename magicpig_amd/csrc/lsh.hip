@@ -18,6 +18,8 @@
 // than the returning atomics; the phase is bound by streaming ~64 KB of ids through one CU)
 // ASCENDING token order (the reference emits second-hit order; only set + nnz are defined,
 // library/lsh/test.py:43-56).
+#include <mutex>
+
 #include "common.h"
 #include "attn_head.h"
 
@@ -805,6 +807,24 @@ __global__ __launch_bounds__(256) void lsh_mask_kernel(
 }
 
 // ---------------------------------------------------------------- host launchers
+// run `fn` once per (process, current device), serialised: function attributes are per device
+struct DeviceOnce {
+    std::mutex mu;
+    bool done[64] = {};
+    template <typename F>
+    hipError_t run(F&& fn) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        std::lock_guard<std::mutex> lock(mu);
+        if (done[dev]) return hipSuccess;
+        e = fn();
+        if (e == hipSuccess) done[dev] = true;
+        return e;
+    }
+};
+
 size_t retrieve_lds_bytes(int64_t M, int L) {
     const int Lpad = (L + 63) & ~63;
     // + fused-hash scratch: 128 words of query, 4 of norm, sign bits of up to 16*L planes (+ ballot slack)
@@ -832,18 +852,19 @@ static bool build_staged_geometry(int NB, int& nw, int& tpl, size_t& lds) {
 
 hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, int64_t M,
                             int2* bounds, int32_t* table, int* err, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce once;
+    const hipError_t attr_err = once.run([] {
         const void* fns[] = {reinterpret_cast<const void*>(lsh_build_kernel<8>),
                              reinterpret_cast<const void*>(lsh_build_kernel<16>),
                              reinterpret_cast<const void*>(lsh_build_kernel<32>),
                              reinterpret_cast<const void*>(lsh_build_direct_kernel)};
         for (const void* f : fns) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
-        attr_done = true;
-    }
+        return hipSuccess;
+    });
+    if (attr_err != hipSuccess) return attr_err;
     if (n > INT32_MAX || NB > BUILD_LDS_COUNTERS) return hipErrorInvalidValue;
     int nbits = 0;
     while ((1 << nbits) < NB) ++nbits;
@@ -874,9 +895,11 @@ __global__ void xcc_probe_kernel(int* __restrict__ out) {
 }
 
 bool xcd_round_robin_verified() {
+    static std::mutex mu;
     static int states[64];   // per device: 0 unknown, 1 no, 2 yes
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(mu);
     int& state = states[dev];
     if (state != 0) return state == 2;
     state = 1;
@@ -912,9 +935,7 @@ static size_t decode_lds_bytes(int64_t M, int L, int D) {
     return retrieve_lds_bytes(M, L) + ((size_t)DECODE_ID_CAP + attn_head_lds_floats(RT_WAVES, D) + 16 + 64) * 4;
 }
 
-static hipError_t retrieve_attr_once() {
-    static bool attr_done = false;
-    if (attr_done) return hipSuccess;
+static hipError_t retrieve_attr_set() {
     const void* fns[] = {reinterpret_cast<const void*>(lsh_retrieve_kernel<false, 16>),
                          reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 16>),
                          reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 8>),
@@ -926,8 +947,12 @@ static hipError_t retrieve_attr_once() {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    attr_done = true;
     return hipSuccess;
+}
+
+static hipError_t retrieve_attr_once() {
+    static DeviceOnce once;
+    return once.run(retrieve_attr_set);
 }
 
 hipError_t launch_lsh_retrieve(const int2* bounds, const int32_t* table, const int32_t* query,

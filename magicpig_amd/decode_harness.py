@@ -228,10 +228,12 @@ def run_decode_benchmark(decoder: SyntheticLlamaDecoder, prompt_len: int, warmup
         with torch.cuda.graph(graph):
             decoder.inference(s_ids, s_pos)
         # (a capture records the step without executing it: lengths advance only on replay)
+        decoder.attention_server.account_steps(-1)
 
     def one(i):
         if graph is not None:
             s_ids.copy_(ids[:, i:i + 1]); s_pos.copy_(pos[:, i:i + 1])
+            decoder.attention_server.account_steps(1)     # the replayed plan() advances the device counter
             graph.replay()
         else:
             decoder.inference(ids[:, i:i + 1], pos[:, i:i + 1])

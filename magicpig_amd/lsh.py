@@ -34,6 +34,7 @@ class LSH:
         self.H, self.Hkv, self.B, self.M = (num_attention_heads, num_key_value_heads, batch_size,
                                             max_length)
         self.NB = 1 << K
+        self._device = L.current_device()      # the handle's state lives here (the C ABI switches to it)
         self._alloc = True
 
     def fill(self, layer_id: int, request_id: int, sorted_hash_code: torch.Tensor,
@@ -44,7 +45,7 @@ class LSH:
         L.expect(sorted_indices, torch.int32, (self.Hkv, self.L, n), "sorted_indices")
         mem = L.same_memory(sorted_hash_code, sorted_indices)
         L.check(L.lib().mp_lsh_fill(self._h, layer_id, request_id, L.ptr(sorted_hash_code),
-                                    L.ptr(sorted_indices), n, mem, L.current_stream(sorted_hash_code)))
+                                    L.ptr(sorted_indices), n, mem, L.current_stream(sorted_hash_code, self._device)))
 
     def fastfill(self, layer_id: int, request_id: int, hash_code: torch.Tensor) -> None:
         """Working version of LSH::fastfill (lsh.cc:93-142, unfinished in the reference): builds
@@ -52,7 +53,7 @@ class LSH:
         n = hash_code.shape[-1]
         L.expect(hash_code, torch.int16, (self.Hkv, self.L, n), "hash_code")
         L.check(L.lib().mp_lsh_build(self._h, layer_id, request_id, L.ptr(hash_code), n,
-                                     L.mem_kind(hash_code), L.current_stream(hash_code)))
+                                     L.mem_kind(hash_code), L.current_stream(hash_code, self._device)))
 
     def batch_retrieve(self, layer_id: int, query: torch.Tensor, results: torch.Tensor,
                        nnz: torch.Tensor) -> None:
@@ -64,11 +65,11 @@ class LSH:
         L.expect(nnz, torch.int32, (BH,), "nnz")
         mem = L.same_memory(query, results, nnz)
         L.check(L.lib().mp_lsh_batch_retrieve(self._h, layer_id, L.ptr(query), L.ptr(results),
-                                              L.ptr(nnz), mem, L.current_stream(query)))
+                                              L.ptr(nnz), mem, L.current_stream(query, self._device)))
 
     def clear(self) -> None:
         """LSH::clear, lsh.cc:293-306."""
-        L.check(L.lib().mp_lsh_clear(self._h, L.current_stream()))
+        L.check(L.lib().mp_lsh_clear(self._h, L.current_stream(device=self._device)))
 
     def copy(self, query: torch.Tensor) -> None:
         """LSH::copy, lsh.cc:203-207: empty in the reference; kept for API parity."""
@@ -78,7 +79,7 @@ class LSH:
         """LSH::get_mask, lsh.cc:308-314: int8 [B,H,M] collision counters min(count,2) of the last
         batch_retrieve (recomputed on demand; returned as a CPU tensor like the reference's)."""
         out = torch.zeros((self.B, self.H, self.M), dtype=torch.int8)
-        L.check(L.lib().mp_lsh_get_mask(self._h, L.ptr(out), L.MEM_HOST, L.current_stream()))
+        L.check(L.lib().mp_lsh_get_mask(self._h, L.ptr(out), L.MEM_HOST, L.current_stream(device=self._device)))
         return out
 
     # debug views (declared but never defined in the reference, lsh.h:24-26)
@@ -86,6 +87,7 @@ class LSH:
         b, t = C.c_void_p(), C.c_void_p()
         L.check(L.lib().mp_lsh_get_tables(self._h, layer_id, C.byref(b), C.byref(t)))
         groups = self.B * self.Hkv
-        bounds = L.device_tensor(b.value, (groups, self.L, self.NB, 2), "<i4")
-        table = L.device_tensor(t.value, (groups, self.L, self.M), "<i4")
+        dev = torch.device("cuda", self._device)
+        bounds = L.device_tensor(b.value, (groups, self.L, self.NB, 2), "<i4", device=dev)
+        table = L.device_tensor(t.value, (groups, self.L, self.M), "<i4", device=dev)
         return bounds, table

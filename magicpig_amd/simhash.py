@@ -17,8 +17,11 @@ class SimHash:
         self._h = C.c_void_p()
         L.check(L.lib().mp_simhash_create(C.byref(self._h)))
         self.D, self.K, self.L = D, K, L_
-        L.check(L.lib().mp_simhash_set_planes(self._h, D, K, L_, L.ptr(hash_func),
-                                              L.mem_kind(hash_func), L.current_stream(hash_func)))
+        # the planes live on hash_func's device when it is a CUDA tensor, else on the current device
+        self._device = hash_func.device.index if hash_func.is_cuda else L.current_device()
+        with torch.cuda.device(self._device):
+            L.check(L.lib().mp_simhash_set_planes(self._h, D, K, L_, L.ptr(hash_func),
+                                                  L.mem_kind(hash_func), L.current_stream(hash_func, self._device)))
 
     def __del__(self):
         try:
@@ -43,7 +46,7 @@ class SimHash:
         L.expect(qnorm, torch.float32, (R,), "qnorm")
         mem = L.same_memory(q2, codes, qnorm)
         L.check(L.lib().mp_simhash_query(self._h, L.ptr(q2), R, L.ptr(codes), L.ptr(qnorm), mem,
-                                         L.current_stream(q2)))
+                                         L.current_stream(q2, self._device)))
         return codes, qnorm
 
     def keys(self, keys: torch.Tensor, codes: torch.Tensor | None = None) -> torch.Tensor:
@@ -55,7 +58,7 @@ class SimHash:
         L.expect(codes, torch.int16, (Hkv, self.L, n), "codes")
         mem = L.same_memory(keys, codes)
         L.check(L.lib().mp_simhash_keys(self._h, L.ptr(keys), Hkv, n, L.ptr(codes), mem,
-                                        L.current_stream(keys)))
+                                        L.current_stream(keys, self._device)))
         return codes
 
     def _debug_acc(self, buf: torch.Tensor | None) -> None:

@@ -32,6 +32,7 @@ class SparseAttentionServer:
         self.num_layers = num_layers
         self.H, self.Hkv, self.D, self.B, self.M = (num_attention_heads, num_key_value_heads,
                                                     head_dim, batch_size, max_length)
+        self._device = L.current_device()      # the handle's state lives here (the C ABI switches to it)
 
     def fill(self, layer_id: int, request_id: int, k: torch.Tensor, v: torch.Tensor,
              kn: torch.Tensor) -> None:
@@ -42,7 +43,7 @@ class SparseAttentionServer:
         L.expect(kn, torch.float32, (self.Hkv, n), "kn")
         mem = L.same_memory(k, v, kn)
         L.check(L.lib().mp_attn_fill(self._h, layer_id, request_id, L.ptr(k), L.ptr(v), L.ptr(kn), n,
-                                     mem, L.current_stream(k)))
+                                     mem, L.current_stream(k, self._device)))
 
     def attention_wrapper(self, layer_id: int, K: int, L_: int, output: torch.Tensor,
                           max_value_expsum: torch.Tensor, query: torch.Tensor,
@@ -56,7 +57,7 @@ class SparseAttentionServer:
         L.expect(max_value_expsum, torch.float32, (2, BH), "max_value_expsum")
         if query.dtype not in (torch.bfloat16, torch.float32):
             query = query.float()
-        L.expect(query, None, (BH, self.D), "query")
+        L.expect(query, None, (BH, self.D), "query", same_numel_ok=True)
         L.expect(query_norm, torch.float32, (BH,), "query_norm")
         L.expect(ind, torch.int32, (BH, self.M), "ind")
         L.expect(nnz, torch.int32, (BH,), "nnz")
@@ -64,7 +65,7 @@ class SparseAttentionServer:
         qd = L.DTYPE_BF16 if query.dtype == torch.bfloat16 else L.DTYPE_F32
         L.check(L.lib().mp_attn_sparse(self._h, layer_id, K, L_, L.ptr(output), L.ptr(max_value_expsum),
                                        L.ptr(query), qd, L.ptr(query_norm), L.ptr(ind), L.ptr(nnz),
-                                       mem, L.current_stream(output)))
+                                       mem, L.current_stream(output, self._device)))
 
     # every reference variant computes the same function (sparse_attention.cc:748-986, 1039-1211)
     attention = attention_wrapper
@@ -80,12 +81,12 @@ class SparseAttentionServer:
         L.expect(max_value_expsum, torch.float32, (2, BH), "max_value_expsum")
         if query.dtype not in (torch.bfloat16, torch.float32):
             query = query.float()
-        L.expect(query, None, (BH, self.D), "query")
+        L.expect(query, None, (BH, self.D), "query", same_numel_ok=True)
         L.expect(nnz, torch.int32, (BH,), "nnz")
         mem = L.same_memory(output, max_value_expsum, query, nnz)
         qd = L.DTYPE_BF16 if query.dtype == torch.bfloat16 else L.DTYPE_F32
         L.check(L.lib().mp_attn_full(self._h, layer_id, L.ptr(output), L.ptr(max_value_expsum),
-                                     L.ptr(query), qd, L.ptr(nnz), mem, L.current_stream(output)))
+                                     L.ptr(query), qd, L.ptr(nnz), mem, L.current_stream(output, self._device)))
 
     def append(self, layer_id: int, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor) -> None:
         """Not in the reference class: the role of flashinfer.append_paged_kv_cache
@@ -96,7 +97,7 @@ class SparseAttentionServer:
         L.expect(pos, torch.int32, (self.B,), "pos")
         if not (k.is_cuda and v.is_cuda and pos.is_cuda):
             raise ValueError("append takes CUDA tensors")
-        L.check(L.lib().mp_attn_append(self._h, layer_id, L.ptr(k), L.ptr(v), L.ptr(pos), L.current_stream(k)))
+        L.check(L.lib().mp_attn_append(self._h, layer_id, L.ptr(k), L.ptr(v), L.ptr(pos), L.current_stream(k, self._device)))
 
     def append_centred(self, layer_id: int, k: torch.Tensor, v: torch.Tensor, centre: torch.Tensor,
                        pos: torch.Tensor, pos_delta: int = 0) -> None:
@@ -109,15 +110,15 @@ class SparseAttentionServer:
         if not (k.is_cuda and v.is_cuda and pos.is_cuda and centre.is_cuda):
             raise ValueError("append_centred takes CUDA tensors")
         L.check(L.lib().mp_attn_append_centred(self._h, layer_id, L.ptr(k), L.ptr(v), L.ptr(centre), L.ptr(pos),
-                                               pos_delta, L.current_stream(k)))
+                                               pos_delta, L.current_stream(k, self._device)))
 
     def check(self) -> None:
         """Raise if a device-side validation failed since the last check (append past max_length)."""
-        L.check(L.lib().mp_attn_check(self._h, L.current_stream()))
+        L.check(L.lib().mp_attn_check(self._h, L.current_stream(device=self._device)))
 
     def clear(self) -> None:
         """SparseAttentionServer::clear, sparse_attention.cc:586-598."""
-        L.check(L.lib().mp_attn_clear(self._h, L.current_stream()))
+        L.check(L.lib().mp_attn_clear(self._h, L.current_stream(device=self._device)))
 
     # ---- views of handle-owned HBM (sparse_attention.cc:1213-1241); K|V are interleaved per
     # token in HBM, so the key/value caches come back as strided (non-contiguous) CUDA views.
@@ -126,7 +127,7 @@ class SparseAttentionServer:
         L.check(L.lib().mp_attn_get_kv(self._h, layer_id, C.byref(k), C.byref(v), C.byref(stride)))
         rs = stride.value * 2
         t = L.device_tensor((k.value, v.value)[which], (self.B, self.Hkv, self.M, self.D), "<i2",
-                            (self.Hkv * self.M * rs, self.M * rs, rs, 2))
+                            (self.Hkv * self.M * rs, self.M * rs, rs, 2), device=torch.device("cuda", self._device))
         return t.view(torch.bfloat16)
 
     def get_key_cache(self, layer_id: int) -> torch.Tensor:
@@ -138,11 +139,11 @@ class SparseAttentionServer:
     def get_key_norm(self, layer_id: int) -> torch.Tensor:
         p = C.c_void_p()
         L.check(L.lib().mp_attn_get_key_norm(self._h, layer_id, C.byref(p)))
-        return L.device_tensor(p.value, (self.B, self.Hkv, self.M), "<f4")
+        return L.device_tensor(p.value, (self.B, self.Hkv, self.M), "<f4", device=torch.device("cuda", self._device))
 
     def get_score(self) -> torch.Tensor:
         """get_score, sparse_attention.cc:1235-1241: f32 [B,H,M] probabilities of the last call
         (first nnz entries per head, in `ind` order)."""
         p = C.c_void_p()
-        L.check(L.lib().mp_attn_get_score(self._h, C.byref(p), L.current_stream()))
-        return L.device_tensor(p.value, (self.B, self.H, self.M), "<f4")
+        L.check(L.lib().mp_attn_get_score(self._h, C.byref(p), L.current_stream(device=self._device)))
+        return L.device_tensor(p.value, (self.B, self.H, self.M), "<f4", device=torch.device("cuda", self._device))

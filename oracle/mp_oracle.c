@@ -389,11 +389,21 @@ void mpo_sparse_attention(const uint16_t* key, const uint16_t* value, const floa
  * decode attention over rows [0, nnz) of each kv head for its G query heads.  The reference
  * indexes nnz by kv-head loop index for QK/PV and by head for softmax (.cc:1010,1018,1032);
  * callers fill all entries equal (models/attnserver.py:470) and so does every test, so the
- * oracle uses nnz[h].  exp is exact here.
+ * oracle uses nnz[h].
+ *
+ * PINNED against the compiled reference by tests/golden/full_dense.npz (G in {1, 4, 8},
+ * nnz in {0, 1, 15, 16, 63, 64, 65, ...}).  `quirks` reproduces what the reference does beyond
+ * the definition, so that the pin also holds where the two differ:
+ *   bit 0: exp by the reference's polynomial (avx512_exp_ps, as exp_mode bit 0 of the sparse path);
+ *   bit 1: softmax_kernel_optimized walks round_up(nnz, 16) score slots with a full 16-lane mask
+ *          (:249-283: `i < nnz ? 0xFFFF : ...` is always true at a block start), i.e. it also counts
+ *          the up-to-15 slots behind the list with whatever the score buffer holds there (zeros on
+ *          a fresh server, .cc:579-580) in max and sum, and overwrites them; P.V uses nnz rows.
+ * quirks = 0 is the definition (exact exp, exactly nnz rows) the HIP path is checked against.
  */
 void mpo_full_attention(const uint16_t* key, const uint16_t* value, const float* query,
                         const int32_t* nnz, int BH, int G, int D, int64_t M, uint16_t* output,
-                        float* max_value_expsum, float* score, int nthreads) {
+                        float* max_value_expsum, float* score, int quirks, int nthreads) {
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
 #endif
@@ -413,19 +423,27 @@ void mpo_full_attention(const uint16_t* key, const uint16_t* value, const float*
             max_value_expsum[BH + h] = -INFINITY;
             continue;
         }
+        int64_t ns = n;                                  /* slots the softmax covers */
+        if (quirks & 2) {
+            ns = (n + 15) & ~(int64_t)15;
+            if (ns > M) ns = M;
+        }
         float m = -INFINITY;
-        for (int64_t j = 0; j < n; ++j) {
-            float acc = 0.f;
-            for (int d = 0; d < D; ++d) acc += q[d] * bf16_to_f32(kk[j * D + d]);
-            s[j] = acc * scale;
+        for (int64_t j = 0; j < ns; ++j) {
+            if (j < n) {
+                float acc = 0.f;
+                for (int d = 0; d < D; ++d) acc += q[d] * bf16_to_f32(kk[j * D + d]);
+                s[j] = acc;
+            }                                            /* else: stale slot, raw score as found */
+            s[j] *= scale;
             m = fmaxf(m, s[j]);
         }
         float sum = 0.f;
-        for (int64_t j = 0; j < n; ++j) {
-            s[j] = expf(s[j] - m);
+        for (int64_t j = 0; j < ns; ++j) {
+            s[j] = (quirks & 1) ? ref_poly_exp(s[j] - m) : expf(s[j] - m);
             sum += s[j];
         }
-        for (int64_t j = 0; j < n; ++j) s[j] /= sum;
+        for (int64_t j = 0; j < ns; ++j) s[j] /= sum;
         max_value_expsum[h] = (float)(m * M_LOG2E);
         max_value_expsum[BH + h] = log2f(sum) + max_value_expsum[h];
         for (int d = 0; d < D; ++d) {
@@ -439,11 +457,15 @@ void mpo_full_attention(const uint16_t* key, const uint16_t* value, const float*
 /* ------------------------------------------------------------------ a-13 LSE merge */
 
 /*
- * flashinfer.merge_state as used at models/attnserver.py:308; FlashInfer is not in
- * /root/reference (un-vendored, unpinned wheel; install.sh:4) -- PARITY UNPINNED for this
- * function.  The math is restated from the in-tree torch statement
- * evaluations/RULER/pred/attnserver_dist.py:848-849,882:
- *   s = log2(2^a + 2^b);  v = (2^a v_a + 2^b v_b) / 2^s        (base-2 LSEs)
+ * flashinfer.merge_state as used at models/attnserver.py:308; FlashInfer is a third-party
+ * dependency absent from /root/reference (un-vendored, unpinned wheel; install.sh:4).  Its
+ * published definition on base-2 LSEs (the ones run_return_lse returns and the reference converts
+ * its own to, evaluations/RULER/pred/attnserver_dist.py:848-849) is
+ *   s = log2(2^a + 2^b);  v = (2^a v_a + 2^b v_b) / 2^s
+ * PINNED by tests/golden/window_merge.npz: a committed torch-CPU statement of the reference's call
+ * site (attnserver_dist.py:813-851, 882; models/attnserver.py:293-308) including the property that
+ * defines the operator -- merge(window part, sampled part) equals ONE softmax attention over the
+ * union of the two token sets (tests/golden/make_golden.py: run_window_merge).
  * va, vb: bf16 [R, D]; sa, sb: f32 [R]; v: bf16 [R, D] (RNE); s: f32 [R].
  */
 void mpo_merge_state(const uint16_t* va, const float* sa, const uint16_t* vb, const float* sb,

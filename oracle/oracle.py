@@ -66,7 +66,7 @@ def lib() -> C.CDLL:
         L.mpo_lsh_batch_retrieve.argtypes = [p, p, p, p, i32, i32, i32, i32, i64, p, p, p, i32]
         L.mpo_sparse_attention.argtypes = [p, p, p, p, i32, p, p, p, i32, i32, i32, i64, i32,
                                            i32, i32, i32, p, p, p, i32]
-        L.mpo_full_attention.argtypes = [p, p, p, p, i32, i32, i32, i64, p, p, p, i32]
+        L.mpo_full_attention.argtypes = [p, p, p, p, i32, i32, i32, i64, p, p, p, i32, i32]
         L.mpo_merge_state.argtypes = [p, p, p, p, i32, i32, p, p]
         for fn in ("mpo_simhash_query", "mpo_simhash_keys", "mpo_lsh_fill",
                    "mpo_lsh_batch_retrieve", "mpo_sparse_attention", "mpo_full_attention",
@@ -154,7 +154,7 @@ def simhash_keys(keys, hash_func, K: int, L: int) -> np.ndarray:
 
 
 def merge_state(va, sa, vb, sb):
-    """flashinfer.merge_state restated (models/attnserver.py:308; PARITY UNPINNED)."""
+    """flashinfer.merge_state restated (models/attnserver.py:308; pinned by tests/golden/window_merge.npz)."""
     a = bf16_bits(va)
     b = bf16_bits(vb)
     R, D = a.reshape(-1, a.shape[-1]).shape
@@ -306,8 +306,9 @@ class SparseAttentionServer:
     attention_bf16 = _sparse
     attention_wrapper_bf16 = _sparse
 
-    def full_attention(self, layer_id, output, max_value_expsum, query, nnz):
-        # library/sparse_attention/sparse_attention.cc:988-1037
+    def full_attention(self, layer_id, output, max_value_expsum, query, nnz, quirks: int = 0):
+        # library/sparse_attention/sparse_attention.cc:988-1037; quirks: see mp_oracle.c (bit 0 the
+        # reference's polynomial exp, bit 1 its 16-slot softmax tail); 0 = the definition
         BH = self.B * self.H
         out = _np_view(output)
         mve = _np_view(max_value_expsum, "float32")
@@ -319,7 +320,7 @@ class SparseAttentionServer:
         lib().mpo_full_attention(_ptr(self.key_cache[layer_id]),
                                  _ptr(self.value_cache[layer_id]), _ptr(q), _ptr(z), BH,
                                  self.G, self.D, self.M, _ptr(out), _ptr(mve),
-                                 _ptr(self.attention_score), self.nthreads)
+                                 _ptr(self.attention_score), int(quirks), self.nthreads)
 
     def clear(self):
         # library/sparse_attention/sparse_attention.cc:586-598

@@ -35,6 +35,21 @@ def case_inputs(seed, B, H, Hkv, n, D, K, L):
     return np.stack(keys), np.stack(kns), np.stack(vals), W, qb
 
 
+def check_sign_ties(g: dict, kcodes: np.ndarray, K: int) -> None:
+    """The key codes of a fixture are the sign bits of the EXACT dot products; `kcodes_ties` lists the
+    (b, g, l, t, bit, torch_bit) where torch's bf16 GEMM -- f32 accumulation in the library's order --
+    landed on the other side of zero (make_golden.exact_sign_ties): a rounding-level handful out of
+    10^8, exact value zero or ~1e-7.  Checks the list is that small and that `kcodes` holds the exact sign
+    there, i.e. the complement of what torch's summation order happened to give."""
+    ties = g.get("kcodes_ties")
+    if ties is None or len(ties) == 0:
+        return
+    assert len(ties) <= 1e-7 * kcodes.size * K + 1
+    assert np.abs(g["kcodes_tie_dots"]).max() < 1e-5
+    for (b, gg, l, t, bit, torch_bit), dot in zip(ties, g["kcodes_tie_dots"]):
+        assert (int(kcodes[b, gg, l, t]) >> bit) & 1 == int(dot > 0) == 1 - torch_bit
+
+
 def stable_sort_codes(codes: np.ndarray):
     """torch.sort(stable=True) along the token axis -> (sorted int16 codes, int32 ids)."""
     order = np.argsort(codes, axis=-1, kind="stable").astype(np.int32)
@@ -55,3 +70,38 @@ def dense_mask_counts(kcodes: np.ndarray, qcodes: np.ndarray, G: int) -> np.ndar
     for h in range(BH):
         out[h] = (kcodes[h // G] == qcodes[h][:, None].astype(kcodes.dtype)).sum(0)
     return out
+
+
+# ---- dense fixture (tests/golden/full_dense.npz): (tag, B, H, Hkv, n, M, nnz values).  D = 128 only: the
+# reference's wv_kernel_dim128_full hard-codes eight 16-lane chunks (sparse_attention.cc:400-402,
+# 441-449) and group sizes 1, 4, 8 (:395-397) -- the grid of library/sparse_attention/test_dense.py:8-14.
+FULL_DENSE_CASES = [
+    ("g1", 1, 4, 4, 200, 264, [0, 1, 16, 63, 64, 65, 200]),
+    ("g4", 2, 8, 2, 300, 320, [1, 48, 63, 64, 65, 257, 300]),
+    ("g8", 1, 8, 1, 1024, 1153, [15, 64, 1000, 1024]),
+]
+
+
+def full_dense_seed(seed, tag, H):
+    return seed + len(tag) * 100 + H
+
+
+def full_dense_inputs(seed, B, H, Hkv, n, D):
+    keys = np.stack([synth.normal_bf16_bits(seed + 10 * b, (Hkv, n, D)) for b in range(B)])
+    vals = np.stack([synth.normal_bf16_bits(seed + 10 * b + 1, (Hkv, n, D)) for b in range(B)])
+    q = synth.normal_f32(seed + 3, (B * H, D))
+    return keys, vals, q
+
+
+# ---- window + LSE merge fixture (tests/golden/window_merge.npz, SURVEY f-2)
+WINDOW_MERGE = dict(seed=61, B=2, H=8, Hkv=2, D=128, K=8, L=60, n=1500, M=1600, win_rows=(75, 70), win_M=96)
+
+
+def window_merge_inputs(c):
+    """Offloaded part as case_inputs; a static window of win_rows[b] rows per request (sink + local +
+    generated tokens, already centred), the last row of which is this step's own (k, v)."""
+    seed, B, H, Hkv, D, K, L, n = (c[k] for k in ("seed", "B", "H", "Hkv", "D", "K", "L", "n"))
+    keys, kns, vals, W, qb = case_inputs(seed, B, H, Hkv, n, D, K, L)
+    wk = [synth.normal_bf16_bits(seed + 100 + b, (Hkv, c["win_rows"][b], D)) for b in range(B)]
+    wv = [synth.normal_bf16_bits(seed + 200 + b, (Hkv, c["win_rows"][b], D)) for b in range(B)]
+    return keys, kns, vals, W, qb, wk, wv

@@ -30,6 +30,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import synth  # noqa: E402
+from cases import (FULL_DENSE_CASES, WINDOW_MERGE, full_dense_inputs, full_dense_seed,  # noqa: E402
+                   window_merge_inputs)
 from oracle.build_ref import load_ref, ref_uses_bf16_family  # noqa: E402
 
 
@@ -81,12 +83,41 @@ def case_inputs(seed, B, H, Hkv, n, D, K, L):
     return np.stack(keys), np.stack(kns), np.stack(vals), W, qb
 
 
+def exact_sign_ties(kcodes: torch.Tensor, keys: np.ndarray, W: np.ndarray, K: int, L: int):
+    """Where does torch's bf16 GEMM (f32 accumulation in the library's own order, attnserver.py:159-162)
+    disagree with the sign of the EXACT dot product?  Only where the exact value is zero or within f32
+    rounding of it -- there the reference's code depends on the GEMM library's summation order (the
+    reference runs this matmul through cuBLAS), so the hash is defined by the exact sign.
+    Products of two bf16 numbers and their 128-term sums are exact in f64.  Returns (patched codes,
+    ties int64 [T, 6] = (b, g, l, t, bit, torch_bit), exact dot products f64 [T])."""
+    B, Hkv, _, n = kcodes.shape
+    Wf = synth.bf16_bits_to_f32(W).astype(np.float64)                       # [D, K*L]
+    patched = kcodes.clone()
+    ties, dots = [], []
+    for b in range(B):
+        for g in range(Hkv):
+            dot = synth.bf16_bits_to_f32(keys[b][g]).astype(np.float64) @ Wf          # [n, K*L] exact
+            bits = (dot > 0).reshape(n, L, K)
+            exact = (bits * (1 << np.arange(K))).sum(-1).T.astype(np.int16)           # [L, n]
+            tc = kcodes[b, g].numpy()
+            for l, t in np.argwhere(exact != tc):
+                x = int(exact[l, t]) ^ int(tc[l, t])
+                for bit in range(K):
+                    if (x >> bit) & 1:
+                        ties.append((b, g, l, t, bit, (int(tc[l, t]) >> bit) & 1))
+                        dots.append(dot[t, l * K + bit])
+            patched[b, g] = torch.from_numpy(exact)
+    return patched, np.array(ties, np.int64).reshape(-1, 6), np.array(dots, np.float64)
+
+
 def run_pipeline(name, seed, B, H, Hkv, n, M, D, K, L, ref_lsh, ref_attn, out):
     keys, kns, vals, W, qb = case_inputs(seed, B, H, Hkv, n, D, K, L)
     Wt = synth.to_torch_bf16(W)
     # --- SimHash (torch restatement)
     qcodes = torch_qhash(synth.to_torch_bf16(qb), Wt, K, L).contiguous()
     kcodes = torch.stack([torch_khash(synth.to_torch_bf16(keys[b]), Wt, K, L) for b in range(B)])
+    kcodes, ties, tie_dots = exact_sign_ties(kcodes, keys, W, K, L)
+    assert len(ties) <= 1e-7 * kcodes.numel() * K + 1 and (len(ties) == 0 or np.abs(tie_dots).max() < 1e-5)
     # --- tables + retrieve (compiled reference)
     lsh = ref_lsh.LSH()
     lsh.alloc(K, L, 1, H, Hkv, B, M)
@@ -115,6 +146,7 @@ def run_pipeline(name, seed, B, H, Hkv, n, M, D, K, L, ref_lsh, ref_attn, out):
         qcodes=qcodes.numpy().astype(np.int32),
         kcodes_sha=np.frombuffer(hashlib.sha256(kcodes.numpy().tobytes()).digest(), np.uint8),
         kcodes_head0_table0=kcodes[0, 0, 0].numpy().copy(),
+        kcodes_ties=ties, kcodes_tie_dots=tie_dots,
         nnz=nz.copy(),
         results_ref_order=np.concatenate([results[h, :nz[h]].numpy() for h in range(B * H)]),
         mask_hist=np.stack([np.bincount(mask[h].numpy().astype(np.int64), minlength=3)
@@ -124,7 +156,8 @@ def run_pipeline(name, seed, B, H, Hkv, n, M, D, K, L, ref_lsh, ref_attn, out):
         mve=mve.numpy().copy(),
         probs=np.concatenate([probs[h, :nz[h]].numpy() for h in range(B * H)]),
     )
-    print(f"{name}: nnz mean {nz.mean():.1f} min {nz.min()} max {nz.max()}")
+    print(f"{name}: nnz mean {nz.mean():.1f} min {nz.min()} max {nz.max()}; "
+          f"{len(ties)} of {kcodes.numel() * K} key sign bits are summation-order ties")
 
 
 def run_qhash_only(name, seed, R, D, K, L, out):
@@ -229,7 +262,115 @@ def run_cfg1_retrieve_sha(name, seed, ref_lsh, out):
     print(f"{name}: nnz mean {nz.mean():.1f}")
 
 
+def run_full_dense(name, seed, ref_attn, out):
+    """SparseAttentionServer::full_attention (sparse_attention.cc:988-1037) of the compiled reference,
+    f32 query as library/sparse_attention/test_dense.py:40, one FRESH server per (case, nnz): the
+    softmax of the reference covers round_up(nnz, 16) score slots (softmax_kernel_optimized, :249-283:
+    the tail mask is never taken because every block start is < nnz), so for nnz % 16 != 0 it also counts
+    whatever the score buffer holds behind the list -- zeros on a fresh server (:579-580).  The oracle
+    emulates that (`quirks` bit 1) to be pinned on ragged lengths too; the definition the HIP path is
+    held to is the softmax over exactly nnz rows."""
+    D = 128
+    d = dict(meta=np.array([seed, D], np.int64))
+    for tag, B, H, Hkv, n, M, nnz_list in FULL_DENSE_CASES:
+        keys, vals, q = full_dense_inputs(full_dense_seed(seed, tag, H), B, H, Hkv, n, D)
+        kn = np.zeros((Hkv, n), np.float32)           # key norms play no role in the dense path
+        for z in nnz_list:
+            srv = ref_attn.SparseAttentionServer()
+            srv.alloc(1, H, Hkv, D, B, M)
+            for b in range(B):
+                srv.fill(0, b, synth.to_torch_bf16(keys[b]), synth.to_torch_bf16(vals[b]), torch.from_numpy(kn))
+            output = torch.zeros((B * H, D), dtype=torch.bfloat16)
+            mve = torch.zeros((2, B * H), dtype=torch.float32)
+            nnz = torch.full((B * H,), z, dtype=torch.int32)
+            srv.full_attention(0, output, mve, torch.from_numpy(q).reshape(B, H, 1, D), nnz)
+            probs = srv.get_score().reshape(B * H, M)
+            z16 = (z + 15) & ~15
+            d[f"{tag}_z{z}_out"] = output.view(torch.int16).numpy().view(np.uint16).copy()
+            d[f"{tag}_z{z}_mve"] = mve.numpy().copy()
+            d[f"{tag}_z{z}_probs"] = probs[:, :min(z16, M)].numpy().copy()
+        print(f"{name}/{tag}: nnz {nnz_list}")
+    out[name] = d
+
+
+def run_window_merge(name, out):
+    """The sparse-layer decode of the reference stated with torch ops on CPU: the in-tree torch statement
+    of the LSH-sampled half (evaluations/RULER/pred/attnserver_dist.py:813-851: collision mask, importance
+    weight, masked softmax, base-2 LSE = logsumexp / ln 2), exact attention with a base-2 LSE over the
+    static window (what BatchDecodeWithPagedKVCacheWrapper.run_return_lse returns,
+    models/attnserver.py:293-296) and flashinfer.merge_state (:305-308, attnserver_dist.py:882).
+    FlashInfer itself is not in /root/reference (install.sh:4, un-vendored, unpinned); its published
+    definition of merge_state on base-2 LSEs is  s = log2(2^sa + 2^sb), v = (2^sa va + 2^sb vb) / 2^s.
+    Two deviations from the literal lines, both toward the C++ hot path: q.K is accumulated in f32
+    (attnserver_dist.py:843 rounds the bf16 matmul result to bf16; qk_kernel keeps f32,
+    sparse_attention.cc:38-103) and softmax(z) is not rounded to bf16 before P.V (:851; wv_kernel keeps
+    f32, sparse_attention.cc:321-384).  Also stored: the same attention as ONE softmax over the union of
+    the two parts in f64 -- the defining property of merge_state, independent of its formula."""
+    import math
+
+    c = WINDOW_MERGE
+    seed, B, H, Hkv, D, K, L, n, M = (c[k] for k in ("seed", "B", "H", "Hkv", "D", "K", "L", "n", "M"))
+    G = H // Hkv
+    keys, kns, vals, W, qb, wk, wv = window_merge_inputs(c)
+    Wt = synth.to_torch_bf16(W)
+    q = synth.to_torch_bf16(qb)                                            # bf16 [BH, D]
+    qcodes = torch_qhash(q, Wt, K, L)                                      # [BH, L]
+    BH = B * H
+    sp_out = torch.zeros((BH, D), dtype=torch.bfloat16)
+    sp_lse = torch.zeros((BH,))
+    w_out = torch.zeros((BH, D), dtype=torch.bfloat16)
+    w_lse = torch.zeros((BH,))
+    mg_out = torch.zeros((BH, D), dtype=torch.bfloat16)
+    mg_lse = torch.zeros((BH,))
+    joint_out = torch.zeros((BH, D), dtype=torch.float64)
+    joint_lse = torch.zeros((BH,), dtype=torch.float64)
+    nnz = np.zeros((BH,), np.int32)
+    for b in range(B):
+        kcodes = torch_khash(synth.to_torch_bf16(keys[b]), Wt, K, L)       # int16 [Hkv, L, n]
+        for hh in range(H):
+            h, g = b * H + hh, hh // G
+            qh = q[h].float()
+            # --- attnserver_dist.py:813-851 for one head
+            mask = (kcodes[g].int() == qcodes[h][:, None]).int().sum(dim=0) > 1          # :820-821
+            nnz[h] = int(mask.sum())
+            kf = synth.to_torch_bf16(keys[b][g]).float()
+            vf = synth.to_torch_bf16(vals[b][g]).float()
+            score = kf @ qh                                                              # :843 (f32)
+            cos = score / (torch.from_numpy(kns[b][g]) * qh.norm(p=2))                   # :846
+            theta = torch.arccos(cos)
+            weight = 1 - theta / torch.pi
+            weight = 1 - (1 - weight ** K) ** L - L * ((1 - weight ** K) ** (L - 1)) * (weight ** K)   # :851-852
+            z = score / math.sqrt(D) - torch.log(weight + 1e-4)
+            z = z.masked_fill(~mask, -torch.inf)
+            lse_sp = torch.logsumexp(z, dim=-1) / math.log(2)                            # :848-849
+            o_sp = (z.softmax(dim=-1) @ vf).to(torch.bfloat16)
+            # --- static window: exact attention + base-2 LSE
+            wkf = synth.to_torch_bf16(wk[b][g]).float()
+            wvf = synth.to_torch_bf16(wv[b][g]).float()
+            zw = (wkf @ qh) / math.sqrt(D)
+            lse_w = torch.logsumexp(zw, dim=-1) / math.log(2)
+            o_w = (zw.softmax(dim=-1) @ wvf).to(torch.bfloat16)
+            # --- flashinfer.merge_state on base-2 LSEs (published definition)
+            s = torch.log2(torch.exp2(lse_w.double()) + torch.exp2(lse_sp.double()))
+            v = (torch.exp2(lse_w.double() - s) * o_w.double() + torch.exp2(lse_sp.double() - s) * o_sp.double())
+            # --- the same thing as one softmax over the union (f64)
+            zz = torch.cat([zw.double(), z.double()])
+            vv = torch.cat([wvf.double(), vf.double()])
+            joint_lse[h] = torch.logsumexp(zz, dim=-1) / math.log(2)
+            joint_out[h] = zz.softmax(dim=-1) @ vv
+            sp_out[h], sp_lse[h], w_out[h], w_lse[h] = o_sp, lse_sp, o_w, lse_w
+            mg_out[h], mg_lse[h] = v.to(torch.bfloat16), s.float()
+    bits = lambda t: t.view(torch.int16).numpy().view(np.uint16).copy()
+    out[name] = dict(meta=np.array([seed, B, H, Hkv, D, K, L, n, M, c["win_M"], *c["win_rows"]], np.int64),
+                     nnz=nnz, sparse_out=bits(sp_out), sparse_lse=sp_lse.numpy().copy(),
+                     window_out=bits(w_out), window_lse=w_lse.numpy().copy(),
+                     merged_out=bits(mg_out), merged_lse=mg_lse.numpy().copy(),
+                     joint_out=joint_out.numpy().astype(np.float32), joint_lse=joint_lse.numpy().astype(np.float32))
+    print(f"{name}: nnz {nnz.tolist()} lse window {w_lse[:3].tolist()} sparse {sp_lse[:3].tolist()}")
+
+
 def main():
+    only = set(sys.argv[1:])            # fixture names to (re)generate; none = all
     ref_lsh, ref_attn = load_ref()
     assert ref_uses_bf16_family(), "fixtures are generated with the __AVX512BF16__ build"
     cases: dict = {}
@@ -244,10 +385,20 @@ def main():
     run_pipeline("cfg0", 42, 1, 1, 1, 4096, 4288, 128, 10, 150, ref_lsh, ref_attn, cases)
     run_pipeline("gqa_32h", 43, 1, 32, 8, 4096, 4288, 128, 10, 150, ref_lsh, ref_attn, cases)
     run_pipeline("b2_k8_l60", 44, 2, 8, 2, 1500, 1600, 128, 8, 60, ref_lsh, ref_attn, cases)
+    # BASELINE cfg 2 / cfg 3 head counts at a small sequence: B = 8, H = 32, Hkv = 8 -> 256 query heads
+    # (the one-workgroup-per-head / cluster = 1 regime of the decode entry), L = 170 and L = 150
+    run_pipeline("cfg2_small", 45, 8, 32, 8, 2048, 2112, 128, 10, 170, ref_lsh, ref_attn, cases)
+    run_pipeline("cfg3_small", 46, 8, 32, 8, 2048, 2112, 128, 10, 150, ref_lsh, ref_attn, cases)
     run_cfg1_retrieve_sha("cfg1_retrieve_sha", 51, ref_lsh, cases)
+    run_full_dense("full_dense", 55, ref_attn, cases)
+    run_window_merge("window_merge", cases)
+    wrote = 0
     for name, d in cases.items():
+        if only and name not in only:
+            continue
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
-    print("wrote", len(cases), "fixtures to", HERE)
+        wrote += 1
+    print("wrote", wrote, "fixtures to", HERE)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,322 @@
+"""GPU parity at the head counts and sizes of BASELINE.json cfg 2 / cfg 3, and against the two fixtures
+that pin the dense path and the window + LSE merge (tests/golden/full_dense.npz from the compiled
+reference's full_attention; tests/golden/window_merge.npz from the committed torch statement of the
+reference's call site).  Needs a real MI355X: `pytest -m gpu`.
+
+Tolerances as in test_gpu_parity.py: <= 1 bf16 ulp / 1e-3 on the base-2 LSE against the oracle's exact
+definition, the reference's own rtol = atol = 1e-2 (library/sparse_attention/test_dense.py:60-66,
+test_sparse.py:87-92) against the reference's outputs (polynomial exp, f32 cancellation in the weight)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import oracle
+import synth
+from test_gpu_parity import bf16_t, bits_of, mp  # noqa: F401  (mp: module fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ a-15 / f-4: full_attention vs the reference
+
+@pytest.mark.parametrize("case", cases.FULL_DENSE_CASES, ids=[c[0] for c in cases.FULL_DENSE_CASES])
+@pytest.mark.parametrize("where", ["cuda", "cpu"])
+def test_full_attention_vs_reference_fixture(mp, case, where):
+    """mp_attn_full against the compiled reference's full_attention (G = 1, 4, 8; list lengths 0, 1 and
+    around the 16- and 64-row block edges) and against the pinned oracle.  Where nnz % 16 != 0 the
+    reference's softmax also counts stale score slots behind the list (oracle quirk bit 1): there the HIP
+    path is held to the definition (oracle quirks = 0) only."""
+    g = cases.load_golden("full_dense")
+    seed, D = (int(x) for x in g["meta"])
+    tag, B, H, Hkv, n, M, nnz_list = case
+    keys, vals, q = cases.full_dense_inputs(cases.full_dense_seed(seed, tag, H), B, H, Hkv, n, D)
+    BH = B * H
+    srv = mp.SparseAttentionServer()
+    srv.alloc(1, H, Hkv, D, B, M)
+    osrv = oracle.SparseAttentionServer()
+    osrv.alloc(1, H, Hkv, D, B, M)
+    kn = np.zeros((Hkv, n), np.float32)
+    for b in range(B):
+        srv.fill(0, b, bf16_t(keys[b], where), bf16_t(vals[b], where), torch.from_numpy(kn).to(where))
+        osrv.fill(0, b, keys[b], vals[b], kn)
+    for z in nnz_list:
+        nnz = np.full((BH,), z, np.int32)
+        out = torch.zeros((BH, D), dtype=torch.bfloat16, device=where)
+        mve = torch.zeros((2, BH), dtype=torch.float32, device=where)
+        srv.full_attention(0, out, mve, torch.from_numpy(q).to(where), torch.from_numpy(nnz).to(where))
+        probs = srv.get_score().reshape(BH, M).cpu().numpy()
+        got, lse = synth.bf16_bits_to_f32(bits_of(out)), mve.cpu().numpy()
+        oout = np.zeros((BH, D), np.uint16)
+        omve = np.zeros((2, BH), np.float32)
+        osrv.full_attention(0, oout, omve, q, nnz)
+        if z == 0:
+            assert not got.any() and np.all(np.isneginf(lse[1])) and np.all(np.isneginf(g[f"{tag}_z{z}_mve"][1]))
+            continue
+        assert np.allclose(lse[1], omve[1], atol=1e-3), (tag, z)
+        assert np.allclose(lse[0], omve[0], atol=1e-3), (tag, z)
+        assert np.allclose(got, synth.bf16_bits_to_f32(oout), rtol=2 ** -7, atol=2e-4), (tag, z)   # <= 1 bf16 ulp
+        oprobs = osrv.get_score().reshape(BH, M)
+        assert np.allclose(probs[:, :z], oprobs[:, :z], rtol=2e-3, atol=1e-8), (tag, z)
+        if z % 16 == 0:   # the reference's own outputs at the reference's own tolerance
+            assert np.allclose(got, synth.bf16_bits_to_f32(g[f"{tag}_z{z}_out"]), rtol=1e-2, atol=1e-2), (tag, z)
+            assert np.allclose(lse[1], g[f"{tag}_z{z}_mve"][1], atol=0.03), (tag, z)
+            assert np.allclose(probs[:, :z], g[f"{tag}_z{z}_probs"][:, :z], rtol=2e-2, atol=1e-4), (tag, z)
+
+
+@pytest.mark.parametrize("G,B,H,D,n,M", [(1, 1, 4, 64, 300, 320), (4, 2, 8, 64, 257, 300), (8, 1, 16, 64, 1000, 1024),
+                                        (8, 2, 16, 128, 700, 704), (3, 1, 6, 128, 100, 128)])
+@pytest.mark.parametrize("qdtype", ["f32", "bf16"])
+def test_full_attention_shapes_vs_oracle(mp, G, B, H, D, n, M, qdtype):
+    """Shapes the reference's full_attention does not have (head_dim 64, group size 3, bf16 queries, ragged
+    per-head lengths) against the pinned oracle."""
+    Hkv = H // G
+    keys, vals, q = cases.full_dense_inputs(900 + G + D, B, H, Hkv, n, D)
+    BH = B * H
+    if qdtype == "bf16":
+        q = synth.bf16_bits_to_f32(synth.f32_to_bf16_bits(q))
+    srv = mp.SparseAttentionServer()
+    srv.alloc(1, H, Hkv, D, B, M)
+    osrv = oracle.SparseAttentionServer()
+    osrv.alloc(1, H, Hkv, D, B, M)
+    kn = np.zeros((Hkv, n), np.float32)
+    for b in range(B):
+        srv.fill(0, b, bf16_t(keys[b], "cuda"), bf16_t(vals[b], "cuda"), torch.from_numpy(kn).cuda())
+        osrv.fill(0, b, keys[b], vals[b], kn)
+    nnz = (1 + synth.randint(5 + G, 0, n, (BH,))).astype(np.int32)
+    nnz[0], nnz[-1] = n, 0
+    out = torch.zeros((BH, D), dtype=torch.bfloat16, device="cuda")
+    mve = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
+    qt = torch.from_numpy(q).cuda()
+    srv.full_attention(0, out, mve, qt.to(torch.bfloat16) if qdtype == "bf16" else qt, torch.from_numpy(nnz).cuda())
+    oout = np.zeros((BH, D), np.uint16)
+    omve = np.zeros((2, BH), np.float32)
+    osrv.full_attention(0, oout, omve, q, nnz)
+    assert np.allclose(mve.cpu().numpy()[1], omve[1], atol=1e-3)
+    assert np.allclose(synth.bf16_bits_to_f32(bits_of(out)), synth.bf16_bits_to_f32(oout), rtol=2 ** -7, atol=2e-4)
+    probs = srv.get_score().reshape(BH, M).cpu().numpy()
+    oprobs = osrv.get_score().reshape(BH, M)
+    for h in range(BH):
+        assert np.allclose(probs[h, :nnz[h]], oprobs[h, :nnz[h]], rtol=2e-3, atol=1e-8)
+
+
+# ------------------------------------------------------------------ a-13 / f-2: window + LSE merge vs the torch statement
+
+def _window_merge_server(mp, c, keys, kns, vals, W, wk, wv):
+    B, H, Hkv, D, K, L, n, M = (c[k] for k in ("B", "H", "Hkv", "D", "K", "L", "n", "M"))
+    gb = c["win_M"] - 1
+    server = mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, num_sink_tokens=0, num_local_tokens=1,
+                                    generation_buffer=gb, max_length=M, dense_layers=(),
+                                    hash_func=bf16_t(W, "cuda"))
+    assert server.length == c["win_M"]
+    for b in range(B):
+        # offloaded part: already-centred keys straight into the hot-path stores (avg_k stays 0)
+        server.hash_code_buffer = server.hasher.keys(bf16_t(keys[b], "cuda"))
+        server.build_table(0, b, n)
+        server.attn_server.fill(0, b, bf16_t(keys[b], "cuda"), bf16_t(vals[b], "cuda"), torch.from_numpy(kns[b]).cuda())
+        # static window: all rows but the last; the last one is this step's own (k, v), appended by decode
+        rows = c["win_rows"][b] - 1
+        wkb, wvb = bf16_t(wk[b][:, :rows], "cuda"), bf16_t(wv[b][:, :rows], "cuda")
+        server.window_server.fill(0, b, wkb.contiguous(), wvb.contiguous(), wkb.float().norm(p=2, dim=-1))
+        server.set_window_rows(b, rows)
+    k_new = torch.stack([bf16_t(wk[b][:, -1], "cuda") for b in range(B)]).view(B, Hkv, 1, D)
+    v_new = torch.stack([bf16_t(wv[b][:, -1], "cuda") for b in range(B)]).view(B, Hkv, 1, D)
+    return server, k_new, v_new
+
+
+def test_window_merge_vs_torch_statement(mp):
+    """decode_full (append, window attention, hot path, mp_merge_state) and decode_full_fused (append + ONE
+    launch) against tests/golden/window_merge.npz: the committed torch-CPU statement of
+    evaluations/RULER/pred/attnserver_dist.py:813-851, 882 / models/attnserver.py:293-308.  The sampled
+    half of that statement evaluates the importance weight literally in f32 (~1e-3 cancellation noise in
+    w + 1e-4): reference tolerance there; the window half and the merge are held to 1 bf16 ulp."""
+    c = cases.WINDOW_MERGE
+    g = cases.load_golden("window_merge")
+    B, H, D = c["B"], c["H"], c["D"]
+    BH = B * H
+    keys, kns, vals, W, qb, wk, wv = cases.window_merge_inputs(c)
+    q = bf16_t(qb, "cuda").view(B, H, 1, D)
+    # -- the merge kernel alone on the statement's own partials
+    v, s = mp.LSHSparseAttnServer.merge(bf16_t(g["window_out"], "cuda"), torch.from_numpy(g["window_lse"]).cuda(),
+                                        bf16_t(g["sparse_out"], "cuda"), torch.from_numpy(g["sparse_lse"]).cuda())
+    assert np.allclose(s.cpu().numpy(), g["merged_lse"], atol=1e-5)
+    assert np.allclose(synth.bf16_bits_to_f32(bits_of(v)), synth.bf16_bits_to_f32(g["merged_out"]), rtol=2 ** -7, atol=1e-6)
+    assert (bits_of(v) == g["merged_out"]).mean() > 0.99
+    # -- four-launch path
+    server, k_new, v_new = _window_merge_server(mp, c, keys, kns, vals, W, wk, wv)
+    server.plan()
+    hidden = server.decode_full(q, k_new, v_new, 0)
+    server.window_server.check()
+    assert np.array_equal(server.nnz.cpu().numpy(), g["nnz"])                 # same tokens as the torch collision mask
+    assert np.allclose(server.window_mve[1].cpu().numpy(), g["window_lse"], atol=1e-3)
+    assert np.allclose(server.window_out.float().cpu().numpy(), synth.bf16_bits_to_f32(g["window_out"]), rtol=2 ** -7, atol=2e-4)
+    assert np.allclose(server.max_value_expsum[1].cpu().numpy(), g["sparse_lse"], atol=5e-3)
+    assert np.allclose(server.output.float().cpu().numpy(), synth.bf16_bits_to_f32(g["sparse_out"]), rtol=1e-2, atol=1e-2)
+    got = hidden.float().cpu().numpy().reshape(BH, D)
+    assert np.allclose(got, synth.bf16_bits_to_f32(g["merged_out"]), rtol=1e-2, atol=1e-2)
+    assert np.allclose(got, g["joint_out"], rtol=1e-2, atol=1e-2)
+    # -- two-launch path: the window joins the softmax of the sampled tokens
+    server2, k_new, v_new = _window_merge_server(mp, c, keys, kns, vals, W, wk, wv)
+    server2.plan()
+    hidden2 = server2.decode_full_fused(q, k_new, v_new, 0)
+    server2.window_server.check()
+    assert np.array_equal(server2.nnz.cpu().numpy(), g["nnz"])
+    got2 = hidden2.float().cpu().numpy().reshape(BH, D)
+    assert np.allclose(got2, g["joint_out"], rtol=1e-2, atol=1e-2)
+    assert np.allclose(server2.max_value_expsum[1].cpu().numpy(), g["joint_lse"], atol=5e-3)
+    # tight, against the pinned oracle's exact evaluation of the same union softmax
+    ref, ref_lse = _oracle_union(c, keys, kns, vals, W, qb, wk, wv, g["nnz"])
+    assert np.allclose(got2, ref, rtol=2 ** -7, atol=2e-4)
+    assert np.allclose(server2.max_value_expsum[1].cpu().numpy(), ref_lse, atol=1e-3)
+
+
+def _oracle_union(c, keys, kns, vals, W, qb, wk, wv, nnz_expected=None):
+    """One softmax over (window rows, exact logits) U (sampled tokens, importance-corrected logits) from the
+    pinned oracle parts: sampled half with exp_mode 2 (exact exp, cancellation-free weight), window half by
+    full_attention, merged in f64 from their UNROUNDED probabilities."""
+    B, H, Hkv, D, K, L, n, M = (c[k] for k in ("B", "H", "Hkv", "D", "K", "L", "n", "M"))
+    BH, G = B * H, H // Hkv
+    qcodes, qn = oracle.simhash_query(qb, W, K, L)
+    lsh = oracle.LSH()
+    lsh.alloc(K, L, 1, H, Hkv, B, M)
+    for b in range(B):
+        sc, si = cases.stable_sort_codes(oracle.simhash_keys(keys[b], W, K, L))
+        lsh.fill(0, b, sc, si)
+    results = np.zeros((BH, M), np.int32)
+    nnz = np.zeros((BH,), np.int32)
+    lsh.batch_retrieve(0, qcodes, results, nnz)
+    if nnz_expected is not None:
+        assert np.array_equal(nnz, nnz_expected)
+    srv = oracle.SparseAttentionServer(exp_mode=2, clamp_cos=1)
+    srv.alloc(1, H, Hkv, D, B, M)
+    for b in range(B):
+        srv.fill(0, b, keys[b], vals[b], kns[b])
+    so = np.zeros((BH, D), np.uint16)
+    sm = np.zeros((2, BH), np.float32)
+    srv.attention_wrapper(0, K, L, so, sm, qb, qn, results, nnz)
+    sp = srv.get_score().reshape(BH, M).astype(np.float64)
+    wM = max(x.shape[1] for x in wk)
+    wsrv = oracle.SparseAttentionServer()
+    wsrv.alloc(1, H, Hkv, D, B, wM)
+    for b in range(B):
+        wsrv.fill(0, b, np.ascontiguousarray(wk[b]), np.ascontiguousarray(wv[b]), np.zeros(wk[b].shape[:2], np.float32))
+    wo = np.zeros((BH, D), np.uint16)
+    wm = np.zeros((2, BH), np.float32)
+    wnnz = np.repeat(np.array([x.shape[1] for x in wk], np.int32), H)
+    wsrv.full_attention(0, wo, wm, synth.bf16_bits_to_f32(qb), wnnz)
+    wp = wsrv.get_score().reshape(BH, wM).astype(np.float64)
+    out = np.zeros((BH, D))
+    lse = np.zeros((BH,))
+    for h in range(BH):
+        b, gq = h // H, (h % H) // G
+        a, bb = float(wm[1, h]), float(sm[1, h])
+        mx = max(a, bb)
+        wa, wb = 2.0 ** (a - mx), (2.0 ** (bb - mx) if np.isfinite(bb) else 0.0)
+        vw = wp[h, :wnnz[h]] @ synth.bf16_bits_to_f32(wv[b][gq]).astype(np.float64)
+        ids = results[h, :nnz[h]]
+        vs = sp[h, :nnz[h]] @ synth.bf16_bits_to_f32(vals[b][gq][ids]).astype(np.float64)
+        out[h] = (wa * vw + wb * vs) / (wa + wb)
+        lse[h] = mx + np.log2(wa + wb)
+    return out.astype(np.float32), lse.astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small"])
+def test_fused_decode_window_at_256_heads(mp, name):
+    """mp_decode_layer_window (static window folded into the decode launch) at B*H = 256 -- one workgroup per
+    head, the regime of BASELINE cfg 2 / cfg 3 -- on the reference-generated case's offloaded part plus a
+    ragged synthetic window per request, against the union softmax of the pinned oracle parts."""
+    g = cases.load_golden(name)
+    seed, B, H, Hkv, n, M, D, K, L = (int(x) for x in g["meta"])
+    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L)
+    win_rows = tuple(20 + 13 * b for b in range(B))                   # 20 .. 111 rows, crossing 32-row slices
+    c = dict(seed=seed, B=B, H=H, Hkv=Hkv, D=D, K=K, L=L, n=n, M=M, win_rows=win_rows, win_M=128)
+    wk = [synth.normal_bf16_bits(seed + 100 + b, (Hkv, win_rows[b], D)) for b in range(B)]
+    wv = [synth.normal_bf16_bits(seed + 200 + b, (Hkv, win_rows[b], D)) for b in range(B)]
+    server, k_new, v_new = _window_merge_server(mp, c, keys, kns, vals, W, wk, wv)
+    server.plan()
+    hidden = server.decode_full_fused(bf16_t(qb, "cuda").view(B, H, 1, D), k_new, v_new, 0)
+    server.window_server.check()
+    assert np.array_equal(server.nnz.cpu().numpy(), g["nnz"])
+    ref, ref_lse = _oracle_union(c, keys, kns, vals, W, qb, wk, wv, g["nnz"])
+    got = hidden.float().cpu().numpy().reshape(B * H, D)
+    assert np.allclose(got, ref, rtol=2 ** -7, atol=2e-4)
+    assert np.allclose(server.max_value_expsum[1].cpu().numpy(), ref_lse, atol=1e-3)
+    # and the four-launch path on a second server: same result up to the bf16 rounding of its two partials
+    server4, k_new, v_new = _window_merge_server(mp, c, keys, kns, vals, W, wk, wv)
+    server4.plan()
+    h4 = server4.decode_full(bf16_t(qb, "cuda").view(B, H, 1, D), k_new, v_new, 0)
+    assert np.allclose(h4.float().cpu().numpy().reshape(B * H, D), ref, rtol=2 ** -6, atol=4e-3)
+
+
+# ------------------------------------------------------------------ BASELINE cfg 2 at full size
+
+def test_cfg2_full_size_fused_decode_properties(mp):
+    """BASELINE cfg 2 (B = 8, H = 32, Hkv = 8, P = 32 768 -> n = 32 700, M = 32 960, K = 10, L = 170), one
+    layer, through size-independent properties: (1) the one-launch entry (256 workgroups, one per head)
+    equals hash -> batch_retrieve -> attention_wrapper on the same stores (codes, nnz bit for bit; outputs up
+    to summation order), for both attention kernels of the three-call path; (2) the selected sets are exactly
+    {tokens colliding in >= 2 tables} recomputed densely from the stored key codes; (3) V -> 2V doubles the
+    output exactly and leaves the LSE unchanged; (4) with the static window folded in, two launches equal
+    the four-launch path."""
+    import magicpig_amd._lib as L_
+
+    B, H, Hkv, D, K, L, P = 8, 32, 8, 128, 10, 170, 32768
+    n, M = P - 68, 32960
+    BH, G = B * H, H // Hkv
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(17)
+    W = torch.randn((D, K * L), device=dev, generator=gen).to(torch.bfloat16)
+    mk = lambda: mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, max_length=M, dense_layers=(),  # noqa: E731
+                                        hash_func=W, generation_buffer=8)
+    server, server4 = mk(), mk()
+    kcodes = []
+    for b in range(B):
+        kc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
+        vc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
+        for srv in (server, server4):
+            srv.fill(0, b, kc, vc, P)
+            if srv is server:
+                kcodes.append(srv.hash_code_buffer.clone())                  # int16 [Hkv, L, n]
+            srv.build_table(0, b, P)
+    q = torch.randn((B, H, 1, D), device=dev, generator=gen).to(torch.bfloat16)
+    out, lse = server.decode(q, 0)
+    out, lse, nz1 = out.clone().reshape(BH, D), lse.clone().reshape(-1), server.nnz.clone()
+    codes, qn = server.hasher.query(q.reshape(BH, D))
+    res = torch.zeros((BH, M), dtype=torch.int32, device=dev)
+    nz = torch.zeros((BH,), dtype=torch.int32, device=dev)
+    server.lsh_retriever.batch_retrieve(0, codes, res, nz)
+    assert torch.equal(nz, nz1) and int(nz.min()) > 100
+    # (2) dense recount from the key codes: count[h][t] = #tables where code matches
+    for h in range(0, BH, 37):
+        b, g = h // H, (h % H) // G
+        cnt = (kcodes[b][g] == codes[h].to(torch.int16)[:, None]).sum(0)
+        sel = torch.nonzero(cnt >= 2).flatten().int()
+        assert torch.equal(sel, res[h, :int(nz[h])])
+    # (1) both stand-alone attention kernels
+    o_ref = mve = None
+    for hk in (1, 0):
+        L_.set_option("attn_head_kernel", hk)
+        try:
+            o_ref = torch.zeros((BH, D), dtype=torch.bfloat16, device=dev)
+            mve = torch.zeros((2, BH), dtype=torch.float32, device=dev)
+            server.attn_server.attention_wrapper(0, K, L, o_ref, mve, q.reshape(BH, D), qn, res, nz)
+        finally:
+            L_.set_option("attn_head_kernel", -1)
+        assert np.allclose(out.float().cpu().numpy(), o_ref.float().cpu().numpy(), rtol=2 ** -6, atol=2e-3)
+        assert np.allclose(lse.cpu().numpy(), mve[1].cpu().numpy(), atol=2e-3)
+    # (3) V -> 2 V through the one-launch entry
+    kvv = server.attn_server.get_value_cache(0)
+    kvv.mul_(2)
+    out2, lse2 = server.decode(q, 0)
+    assert torch.equal(out2.reshape(BH, D).float(), out.float() * 2)
+    assert torch.equal(lse2.reshape(-1), lse)
+    kvv.mul_(0.5)
+    # (4) window folded in vs four launches
+    k_new = torch.randn((B, Hkv, 1, D), device=dev, generator=gen).to(torch.bfloat16)
+    v_new = torch.randn((B, Hkv, 1, D), device=dev, generator=gen).to(torch.bfloat16)
+    server.plan()
+    server4.plan()
+    got = server.decode_full_fused(q, k_new, v_new, 0).float().cpu().numpy().reshape(BH, D)
+    ref = server4.decode_full(q, k_new, v_new, 0).float().cpu().numpy().reshape(BH, D)
+    assert torch.equal(server.nnz, server4.nnz)
+    assert np.allclose(got, ref, rtol=2 ** -6, atol=4e-3)

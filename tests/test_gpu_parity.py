@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 
 QHASH = ["qhash_r1_k10_l150", "qhash_r32_k10_l150", "qhash_r64_k11_l300", "qhash_r40_k8_l50",
          "qhash_r256_k10_l170"]
-PIPE = ["lsh_small", "cfg0", "gqa_32h", "b2_k8_l60"]
+PIPE = ["lsh_small", "cfg0", "gqa_32h", "b2_k8_l60",
+        "cfg2_small", "cfg3_small"]   # BASELINE cfg 2 / cfg 3 head counts: B = 8 x H = 32 = 256 query heads, L = 170 / 150
 
 
 @pytest.fixture(scope="module")
@@ -244,6 +245,7 @@ def test_pipeline_vs_reference_and_oracle(mp, name, where):
     assert np.array_equal(r["qcodes"], g["qcodes"])
     assert np.array_equal(
         np.frombuffer(hashlib.sha256(r["kcodes"].tobytes()).digest(), np.uint8), g["kcodes_sha"])
+    cases.check_sign_ties(g, r["kcodes"], K)
     assert np.array_equal(r["nnz"], g["nnz"])
     ref_lists = cases.split_ragged(g["results_ref_order"], g["nnz"])
     for h in range(B * H):
@@ -447,11 +449,24 @@ def test_sparse_attention_like_reference_test(mp, G, batch_size, H, D, delta):
         assert abs(float(mve[1][i]) - float(lse2)) < 1e-2          # the reference never asserts its LSE
 
 
-def test_in_launch_merge_is_deterministic_under_load(mp):
-    """The attention kernel merges a head's slice partials inside the launch (last-arriver ticket,
-    write-through partials).  Any stale read shows up as run-to-run differences: 60 launches over
-    256 heads with ragged list lengths (1 .. 6000 entries, i.e. 1 .. 94 slices per head) must be
-    bit-identical, and equal to the oracle."""
+@pytest.mark.parametrize("head_kernel", [0, 1])
+def test_in_launch_merge_is_deterministic_under_load(mp, head_kernel):
+    """head_kernel = 0: the split-KV attention kernel merges a head's slice partials inside the launch
+    (last-arriver ticket, write-through partials).  Any stale read shows up as run-to-run differences: 60
+    launches over 256 heads with ragged list lengths (1 .. 6000 entries, i.e. 1 .. 94 slices per head)
+    must be bit-identical, and equal to the oracle.  At 256 heads the handle would pick the
+    one-workgroup-per-head kernel by itself (head_kernel = 1, the same load without tickets), so the
+    choice is forced through mp_debug_set_option for both."""
+    import magicpig_amd._lib as L_
+
+    L_.set_option("attn_head_kernel", head_kernel)
+    try:
+        _in_launch_merge_under_load(mp)
+    finally:
+        L_.set_option("attn_head_kernel", -1)
+
+
+def _in_launch_merge_under_load(mp):
     H, Hkv, B, D, n, M, K, L = 32, 8, 8, 128, 8000, 8192, 10, 150
     gen = torch.Generator().manual_seed(99)
     key = torch.randn((B, Hkv, n, D), generator=gen).to(torch.bfloat16)
@@ -546,9 +561,12 @@ def test_merge_state_vs_oracle(mp):
 
 # ------------------------------------------------------------------ fused decode step (the hot path as benchmarked)
 
-@pytest.mark.parametrize("name", ["gqa_32h", "b2_k8_l60"])
+@pytest.mark.parametrize("name", ["gqa_32h", "b2_k8_l60", "cfg2_small", "cfg3_small"])
 @pytest.mark.parametrize("table_build", ["sort", "counting"])
 def test_fused_decode_layer(mp, name, table_build):
+    """The one-launch decode entry against the reference's vectors and the oracle.  gqa_32h / b2_k8_l60
+    run it with workgroup clusters (B*H = 32 / 16), cfg2_small / cfg3_small with B*H = 256 heads: one
+    workgroup per head, no cluster -- the regime of BASELINE cfg 2 and cfg 3."""
     g = cases.load_golden(name)
     seed, B, H, Hkv, n, M, D, K, L = (int(x) for x in g["meta"])
     keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L)
@@ -869,10 +887,16 @@ def test_decode_full_window_plus_sparse_merge(mp):
         ref = (wa[:, None] * w_out + sa[:, None] * synth.bf16_bits_to_f32(s_out)) / (wa + sa)[:, None]
         assert np.allclose(synth.bf16_bits_to_f32(got), ref, rtol=1e-2, atol=3e-3)
     assert server.kv_last_page_len.tolist() == [71, 71]
-    # the window is 4 + 64 + 8 rows: 6 more appends overflow it and are reported, not written
-    for _ in range(6):
+    # the window is 4 + 64 + 8 rows: five more steps fill it, the sixth is refused by plan() on the host
+    for _ in range(5):
         server.plan()
         server.decode_full(q.cuda(), k_new.cuda(), v_new.cuda(), 0)
+    server.window_server.check()
+    with pytest.raises(mp.MagicPigError):
+        server.plan()
+    # an append past the store's last row (bypassing plan) is reported by the device flag, never written
+    server.window_server.append(0, k_new.reshape(B, Hkv, D).cuda().contiguous(), v_new.reshape(B, Hkv, D).cuda().contiguous(),
+                                torch.full((B,), server.length, dtype=torch.int32, device="cuda"))
     with pytest.raises(mp.MagicPigError):
         server.window_server.check()
 

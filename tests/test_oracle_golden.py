@@ -12,7 +12,8 @@ import synth
 
 QHASH = ["qhash_r1_k10_l150", "qhash_r32_k10_l150", "qhash_r64_k11_l300", "qhash_r40_k8_l50",
          "qhash_r256_k10_l170"]
-PIPE = ["lsh_small", "cfg0", "gqa_32h", "b2_k8_l60"]
+PIPE = ["lsh_small", "cfg0", "gqa_32h", "b2_k8_l60",
+        "cfg2_small", "cfg3_small"]   # BASELINE cfg 2 / cfg 3 head counts (B = 8, 256 query heads; L = 170 / 150)
 
 
 @pytest.mark.parametrize("name", QHASH)
@@ -63,6 +64,7 @@ def test_pipeline_matches_reference(name):
     assert np.array_equal(r["kcodes"][0, 0, 0], g["kcodes_head0_table0"])
     assert np.array_equal(
         np.frombuffer(hashlib.sha256(r["kcodes"].tobytes()).digest(), np.uint8), g["kcodes_sha"])
+    cases.check_sign_ties(g, r["kcodes"], K)
     assert np.array_equal(r["nnz"], g["nnz"])
     ref_lists = cases.split_ragged(g["results_ref_order"], g["nnz"])
     for h in range(B * H):
@@ -177,3 +179,119 @@ def test_cfg1_shaped_retrieve_sha():
     for h in range(B * H):
         hsh.update(np.sort(results[h, :nnz[h]]).tobytes())
     assert np.array_equal(np.frombuffer(hsh.digest(), np.uint8), g["sha256"])
+
+
+# ------------------------------------------------------------------ a-15 / f-4: full_attention pinned
+
+@pytest.mark.parametrize("case", cases.FULL_DENSE_CASES, ids=[c[0] for c in cases.FULL_DENSE_CASES])
+def test_full_attention_matches_reference(case):
+    """mpo_full_attention against the compiled reference's full_attention (sparse_attention.cc:988-1037),
+    group sizes 1 / 4 / 8 as library/sparse_attention/test_dense.py:8-14, list lengths around the 16- and
+    64-row block edges and 0.  quirks = 3 reproduces the reference (polynomial exp, 16-slot softmax tail):
+    tight; quirks = 0 is the definition: equal to the reference within its own test tolerance wherever
+    the tail quirk is silent (nnz % 16 == 0)."""
+    g = cases.load_golden("full_dense")
+    seed, D = (int(x) for x in g["meta"])
+    tag, B, H, Hkv, n, M, nnz_list = case
+    keys, vals, q = cases.full_dense_inputs(cases.full_dense_seed(seed, tag, H), B, H, Hkv, n, D)
+    kn = np.zeros((Hkv, n), np.float32)
+    BH = B * H
+    for z in nnz_list:
+        ref_out = synth.bf16_bits_to_f32(g[f"{tag}_z{z}_out"])
+        ref_mve = g[f"{tag}_z{z}_mve"]
+        ref_probs = g[f"{tag}_z{z}_probs"]
+        nnz = np.full((BH,), z, np.int32)
+        for quirks in (3, 0):
+            srv = oracle.SparseAttentionServer()          # fresh server: the score buffer is zero
+            srv.alloc(1, H, Hkv, D, B, M)
+            for b in range(B):
+                srv.fill(0, b, keys[b], vals[b], kn)
+            out = np.zeros((BH, D), np.uint16)
+            mve = np.zeros((2, BH), np.float32)
+            srv.full_attention(0, out, mve, q, nnz, quirks=quirks)
+            probs = srv.get_score().reshape(BH, M)
+            o = synth.bf16_bits_to_f32(out)
+            if z == 0:        # empty list: out = 0, LSE = -inf (row 0 of max_value_expsum is -inf too)
+                assert not out.any() and not g[f"{tag}_z{z}_out"].any()
+                assert np.all(np.isneginf(mve[1])) and np.all(np.isneginf(ref_mve[1]))
+                continue
+            if quirks == 3:
+                z16 = min((z + 15) & ~15, M)
+                assert np.allclose(probs[:, :z16], ref_probs[:, :z16], rtol=2e-4, atol=1e-7), (tag, z)
+                assert np.allclose(mve, ref_mve, rtol=1e-5, atol=1e-4), (tag, z)
+                assert np.allclose(o, ref_out, rtol=2 ** -7, atol=1e-5), (tag, z)          # <= 1 bf16 ulp
+                assert (out == g[f"{tag}_z{z}_out"]).mean() > 0.97
+            elif z % 16 == 0:
+                assert np.allclose(probs[:, :z], ref_probs[:, :z], rtol=2e-2, atol=1e-4), (tag, z)
+                assert np.allclose(o, ref_out, rtol=1e-2, atol=1e-2), (tag, z)             # test_dense.py:66
+                assert np.allclose(mve[1], ref_mve[1], atol=0.03), (tag, z)                # poly exp <= 1.7 % low
+                assert np.all(np.abs(probs[:, :z].sum(-1) - 1) <= 1e-4)
+            else:
+                # the reference's softmax also counted zero-score slots behind the list: its sum is
+                # larger by (z16 - z) * exp(0 - m), nothing else differs
+                assert np.all(np.abs(probs[:, :z].sum(-1) - 1) <= 1e-4)
+                assert np.all(mve[1] <= ref_mve[1] + 0.03)
+
+
+# ------------------------------------------------------------------ a-13 / f-2: window + LSE merge pinned
+
+def _window_merge_oracle_parts(c, g):
+    seed, B, H, Hkv, D, K, L, n, M = (c[k] for k in ("seed", "B", "H", "Hkv", "D", "K", "L", "n", "M"))
+    keys, kns, vals, W, qb, wk, wv = cases.window_merge_inputs(c)
+    BH = B * H
+    qcodes, qn = oracle.simhash_query(qb, W, K, L)
+    kcodes = np.stack([oracle.simhash_keys(keys[b], W, K, L) for b in range(B)])
+    lsh = oracle.LSH()
+    lsh.alloc(K, L, 1, H, Hkv, B, M)
+    for b in range(B):
+        sc, si = cases.stable_sort_codes(kcodes[b])
+        lsh.fill(0, b, sc, si)
+    results = np.zeros((BH, M), np.int32)
+    nnz = np.zeros((BH,), np.int32)
+    lsh.batch_retrieve(0, qcodes, results, nnz)
+    return keys, kns, vals, W, qb, wk, wv, qn, results, nnz
+
+
+def test_window_merge_matches_torch_statement():
+    """The three oracle functions of the sparse-layer decode against the committed torch-CPU statement of
+    the reference's call site (tests/golden/make_golden.py: run_window_merge): sampled half
+    (attnserver_dist.py:813-851), exact window attention with a base-2 LSE, flashinfer.merge_state."""
+    c = cases.WINDOW_MERGE
+    g = cases.load_golden("window_merge")
+    B, H, Hkv, D, K, L, n, M, win_M = (c[k] for k in ("B", "H", "Hkv", "D", "K", "L", "n", "M", "win_M"))
+    BH = B * H
+    keys, kns, vals, W, qb, wk, wv, qn, results, nnz = _window_merge_oracle_parts(c, g)
+    assert np.array_equal(nnz, g["nnz"])                 # the torch collision mask selects the same tokens
+    # -- sampled half: the literal f32 formula (exp_mode 0) within the reference's tolerance
+    srv = oracle.SparseAttentionServer(exp_mode=0)
+    srv.alloc(1, H, Hkv, D, B, M)
+    for b in range(B):
+        srv.fill(0, b, keys[b], vals[b], kns[b])
+    sp_out = np.zeros((BH, D), np.uint16)
+    sp_mve = np.zeros((2, BH), np.float32)
+    srv.attention_wrapper(0, K, L, sp_out, sp_mve, qb, qn, results, nnz)
+    assert np.allclose(sp_mve[1], g["sparse_lse"], atol=5e-3)
+    assert np.allclose(synth.bf16_bits_to_f32(sp_out), synth.bf16_bits_to_f32(g["sparse_out"]), rtol=1e-2, atol=1e-2)
+    # -- window: full_attention over the first win_rows[b] rows of a second store
+    wsrv = oracle.SparseAttentionServer()
+    wsrv.alloc(1, H, Hkv, D, B, win_M)
+    for b in range(B):
+        wsrv.fill(0, b, wk[b], wv[b], np.zeros((Hkv, wk[b].shape[1]), np.float32))
+    w_out = np.zeros((BH, D), np.uint16)
+    w_mve = np.zeros((2, BH), np.float32)
+    wnnz = np.repeat(np.array(c["win_rows"], np.int32), H)
+    wsrv.full_attention(0, w_out, w_mve, synth.bf16_bits_to_f32(qb), wnnz)
+    assert np.allclose(w_mve[1], g["window_lse"], atol=1e-4)
+    assert np.allclose(synth.bf16_bits_to_f32(w_out), synth.bf16_bits_to_f32(g["window_out"]), rtol=2 ** -7, atol=1e-5)
+    # -- merge_state on the statement's own partials: bit-level agreement with its f64 evaluation
+    v, s = oracle.merge_state(g["window_out"], g["window_lse"], g["sparse_out"], g["sparse_lse"])
+    assert np.allclose(s, g["merged_lse"], atol=1e-5)
+    assert np.allclose(synth.bf16_bits_to_f32(v), synth.bf16_bits_to_f32(g["merged_out"]), rtol=2 ** -7, atol=1e-6)
+    assert (v == g["merged_out"]).mean() > 0.99
+    # -- the defining property: merged == one softmax over the union (up to the bf16 rounding of the partials)
+    assert np.allclose(s, g["joint_lse"], atol=1e-4)
+    assert np.allclose(synth.bf16_bits_to_f32(v), g["joint_out"], rtol=2 ** -6, atol=2e-3)
+    # -- and end to end from the oracle's own partials
+    v2, s2 = oracle.merge_state(w_out, w_mve[1], sp_out, sp_mve[1])
+    assert np.allclose(s2, g["joint_lse"], atol=5e-3)
+    assert np.allclose(synth.bf16_bits_to_f32(v2), g["joint_out"], rtol=1e-2, atol=1e-2)
