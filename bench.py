@@ -342,8 +342,8 @@ def main():
             codes, _ = server.hasher.query(q_static[li].reshape(BH, D))
             bounds, _ = server.lsh_retriever.get_tables(li)
             g = torch.arange(BH, device=dev) // (H // Hkv)
-            be = bounds[g[:, None], torch.arange(Lt, device=dev)[None, :], codes.long()]   # [BH, L, 2]
-            cand_obs.append((be[..., 1] - be[..., 0]).sum(-1))
+            be = bounds[g[:, None], torch.arange(Lt, device=dev)[None, :], codes.long()]   # [BH, L, R + 1]
+            cand_obs.append((be[..., -1] - be[..., 0]).sum(-1))
     torch.cuda.synchronize()
     nnz_all = torch.stack(nnz_obs).float()
     nnz_mean = float(nnz_all.mean())

@@ -104,8 +104,13 @@ int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream);    /* LSH::clear            l
  * batch_retrieve call (recomputed on demand; the hot path keeps only bitmaps in LDS). */
 int mp_lsh_get_mask(mp_lsh_t* h, int8_t* mask, int mem, mp_stream_t stream);
 /* debug views (the reference declares get_table*, lsh.h:24-26, but never defines them):
- * bounds int32 [B*Hkv, L, NB, 2] = (start, end) interleaved; table int32 [B*Hkv, L, M]. */
+ * bounds int32 [B*Hkv, L, NB, R+1]: entry 0 = start and entry R = end of a bucket inside its table row (the
+ * reference's table_start / table_end, lsh.h:38-39), entry r = first position of the bucket whose token id is
+ * >= r * range_len (ids ascend inside a bucket when R > 1); table int32 [B*Hkv, L, M].
+ * R (1, 2, 4 or 8) is the number of token ranges a table row is cut into = the number of workgroups that serve
+ * one query head in mp_decode_sparse_layer, chosen at alloc from B*H and the device's CU count. */
 int mp_lsh_get_tables(mp_lsh_t* h, int layer_id, void** bounds_dev, void** table_dev);
+int mp_lsh_get_ranges(mp_lsh_t* h, int* ranges, int* range_len);
 
 /* ---------------------------------------------------------------- sparse attention */
 int mp_attn_create(mp_attn_t** out);                  /* sparse_attention.cc:519-527 */
@@ -168,7 +173,8 @@ int mp_debug_xcd_round_robin(void);
 /* Debug: A/B switches for measurements and tests, process-wide, read at every call (never needed in
  * production; unknown names return MP_ERR_INVALID):
  *   "decode_two_launch"  0/1   mp_decode_sparse_layer as (hash + retrieve) then attention: two launches
- *   "decode_cluster"     0 = auto, n = workgroups per head of the one-launch decode (clamped to [1, 8])
+ *   "decode_cluster"     0 = auto, n = workgroups per head of the one-launch decode = token ranges of the
+ *                        tables (rounded down to 1, 2, 4 or 8); read by mp_lsh_alloc
  *   "decode_agent_scope" 0/1   cluster hand-off through memory even where the XCD placement was observed
  *   "attn_head_kernel"   -1 = auto, 0 = split-KV kernel with the in-launch ticket merge, 1 = one workgroup per head
  *   "attn_gx"            0 = auto, n = split-KV workgroups per head */

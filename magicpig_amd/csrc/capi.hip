@@ -21,23 +21,27 @@ hipError_t launch_simhash_query(const uint16_t*, const uint16_t*, const float*, 
 hipError_t launch_simhash_keys(const uint16_t*, const uint16_t*, const float*, int, int64_t, int,
                                int, int, int16_t*, hipStream_t);
 size_t retrieve_lds_bytes(int64_t M, int L);
-bool lsh_decode_supported(int64_t M, int L, int D);
+int lsh_range_len(int64_t M, int R);
+bool lsh_decode_supported(int64_t M, int L, int D, int R);
 bool xcd_round_robin_verified();
-hipError_t launch_lsh_decode(const int2*, const int32_t*, const uint16_t*, const uint16_t*, const float*, int,
+hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, const uint16_t*, const float*, int,
                              int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
-                             float*, float2*, int*, uint16_t*, float*, float2*, float*, int, int, bool,
+                             float*, float2*, int*, int*, uint16_t*, float*, float2*, float*, int*, int, int, bool,
                              const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t, hipStream_t);
-hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int2*,
+hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
                            int32_t*, int*, hipStream_t);
-hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int2*, int32_t*, int*,
+hipError_t launch_lsh_unsort(const int16_t*, const int32_t*, int, int64_t, int16_t*, hipStream_t);
+hipError_t launch_lsh_subbounds(const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
+hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int, int32_t*, int32_t*, int*,
                             hipStream_t);
-hipError_t launch_lsh_retrieve(const int2*, const int32_t*, const int32_t*, int32_t*, int32_t*, int,
-                               int, int, int, int64_t, hipStream_t);
-hipError_t launch_lsh_hash_retrieve(const int2*, const int32_t*, const uint16_t*, const uint16_t*,
+hipError_t launch_lsh_retrieve(const int32_t*, const int32_t*, const int32_t*, int32_t*, int32_t*, int,
+                               int, int, int, int64_t, int, hipStream_t);
+hipError_t launch_lsh_hash_retrieve(const int32_t*, const int32_t*, const uint16_t*, const uint16_t*,
                                     const float*, int, int, int, int32_t*, float*, int32_t*, int32_t*,
-                                    int, int, int, int, int64_t, hipStream_t);
-hipError_t launch_lsh_mask(const int2*, const int32_t*, const int32_t*, int8_t*, int, int, int, int,
-                           int64_t, hipStream_t);
+                                    int, int, int, int, int64_t, int, hipStream_t);
+hipError_t launch_lsh_compact(uint32_t*, const int*, int, int, int64_t, hipStream_t);
+hipError_t launch_lsh_mask(const int32_t*, const int32_t*, const int32_t*, int8_t*, int, int, int, int,
+                           int64_t, int, hipStream_t);
 int attn_slices_per_head(int64_t M);
 int attn_supported_head_dim(int D);
 hipError_t launch_attn_sparse(int, bool, bool, const uint16_t*, const float*, const void*, const float*,
@@ -153,8 +157,11 @@ struct mp_lsh {
     bool allocated = false;
     int K = 0, L = 0, NB = 0, layers = 0, H = 0, Hkv = 0, B = 0, G = 0;
     int64_t M = 0;
-    std::vector<int2*> bounds;     // per layer [B*Hkv][L][NB]
+    int R = 1;                     // token ranges per table row = workgroups per head of the decode kernel
+    int range_len = 0;             // tokens per range (multiple of 32)
+    std::vector<int32_t*> bounds;  // per layer [B*Hkv][L][NB][R+1]
     std::vector<int32_t*> table;   // per layer [B*Hkv][L][M]
+    int* part_cnt = nullptr;       // [BH][8] per-member selected counts of the last decode launch
     int32_t* last_query = nullptr; // [BH][L] staging copy of host-side query codes
     const int32_t* lastq = nullptr;// device codes of the last retrieve (for get_mask): last_query,
                                    // `codes`, or the caller's own device buffer (valid until it changes)
@@ -184,6 +191,8 @@ struct mp_attn {
     const int32_t* lastz = nullptr;// device nnz of the last call (for get_score): last_nnz or the
                                    // caller's own device buffer (valid until it changes)
     int score_state = 0;           // 0 none, 1 logits, 2 probabilities
+    const int* seg_cnt = nullptr;  // score rows are in R segments (decode kernel, R > 1): per-member counts,
+    int seg_R = 1;                 // compacted on demand by mp_attn_get_score
     int grid = 8;                  // workgroups per head of the partial kernel (grid.x)
     bool head_kernel = false;      // one workgroup per head (attn_head_kernel) instead of split-KV
     bool xcd_rr = false;           // block b -> XCD b % 8 observed on this device (xcd_round_robin_verified)
@@ -312,10 +321,10 @@ static void lsh_free(mp_lsh_t* h) {
     for (auto p : h->table) if (p) (void)hipFree(p);
     h->bounds.clear();
     h->table.clear();
-    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm};
+    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->part_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->last_query = nullptr; h->err = nullptr; h->codes = nullptr; h->results = nullptr;
-    h->nnz = nullptr; h->qnorm = nullptr;
+    h->nnz = nullptr; h->qnorm = nullptr; h->part_cnt = nullptr;
     h->allocated = false;
 }
 
@@ -326,6 +335,8 @@ int mp_lsh_destroy(mp_lsh_t* h) {
     delete h;
     return MP_OK;
 }
+
+static int decode_cluster_size(int BH, int64_t M);
 
 int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_heads,
                  int num_key_value_heads, int batch_size, int max_length) {
@@ -346,14 +357,17 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
     h->H = num_attention_heads; h->Hkv = num_key_value_heads; h->B = batch_size;
     h->G = h->H / h->Hkv; h->M = max_length;
     const size_t groups = (size_t)h->B * h->Hkv, BH = (size_t)h->B * h->H;
+    h->R = decode_cluster_size((int)BH, h->M);
+    h->range_len = lsh_range_len(h->M, h->R);
     int rc = MP_OK;
     for (int i = 0; i < num_layers && rc == MP_OK; ++i) {
         void* b = nullptr; void* t = nullptr;
-        rc = alloc_zero(&b, groups * L * h->NB * sizeof(int2));
+        rc = alloc_zero(&b, groups * L * h->NB * (size_t)(h->R + 1) * 4);
         if (rc == MP_OK) rc = alloc_zero(&t, groups * L * (size_t)h->M * 4);
-        h->bounds.push_back((int2*)b);
+        h->bounds.push_back((int32_t*)b);
         h->table.push_back((int32_t*)t);
     }
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->part_cnt, BH * 8 * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->last_query, BH * L * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->err, 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->codes, BH * L * 4);
@@ -365,6 +379,24 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
     return MP_OK;
 }
 
+// Workgroups per query head of the one-launch decode (= token ranges of the tables): spread a head over
+// several CUs while there are idle ones.  Measured: 16 and 32 members lose more in the hand-off and in L2
+// plane traffic than they gain.
+static int decode_cluster_size(int BH, int64_t M) {
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        cus = prop.multiProcessorCount;
+    int cluster = cus / (BH > 0 ? BH : 1);
+    if (const int o = g_opt.decode_cluster.load(); o >= 1) cluster = o;      // A/B switch, read at alloc
+    if (cluster > 8) cluster = 8;
+    const int64_t slices = (M + 63) / 64;
+    if (cluster > slices) cluster = (int)slices;
+    int r = 1;
+    while (2 * r <= cluster) r *= 2;
+    return r;
+}
+
 static int lsh_check_slot(mp_lsh_t* h, int layer_id, int request_id, int64_t n, const char* who) {
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, std::string(who) + ": not allocated");
     MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, std::string(who) + ": layer_id out of range");
@@ -373,15 +405,17 @@ static int lsh_check_slot(mp_lsh_t* h, int layer_id, int request_id, int64_t n, 
     return MP_OK;
 }
 
-static int lsh_read_err(mp_lsh_t* h, hipStream_t st, const char* who) {
+// reads and clears the device flag: bit 0 -> MP_ERR_DATA; *unsorted (optional) <- bit 2 (a bucket whose ids
+// do not ascend: not an error, the caller re-sorts)
+static int lsh_read_err(mp_lsh_t* h, hipStream_t st, const char* who, bool* unsorted = nullptr) {
     int flag = 0;
     MP_HIP_CHECK(hipMemcpyAsync(&flag, h->err, 4, hipMemcpyDeviceToHost, st));
     MP_HIP_CHECK(hipStreamSynchronize(st));
-    if (flag) {
-        MP_HIP_CHECK(hipMemsetAsync(h->err, 0, 4, st));
+    if (flag) MP_HIP_CHECK(hipMemsetAsync(h->err, 0, 4, st));
+    if (unsorted) *unsorted = (flag & 4) != 0;
+    if (flag & 1)
         return fail(MP_ERR_DATA, std::string(who) + ": device-side validation failed (codes not sorted / "
                                                     "out of [0, 2^K) or token id out of [0, max_length))");
-    }
     return MP_OK;
 }
 
@@ -399,11 +433,27 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
     if (rc) return rc;
     rc = stage_in(sorted_ids, (size_t)rows * n * 4, mem, di, &i);
     if (rc) return rc;
-    int2* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB;
+    int32_t* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB * (h->R + 1);
     int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
-    MP_HIP_CHECK(launch_lsh_fill((const int16_t*)c, (const int32_t*)i, rows, n, h->NB, h->M, b, t,
+    MP_HIP_CHECK(launch_lsh_fill((const int16_t*)c, (const int32_t*)i, rows, n, h->NB, h->M, h->R, b, t,
                                  h->err, st));
-    return lsh_read_err(h, st, "mp_lsh_fill");
+    bool unsorted = false;
+    rc = lsh_read_err(h, st, "mp_lsh_fill", &unsorted);
+    if (rc) return rc;
+    if (unsorted) {
+        // R > 1 and some bucket's ids do not ascend (an unstable sort, models/attnserver.py:187): put the codes
+        // back in token order and let the device counting sort rebuild the rows -- same buckets, ascending ids
+        DevBuf tok;
+        MP_HIP_CHECK(tok.alloc((size_t)rows * n * 2));
+        MP_HIP_CHECK(hipMemsetAsync(tok.p, 0xff, (size_t)rows * n * 2, st));      // code -1: a token no id named
+        MP_HIP_CHECK(launch_lsh_unsort((const int16_t*)c, (const int32_t*)i, rows, n, tok.as<int16_t>(), st));
+        MP_HIP_CHECK(launch_lsh_build(tok.as<int16_t>(), rows, n, h->NB, h->M, h->R, b, t, h->err, st));
+        rc = lsh_read_err(h, st, "mp_lsh_fill");       // a token missing from the id list shows up as code -1
+        if (rc) return rc;
+    }
+    MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, st));
+    if (mem == MP_MEM_HOST) MP_HIP_CHECK(hipStreamSynchronize(st));
+    return MP_OK;
 }
 
 int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes, int64_t n,
@@ -418,9 +468,10 @@ int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes
     const void* c = nullptr;
     rc = stage_in(codes, (size_t)rows * n * 2, mem, dc, &c);
     if (rc) return rc;
-    int2* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB;
+    int32_t* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB * (h->R + 1);
     int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
-    MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, b, t, h->err, st));
+    MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, h->R, b, t, h->err, st));
+    MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, st));
     return lsh_read_err(h, st, "mp_lsh_build");
 }
 
@@ -437,7 +488,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
         h->lastq = query;
         h->last_layer = layer_id;
         MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], query, results,
-                                         nnz, BH, h->G, h->L, h->NB, h->M, st));
+                                         nnz, BH, h->G, h->L, h->NB, h->M, h->R, st));
         return MP_OK;
     }
     // host callers (models/attnserver.py:299 passes pinned CPU tensors): stage through the
@@ -446,7 +497,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     h->lastq = h->last_query;
     h->last_layer = layer_id;
     MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], h->last_query,
-                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, st));
+                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, st));
     MP_HIP_CHECK(hipStreamSynchronize(st));
     MP_HIP_CHECK(hipMemcpy(nnz, h->nnz, (size_t)BH * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < BH; ++i)
@@ -462,7 +513,7 @@ int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     const size_t groups = (size_t)h->B * h->Hkv;
     for (int i = 0; i < h->layers; ++i) {
-        MP_HIP_CHECK(hipMemsetAsync(h->bounds[i], 0, groups * h->L * h->NB * sizeof(int2), st));
+        MP_HIP_CHECK(hipMemsetAsync(h->bounds[i], 0, groups * h->L * h->NB * (size_t)(h->R + 1) * 4, st));
         MP_HIP_CHECK(hipMemsetAsync(h->table[i], 0, groups * h->L * (size_t)h->M * 4, st));
     }
     h->last_layer = -1;
@@ -488,7 +539,7 @@ int mp_lsh_get_mask(mp_lsh_t* h, int8_t* mask, int mem, mp_stream_t stream) {
         d = tmp.as<int8_t>();
     }
     MP_HIP_CHECK(launch_lsh_mask(h->bounds[h->last_layer], h->table[h->last_layer], h->lastq,
-                                 d, BH, h->G, h->L, h->NB, h->M, st));
+                                 d, BH, h->G, h->L, h->NB, h->M, h->R, st));
     if (mem == MP_MEM_HOST) {
         MP_HIP_CHECK(hipStreamSynchronize(st));
         MP_HIP_CHECK(hipMemcpy(mask, d, bytes, hipMemcpyDeviceToHost));
@@ -501,6 +552,13 @@ int mp_lsh_get_tables(mp_lsh_t* h, int layer_id, void** bounds_dev, void** table
     MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_lsh_get_tables: layer_id out of range");
     if (bounds_dev) *bounds_dev = h->bounds[layer_id];
     if (table_dev) *table_dev = h->table[layer_id];
+    return MP_OK;
+}
+
+int mp_lsh_get_ranges(mp_lsh_t* h, int* ranges, int* range_len) {
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_lsh_get_ranges: not allocated");
+    if (ranges) *ranges = h->R;
+    if (range_len) *range_len = h->range_len;
     return MP_OK;
 }
 
@@ -643,6 +701,10 @@ int mp_attn_check(mp_attn_t* h, mp_stream_t stream) {
     MP_HIP_CHECK(hipStreamSynchronize(st));
     if (flag) {
         MP_HIP_CHECK(hipMemsetAsync(h->err, 0, 4, st));
+        if (flag & 4)
+            return fail(MP_ERR_STATE, "mp_attn_check: a decode cluster ran on another XCD than the placement "
+                                      "observed at alloc (stream with a CU mask / partition change): its hand-off "
+                                      "may have read stale partials; set the decode_agent_scope option");
         return fail(MP_ERR_DATA, "mp_attn_check: an append hit a full store (position >= max_length)");
     }
     return MP_OK;
@@ -663,6 +725,8 @@ static int attn_run(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint16
                                     grid, head_kernel, st));
     h->lastz = nnz;
     h->score_state = 1;
+    h->seg_cnt = nullptr;
+    h->seg_R = 1;
     return MP_OK;
 }
 
@@ -789,6 +853,12 @@ int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream) {
     MP_REQUIRE(score_dev, MP_ERR_INVALID, "mp_attn_get_score: null argument");
     hipStream_t st = (hipStream_t)stream;
     if (h->score_state == 1) {
+        if (h->seg_cnt != nullptr && h->seg_R > 1) {   // one-launch decode: R per-member segments -> one list
+            MP_HIP_CHECK(launch_lsh_compact(reinterpret_cast<uint32_t*>(h->score), h->seg_cnt, h->B * h->H,
+                                            h->seg_R, h->M, st));
+            h->seg_cnt = nullptr;
+            h->seg_R = 1;
+        }
         MP_HIP_CHECK(launch_attn_normalize(h->score, h->lastz, h->head_mz, h->B * h->H, h->M, st));
         h->score_state = 2;
     }
@@ -818,7 +888,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
     lsh->lastq = lsh->codes;
     lsh->last_layer = layer_id;
     const bool two_launch = g_opt.decode_two_launch.load() != 0;                // A/B switch
-    const bool fused = !two_launch && lsh_decode_supported(lsh->M, lsh->L, s->D);
+    const bool fused = !two_launch && lsh_decode_supported(lsh->M, lsh->L, s->D, lsh->R);
     if (win != nullptr) {
         MP_REQUIRE(win->allocated && win_len, MP_ERR_INVALID, w + ": window store not allocated / null win_len");
         MP_REQUIRE(win->B == attn->B && win->H == attn->H && win->Hkv == attn->Hkv && win->D == attn->D &&
@@ -830,32 +900,26 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
     }
     if (fused) {
         // a-1 .. a-12 (models/attnserver.py:264-300) in ONE launch: hash -> retrieve -> attention of a
-        // head inside one workgroup cluster; the selected ids stay in LDS.  Cluster size: spread a
-        // head over several CUs while there are idle ones.
-        int cluster = attn->cus / BH;
-        if (cluster > 8) cluster = 8;     // measured: 16 and 32 members lose more in the hand-off and in L2 plane traffic than they gain
-        if (cluster > attn_slices_per_head(attn->M)) cluster = attn_slices_per_head(attn->M);
-        if (cluster < 1) cluster = 1;
-        if (const int o = g_opt.decode_cluster.load(); o >= 1) {      // A/B switch, clamped like the default
-            cluster = o > 8 ? 8 : o;
-            if (cluster > attn_slices_per_head(attn->M)) cluster = attn_slices_per_head(attn->M);
-        }
+        // head inside a cluster of lsh->R workgroups, each owning one token range of the head's tables;
+        // the selected ids stay in LDS.
         MP_HIP_CHECK(launch_lsh_decode(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk, s->wnorm, s->D,
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
-                                       attn->head_cnt, output, max_value_expsum, attn->head_mz, attn->score,
-                                       attn_slices_per_head(attn->M), cluster,
+                                       lsh->part_cnt, attn->head_cnt, output, max_value_expsum, attn->head_mz,
+                                       attn->score, attn->err, attn_slices_per_head(attn->M), lsh->R,
                                        attn->xcd_rr && g_opt.decode_agent_scope.load() == 0,
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
                                        lsh->L, lsh->NB, lsh->M, st));
         attn->lastz = lsh->nnz;
         attn->score_state = 1;
+        attn->seg_cnt = lsh->R > 1 ? lsh->part_cnt : nullptr;
+        attn->seg_R = lsh->R;
     } else {
         // two launches: (hash + retrieve), then attention (models/attnserver.py:264-299, :300)
         MP_HIP_CHECK(launch_lsh_hash_retrieve(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk,
                                               s->wnorm, s->D, s->K, s->KLpad, lsh->codes, lsh->qnorm,
                                               lsh->results, lsh->nnz, BH, lsh->G, lsh->L, lsh->NB, lsh->M,
-                                              st));
+                                              lsh->R, st));
         int rc = attn_run(attn, layer_id, false, s->K, s->L, output, max_value_expsum, q, MP_DTYPE_BF16,
                           lsh->qnorm, lsh->results, lsh->nnz, st);
         if (rc) return rc;

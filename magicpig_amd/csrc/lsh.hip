@@ -4,10 +4,17 @@
 // (:210-288), get_mask (:308-314).  Integer work, bit-exact as a set + nnz.
 //
 // HBM layout (per layer):
-//   bounds int2  [B*Hkv][L][NB]   (start, end) of bucket b of table l -- the reference keeps
-//                                  two arrays (lsh.h:38-39); interleaving makes the per-step
-//                                  probe ONE 8-byte random read instead of two 4-byte ones;
-//   table  int32 [B*Hkv][L][M]    token ids in code-sorted order, row stride M (lsh.h:40).
+//   bounds int32 [B*Hkv][L][NB][R+1]  positions in the table row that cut bucket b of table l into R
+//                                  token ranges: entry 0 = start, entry R = end of the bucket (the
+//                                  reference's table_start / table_end, lsh.h:38-39, interleaved: a probe
+//                                  is one 8-byte-wide random read), entry r = first position whose token id
+//                                  is >= r * range_len.  R = 1, 2, 4 or 8 = the number of workgroups that
+//                                  serve one query head in the decode kernel (fixed at alloc): member r of
+//                                  a head's cluster probes entries (r, r+1) and streams, counts, emits and
+//                                  gathers ONLY the tokens of its range -- nothing is replicated;
+//   table  int32 [B*Hkv][L][M]    token ids in code-sorted order, ASCENDING inside a bucket when R > 1
+//                                  (the device build emits them so; mp_lsh_fill checks and re-sorts),
+//                                  row stride M (lsh.h:40).
 //
 // retrieve: the CPU code is serial per head with a byte mask in DRAM (lsh.cc:266-283).  Here
 // one workgroup owns a head: the collision state of all M tokens lives in LDS as two bitmaps
@@ -34,23 +41,26 @@ constexpr int RT_TAIL_CAP = 2048;          // pooled chunk descriptors for ids b
 constexpr int RT_TAIL_UNROLL = 8;
 
 // ---------------------------------------------------------------- LSH::fill
-// grid = Hkv*L rows of one request; one workgroup per (kv head, table) row.
+// grid = Hkv*L rows of one request; one workgroup per (kv head, table) row.  RS = R + 1 entries per
+// bucket: this kernel writes entries 0 (start) and R (end); lsh_subbounds_kernel fills the rest.
+// err bits: 1 = invalid input (unsorted codes, code or id out of range); 4 = ids not ascending inside a
+// bucket (only looked at when R > 1; the host then re-sorts the row's buckets on device).
 __global__ __launch_bounds__(256) void lsh_fill_kernel(
     const int16_t* __restrict__ codes,   // [Hkv*L][n] sorted ascending per row
     const int32_t* __restrict__ ids,     // [Hkv*L][n]
-    int64_t n, int NB, int64_t M,
-    int2* __restrict__ bounds,           // [Hkv*L][NB]   (this request's slice)
+    int64_t n, int NB, int64_t M, int RS,
+    int32_t* __restrict__ bounds,        // [Hkv*L][NB][RS]   (this request's slice)
     int32_t* __restrict__ table,         // [Hkv*L][M]
     int* __restrict__ err) {
     const int64_t row = blockIdx.x;
     const int16_t* c = codes + row * n;
     const int32_t* src = ids + row * n;
-    int2* b = bounds + row * NB;
+    int32_t* b = bounds + row * NB * RS;
     int32_t* dst = table + row * M;
     // buckets that do not occur keep start = end = 0 (lsh.cc:177-185 on zeroed arrays)
-    for (int i = threadIdx.x; i < NB; i += blockDim.x) b[i] = make_int2(0, 0);
+    for (int i = threadIdx.x; i < NB * RS; i += blockDim.x) b[i] = 0;
     __syncthreads();
-    bool bad = false;
+    bool bad = false, unsorted = false;
     for (int64_t k = threadIdx.x; k < n; k += blockDim.x) {
         const int v = c[k];
         const int prev = (k > 0) ? (int)c[k - 1] : -1;
@@ -59,12 +69,51 @@ __global__ __launch_bounds__(256) void lsh_fill_kernel(
         if (v < 0 || v >= NB || v < prev || id < 0 || id >= M) {
             bad = true;
         } else {
-            if (v != prev) b[v].x = (int)k;        // first position of value v
-            if (v != next) b[v].y = (int)(k + 1);  // one past the last
+            if (v != prev) b[v * RS] = (int)k;                  // first position of value v
+            else if (RS > 2 && id <= src[k - 1]) unsorted = true;
+            if (v != next) b[v * RS + RS - 1] = (int)(k + 1);   // one past the last
         }
         dst[k] = id;
     }
     if (bad) atomicOr(err, 1);
+    if (unsorted) atomicOr(err, 4);
+}
+
+// codes of a reference-sorted row back in token order (the fallback of mp_lsh_fill when a bucket's ids are
+// not ascending -- torch.sort without stable=True, models/attnserver.py:187): tok[row][ids[k]] = codes[k];
+// the row is then rebuilt by lsh_build_kernel, which emits ascending ids.
+__global__ void lsh_unsort_kernel(const int16_t* __restrict__ codes, const int32_t* __restrict__ ids,
+                                  int64_t n, int16_t* __restrict__ tok) {
+    const int64_t row = blockIdx.y;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t id = ids[row * n + k];
+        if (id >= 0 && id < n) tok[row * n + id] = codes[row * n + k];
+    }
+}
+
+// entries 1 .. R-1 of every bucket: first position of the bucket whose token id is >= r * range_len
+// (ids ascend inside a bucket).  One workgroup per (kv head, table) row, one thread per bucket, R - 1
+// binary searches each over a table row that was just written (L2 hits).
+__global__ __launch_bounds__(256) void lsh_subbounds_kernel(
+    const int32_t* __restrict__ table, int32_t* __restrict__ bounds, int NB, int R, int range_len, int64_t M) {
+    const int64_t row = blockIdx.x;
+    const int RS = R + 1;
+    const int32_t* t = table + row * M;
+    int32_t* b = bounds + row * NB * RS;
+    for (int i = threadIdx.x; i < NB; i += blockDim.x) {
+        const int st = b[i * RS], en = b[i * RS + R];
+        int lo = st;
+        for (int r = 1; r < R; ++r) {
+            const int target = r * range_len;
+            int hi = en;                                  // first position in [lo, en) with t[p] >= target
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (t[mid] < target) lo = mid + 1;
+                else hi = mid;
+            }
+            b[i * RS + r] = lo;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- device-side table build
@@ -97,7 +146,7 @@ __device__ __forceinline__ unsigned long long match_any_bits(int v, bool ok, int
 // of the bucket totals: writes bounds, returns each bucket's start through `start_of(i, ex, v)`.
 template <typename F>
 __device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ c, int n, int NB,
-                                                    int* s_cnt, int* s_tmp, int2* __restrict__ b,
+                                                    int* s_cnt, int* s_tmp, int32_t* __restrict__ b, int RS,
                                                     int* __restrict__ err, F&& start_of) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     for (int i = tid; i < nw * NB; i += blockDim.x) s_cnt[i] = 0;
@@ -125,7 +174,8 @@ __device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ 
         __syncthreads();
         const int ex = block_excl_scan(v, s_tmp, total) + carry;
         if (i < NB) {
-            b[i] = (v > 0) ? make_int2(ex, ex + v) : make_int2(0, 0);
+            b[i * RS] = (v > 0) ? ex : 0;
+            b[i * RS + RS - 1] = (v > 0) ? ex + v : 0;
             start_of(i, ex, v);
         }
         carry += total;
@@ -137,7 +187,7 @@ __device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ 
 template <int TPL>   // tokens per lane and tile: T = TPL * blockDim.x
 __global__ __launch_bounds__(1024) void lsh_build_kernel(
     const int16_t* __restrict__ codes,   // [Hkv*L][n] unsorted
-    int n, int NB, int nbits, int64_t M, int2* __restrict__ bounds, int32_t* __restrict__ table,
+    int n, int NB, int nbits, int64_t M, int RS, int32_t* __restrict__ bounds, int32_t* __restrict__ table,
     int* __restrict__ err) {
     extern __shared__ int s_mem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -151,7 +201,7 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
     const int64_t row = blockIdx.x;
     const int16_t* c = codes + row * n;
     int32_t* dst = table + row * M;
-    build_row_histogram(c, n, NB, s_cnt, s_tmp, bounds + row * NB, err,
+    build_row_histogram(c, n, NB, s_cnt, s_tmp, bounds + row * NB * RS, RS, err,
                         [&](int i, int ex, int) { s_gbase[i] = ex; });
     int* mine = s_cnt + wave * NB;
     for (int t0 = 0; t0 < n; t0 += T) {
@@ -225,15 +275,15 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
 // Direct variant for NB too large for the staged layout (K >= 14): the row is cut into one
 // contiguous segment per wave and the waves scatter straight to HBM from private cursors.
 __global__ __launch_bounds__(1024) void lsh_build_direct_kernel(
-    const int16_t* __restrict__ codes, int n, int NB, int nbits, int64_t M,
-    int2* __restrict__ bounds, int32_t* __restrict__ table, int* __restrict__ err) {
+    const int16_t* __restrict__ codes, int n, int NB, int nbits, int64_t M, int RS,
+    int32_t* __restrict__ bounds, int32_t* __restrict__ table, int* __restrict__ err) {
     extern __shared__ int s_mem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     int* s_cnt = s_mem;                  // [nw][NB] per-wave histogram, then per-wave cursors
     int* s_tmp = s_mem + nw * NB;
     const int64_t row = blockIdx.x;
     const int16_t* c = codes + row * n;
-    int2* b = bounds + row * NB;
+    int32_t* b = bounds + row * NB * RS;
     int32_t* dst = table + row * M;
     for (int i = tid; i < nw * NB; i += blockDim.x) s_cnt[i] = 0;
     __syncthreads();
@@ -259,7 +309,8 @@ __global__ __launch_bounds__(1024) void lsh_build_direct_kernel(
         __syncthreads();
         const int ex = block_excl_scan(v, s_tmp, total) + carry;
         if (i < NB) {
-            b[i] = (v > 0) ? make_int2(ex, ex + v) : make_int2(0, 0);
+            b[i * RS] = (v > 0) ? ex : 0;
+            b[i * RS + RS - 1] = (v > 0) ? ex + v : 0;
             int run = ex;
             for (int w = 0; w < nw; ++w) {
                 const int t = s_cnt[w * NB + i];
@@ -287,9 +338,10 @@ __global__ __launch_bounds__(1024) void lsh_build_direct_kernel(
 }
 
 // ---------------------------------------------------------------- LSH::batch_retrieve
-// grid = B*H (one workgroup per query head), block = 1024, dynamic LDS:
+// block = 1024, dynamic LDS:
 //   A[words] | B[words] | s_start[Lpad] | s_len[Lpad] | s_tail[RT_TAIL_CAP] | s_tmp[32] | s_ntail
-// `words` = ceil(M/32) words per bitmap.
+// `words` = words per collision bitmap = ceil(tokens the workgroup owns / 32): all M tokens of the head in
+// the stand-alone retrieve (grid = B*H), one RANGE of M / R tokens in the decode kernel (grid = R * B*H).
 // HASH = true fuses the query SimHash of models/attnserver.py:264-270 into the prologue: the head's
 // query row is normalised (bf16 semantics as simhash.hip), every thread evaluates <= 2 hyperplanes
 // from the chunk-major plane copy Wk[D/8][KLpad][8] (coalesced 16-byte loads, 128 f32 FMAs each,
@@ -305,23 +357,28 @@ struct HashArgs {
 };
 
 // AD > 0 (with HASH) appends the sparse attention of the head to the same launch (attn_head.h): the
-// selected ids never leave the workgroup's LDS.  A head is served by a CLUSTER of 1, 2, 4 or 8
-// workgroups (grid = cluster * BH, block b -> head b % BH, rank b / BH): every member repeats the
-// hash + retrieve of the head (identical bitmaps, the table ids come from L2), keeps the ids of the
-// 32-entry slices rank, rank + cluster, ... and gathers only those; with cluster > 1 the members' states meet
-// through one write-through partial each and an arrival ticket.  cluster = 1 when every CU has a head.
+// selected ids never leave the workgroup's LDS.  A head is served by a CLUSTER of R = 1, 2, 4 or 8
+// workgroups (grid = R * BH, block b -> head b % BH, rank b / BH).  The head's TOKENS are partitioned over
+// the members: member r owns tokens [r * range_len, (r + 1) * range_len).  Every bucket's ids ascend, so
+// the part of a probed bucket that falls into the range is the contiguous piece between the bucket's
+// sub-bounds r and r + 1: the member reads that pair, streams only that piece, counts collisions in a bitmap
+// of range_len bits, emits and gathers its own selected tokens.  Only the query hash is repeated by the
+// members; with R > 1 their softmax states meet through one partial each and an arrival ticket.
 struct AttnArgs {
     const uint16_t* kv;      // [B*Hkv][M][2][D]
     const float* kn;         // [B*Hkv][M]
     float* part_o;           // [BH][maxs][D]
     float2* part_ml;         // [BH][maxs]
+    int* part_cnt;           // [BH][8] selected tokens of every member (R > 1)
     int* head_cnt;           // [BH] arrival tickets, zero between launches
     uint16_t* out;           // [BH][D] bf16
     float* mve;              // [2][BH]
     float2* head_mz;         // [BH]
-    float* score;            // [BH][M] (nullable)
+    float* score;            // [BH][M] (nullable); member r's logits start at column r * range_len
+    int* err;                // device flag: bit 4 = a cluster member ran on another XCD than observed
     int BH, maxs, cap, cluster_log2;   // cap: ids of the LDS stage (multiple of AH_SLICE)
     int same_xcd;            // the members of a cluster share one XCD (and its L2): verified by the host
+    uint32_t xcc_expect;     // same_xcd: XCC_ID observed for block residue b % 8, 4 bits each
     // optional static window (models/attnserver.py:281-308): exact attention over the first win_len[h]
     // rows of a second KV store joins the same softmax, which IS flashinfer.merge_state of the two parts
     const uint16_t* win_kv;  // [B*Hkv][win_M][2][D] or nullptr
@@ -333,10 +390,10 @@ template <bool HASH, int CH, int AD, bool WIN>   // CH = min(16, D / 8): plane c
                                                  // WIN: fold the static window in (its own instantiation, so the
                                                  // plain decode kernel carries none of its code)
 __device__ __forceinline__ void lsh_head_body(
-    const int2* __restrict__ bounds, const int32_t* __restrict__ table,
+    const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
-    int G, int L, int NB, int64_t M, int words, int Lpad, const HashArgs& ha, const AttnArgs& aa,
-    unsigned long long* __restrict__ stamp) {
+    int G, int L, int NB, int64_t M, int R, int range_len, int words, int Lpad, const HashArgs& ha,
+    const AttnArgs& aa, unsigned long long* __restrict__ stamp) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_u32[];
     uint32_t* bmA = s_u32;
     uint32_t* bmB = s_u32 + words;
@@ -361,10 +418,16 @@ __device__ __forceinline__ void lsh_head_body(
     const int64_t h = (AD > 0) ? (int64_t)(blockIdx.x % aa.BH) : (int64_t)blockIdx.x;
     const int rank = (AD > 0) ? (int)(blockIdx.x / aa.BH) : 0;
     const int clog = (AD > 0) ? aa.cluster_log2 : 0;
-    const bool lead = rank == 0;                              // the member that writes codes / ||q|| / results / nnz
+    const bool lead = rank == 0;                              // the member that writes codes / ||q||
     const int64_t g = h / G;
-    const int2* bnd = bounds + g * L * NB;
+    const int RS = R + 1;
+    const int32_t* bnd = bounds + g * L * NB * RS;
     const int32_t* tab = table + g * L * M;
+    // the tokens this workgroup owns: [t0, t0 + tlen); sub-bound entries (e_lo, e_hi) of every probed bucket
+    const int e_lo = (AD > 0) ? rank : 0, e_hi = (AD > 0) ? rank + 1 : R;
+    const int64_t t0 = (AD > 0) ? (int64_t)rank * range_len : 0;
+    const int64_t trem = M - t0;
+    const uint32_t tlen = (AD > 0) ? (uint32_t)(trem <= 0 ? 0 : (trem < range_len ? trem : range_len)) : (uint32_t)M;
 
     MP_STAMP(stamp, 16);
     if (tid == 0) *s_ntail = 0;
@@ -473,7 +536,8 @@ __device__ __forceinline__ void lsh_head_body(
     }
     __syncthreads();
     MP_STAMP(stamp, 27);
-    // probe: one 8-byte random read per table (issued first: longest latency)
+    // probe: the two sub-bounds of this workgroup's token range, adjacent 4-byte words of the bucket's record
+    // (issued first: longest latency)
     for (int l = tid; l < Lpad; l += RT_THREADS) {
         int st = 0, len = 0;
         if (l < L) {
@@ -488,9 +552,10 @@ __device__ __forceinline__ void lsh_head_body(
                 code = query[h * L + l];
             }
             if (code >= 0 && code < NB) {
-                const int2 be = bnd[(int64_t)l * NB + code];
-                st = be.x;
-                len = be.y - be.x;
+                const int32_t* rec = bnd + ((int64_t)l * NB + code) * RS;
+                const int lo = rec[e_lo], hi = rec[e_hi];
+                st = lo;
+                len = hi - lo;
                 if (st < 0 || len < 0 || (int64_t)st + len > M) len = 0;
             }
         }
@@ -508,14 +573,15 @@ __device__ __forceinline__ void lsh_head_body(
     MP_STAMP(stamp, 17);
     MP_STAMP(stamp, 18);
 
-    // stream the probed buckets: wave w owns tables w, w+16, ...; per round it keeps RT_GROUP
-    // buckets x 2 chunks of 64 ids (<= 128 ids per bucket) in flight, then applies them
-    const uint32_t M32 = (uint32_t)M;                                   // M <= 2^22 (mp_lsh_alloc)
+    // stream the probed pieces: wave w owns tables w, w+16, ...; per round it keeps RT_GROUP
+    // pieces x 2 chunks of 64 ids (<= 128 ids per piece) in flight, then applies them
+    const uint32_t T0 = (uint32_t)t0;                                   // M <= 2^22 (mp_lsh_alloc)
     auto apply = [&](int32_t t) {
-        if ((uint32_t)t < M32) {                                        // one unsigned compare: 0 <= t < M
-            const uint32_t bit = 1u << (t & 31);
-            const uint32_t old = atomicOr(&bmA[t >> 5], bit);           // first hit: 0 -> 1
-            if (old & bit) atomicOr(&bmB[t >> 5], bit);                 // any later hit: -> 2
+        const uint32_t u = (uint32_t)t - T0;                            // token index inside the range
+        if (u < tlen) {                                                 // one unsigned compare: t0 <= t < t0 + tlen
+            const uint32_t bit = 1u << (u & 31);
+            const uint32_t old = atomicOr(&bmA[u >> 5], bit);           // first hit: 0 -> 1
+            if (old & bit) atomicOr(&bmB[u >> 5], bit);                 // any later hit: -> 2
         }
     };
     for (int l0 = wave; l0 < L; l0 += RT_WAVES * RT_GROUP) {
@@ -538,7 +604,7 @@ __device__ __forceinline__ void lsh_head_body(
             apply(id1[b]);
         }
     }
-    // ids beyond the first 128 of a bucket (skewed data): pooled 64-id chunks, waves take them
+    // ids beyond the first 128 of a piece (skewed data): pooled 64-id chunks, waves take them
     // round-robin with RT_TAIL_UNROLL loads in flight
     const int ntail = __builtin_amdgcn_readfirstlane(*s_ntail);
     if (ntail <= RT_TAIL_CAP) {
@@ -557,7 +623,7 @@ __device__ __forceinline__ void lsh_head_body(
 #pragma unroll
             for (int u = 0; u < RT_TAIL_UNROLL; ++u) apply(idt[u]);
         }
-    } else {   // pool overflow (> 128 K extra ids per head): plain strided sweep of every long bucket
+    } else {   // pool overflow (> 128 K extra ids per head): plain strided sweep of every long piece
         for (int l = 0; l < L; ++l) {
             const int len = s_len[l];
             if (len <= 128) continue;
@@ -570,7 +636,9 @@ __device__ __forceinline__ void lsh_head_body(
 
     // sweep B: contiguous words per thread, block-wide exclusive scan, ascending emission
     int cnt = 0;
-    int32_t* out = results + h * M;
+    // the stand-alone retrieve writes the head's list; a decode member writes ITS list at column t0 of the
+    // head's row (a by-product: get_score's order, the spill path below), nnz is summed at the hand-off
+    int32_t* out = results + h * M + t0;
     const int nsw = words;
     const int wpt = (nsw + RT_THREADS - 1) / RT_THREADS;
     const int w0 = tid * wpt;
@@ -579,30 +647,21 @@ __device__ __forceinline__ void lsh_head_body(
     int total;
     int off = block_excl_scan(cnt, s_tmp, total);
     MP_STAMP(stamp, 20);
-    // AD: the ids of slices rank, rank + cluster, ... stay in LDS; when the list is longer than the
-    // stage holds (cap * cluster ids) every member also writes the (identical) list to HBM and reads
-    // its own copy back.
-    const bool spill = AD > 0 && total > (aa.cap << clog);
-    const bool to_hbm = AD == 0 || lead || spill;
+    // AD: the member's ids stay in LDS; a list longer than the stage (cap ids) is read back from HBM
+    const bool spill = AD > 0 && total > aa.cap;
     for (int k = 0; k < wpt; ++k) {
         if (w0 + k >= nsw) break;
         uint32_t bits = bmB[w0 + k];
-        const int base = (w0 + k) << 5;
+        const int base = (int)T0 + ((w0 + k) << 5);
         while (bits) {
             const int p = __ffs((int)bits) - 1;
             bits &= bits - 1;
-            if (to_hbm) out[off] = base + p;
-            if (AD > 0) {
-                const int sl = off / AH_SLICE;
-                if ((sl & ((1 << clog) - 1)) == rank) {
-                    const int li = (sl >> clog) * AH_SLICE + (off % AH_SLICE);
-                    if (li < aa.cap) s_ids[li] = base + p;
-                }
-            }
+            out[off] = base + p;
+            if (AD > 0 && off < aa.cap) s_ids[off] = base + p;
             ++off;
         }
     }
-    if (tid == 0 && lead) nnz[h] = total;
+    if (tid == 0 && (AD == 0 || clog == 0)) nnz[h] = total;
     MP_STAMP(stamp, 21);
     if (AD == 0) return;
 
@@ -614,8 +673,8 @@ __device__ __forceinline__ void lsh_head_body(
         wlen = aa.win_len[h];
         wlen = wlen < 0 ? 0 : (wlen > aa.win_M ? (int)aa.win_M : wlen);
     }
-    if (total == 0 && wlen == 0) {          // every member sees the same list
-        if (lead) attn_head_empty<ADD>(out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
+    if (clog == 0 && total == 0 && wlen == 0) {
+        attn_head_empty<ADD>(out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
         return;
     }
     __syncthreads();                        // s_ids complete; the spilled list drained (vmcnt) and visible in L2
@@ -623,34 +682,34 @@ __device__ __forceinline__ void lsh_head_body(
     // two instantiations of the sparse fold: the LDS path carries no global load ahead of its gathers
     float m, Z, o;
     const u32x4 qv = *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADD / 8)) * 4);
-    float* score_h = aa.score ? aa.score + h * M : nullptr;
+    float* score_h = aa.score ? aa.score + h * M + t0 : nullptr;
     const uint16_t* kv_g = aa.kv + g * M * 2 * ADD;
     const float* kn_g = aa.kn + g * M;
     auto ids_lds = [&](int k, int j) { return *reinterpret_cast<const u32x4*>(s_ids + k * AH_SLICE + j); };
     auto ids_hbm = [&](int k, int j) {
         u32x4 v = {0u, 0u, 0u, 0u};
-        const int64_t j0 = (((int64_t)k << clog) + rank) * AH_SLICE + j;
+        const int64_t j0 = (int64_t)k * AH_SLICE + j;
         for (int e = 0; e < 4; ++e)
-            v[e] = (j0 + e < M) ? (uint32_t)__builtin_nontemporal_load(out + j0 + e) : 0u;
+            v[e] = (j0 + e < (int64_t)tlen) ? (uint32_t)__builtin_nontemporal_load(out + j0 + e) : 0u;
         return v;
     };
     if (!WIN) {                             // fold + merge as one straight path per id source
         if (!spill)
-            attn_head_tail<ADD, RT_WAVES>(kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, rank, 1 << clog, ids_lds,
+            attn_head_tail<ADD, RT_WAVES>(kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1, ids_lds,
                                           s_merge, score_h, stamp, m, Z, o);
         else
-            attn_head_tail<ADD, RT_WAVES>(kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, rank, 1 << clog, ids_hbm,
+            attn_head_tail<ADD, RT_WAVES>(kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1, ids_hbm,
                                           s_merge, score_h, stamp, m, Z, o);
     } else {
         AhState st = ah_state_init(lane, ADD / 8);
         if (!spill)
-            attn_head_fold<ADD, RT_WAVES, false>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, rank, 1 << clog,
+            attn_head_fold<ADD, RT_WAVES, false>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
                                                  ids_lds, score_h, stamp);
         else
-            attn_head_fold<ADD, RT_WAVES, false>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, rank, 1 << clog,
+            attn_head_fold<ADD, RT_WAVES, false>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
                                                  ids_hbm, score_h, stamp);
-        if (wlen > 0) {                     // the static window: dense slices (k runs from `wave` again, so the
-                                            // waves that got no sparse slice of this member are served first)
+        if (wlen > 0) {                     // the static window: dense slices rank, rank + R, ... (k runs from
+                                            // `wave` again, so the waves that got no sparse slice are served first)
             auto none = [](int, int) { return u32x4{0u, 0u, 0u, 0u}; };
             attn_head_fold<ADD, RT_WAVES, true>(st, aa.win_kv + g * aa.win_M * 2 * ADD, nullptr, qv, 1.f, wlen,
                                                 aa.win_M, 0, 0, rank, 1 << clog, none, nullptr, stamp);
@@ -662,27 +721,35 @@ __device__ __forceinline__ void lsh_head_body(
         MP_STAMP(stamp, 39);
         return;
     }
-    // ---- cluster > 1: publish this member's state, drain, take an arrival ticket; the member that
-    // draws the last ticket merges (hand-off recipe: cdna_hip_programming.md G16, as
-    // attn_sparse_kernel).  Block b runs on XCD b % 8, so when B*H is a multiple of 8 the members of a
-    // cluster (blocks h, h + BH, ...) share ONE XCD and its L2: the hand-off then only has to bypass the
-    // per-CU L1 (sc0, the workgroup scope of a split workgroup) instead of writing through to the
+    // ---- cluster > 1: publish this member's state (a member without tokens publishes m = -inf, Z = 0), drain,
+    // take an arrival ticket; the member that draws the last ticket merges (hand-off recipe:
+    // cdna_hip_programming.md G16, as attn_sparse_kernel).  Block b runs on XCD b % 8, so when B*H is a multiple
+    // of 8 the members of a cluster (blocks h, h + BH, ...) share ONE XCD and its L2: the hand-off then only has
+    // to bypass the per-CU L1 (sc0, the workgroup scope of a split workgroup) instead of writing through to the
     // memory side (sc1), which takes three ~0.6 us L2 round trips instead of three ~1.8 us ones.  The
-    // host enables it only after xcd_round_robin_verified() has seen the placement on this device.
+    // host enables it only after xcd_round_robin_verified() has seen the placement on this device, and every
+    // member checks its own XCC_ID against that observation (err bit 4 otherwise: mp_attn_check reports it).
     const int nmem = 1 << clog;
     const int64_t pre = h * aa.maxs;
     float mr[8], zr[8], orr[8];
+    int cr[8];
     if (aa.same_xcd) {
+        if (tid == 0) {
+            const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
+            if (xcc != ((aa.xcc_expect >> (4 * (blockIdx.x & 7))) & 15u)) atomicOr(aa.err, 4);
+        }
         constexpr int kSc0 = 1;   // aux bit 0 = sc0 on gfx940+
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
             aa.part_o + pre * ADD, 0, (int)(aa.maxs * ADD * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<float*>(aa.part_ml + pre), 0, (int)(aa.maxs * 8), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(aa.part_cnt + h * 8, 0, 32, 0x00020000);
         if (tid < ADD)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro, (rank * ADD + tid) * 4, 0, kSc0);
         if (tid == 0) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rm, rank * 8, 0, kSc0);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Z), rm, rank * 8 + 4, 0, kSc0);
+            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)total, rc, rank * 4, 0, kSc0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -698,10 +765,12 @@ __device__ __forceinline__ void lsh_head_body(
                 mr[u] = -INFINITY;
                 zr[u] = 0.f;
                 orr[u] = 0.f;
+                cr[u] = 0;
                 if (u < nmem) {
                     mr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, u * 8, 0, kSc0));
                     zr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, u * 8 + 4, 0, kSc0));
                     orr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (u * ADD + tid) * 4, 0, kSc0));
+                    cr[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rc, u * 4, 0, kSc0);
                 }
             }
         }
@@ -709,10 +778,12 @@ __device__ __forceinline__ void lsh_head_body(
         if (tid < ADD)
             __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + tid),
                                __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0)
+        if (tid == 0) {
             __hip_atomic_store(reinterpret_cast<unsigned long long*>(aa.part_ml + pre + rank),
                                (unsigned long long)__float_as_uint(m) | ((unsigned long long)__float_as_uint(Z) << 32),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(aa.part_cnt + h * 8 + rank, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0)
@@ -727,6 +798,7 @@ __device__ __forceinline__ void lsh_head_body(
                 mr[u] = -INFINITY;
                 zr[u] = 0.f;
                 orr[u] = 0.f;
+                cr[u] = 0;
                 if (u < nmem) {
                     const unsigned long long pk = __hip_atomic_load(
                         reinterpret_cast<unsigned long long*>(aa.part_ml + pre + u), __ATOMIC_RELAXED,
@@ -736,24 +808,34 @@ __device__ __forceinline__ void lsh_head_body(
                     orr[u] = __uint_as_float(__hip_atomic_load(
                         reinterpret_cast<unsigned int*>(aa.part_o + (pre + u) * ADD + tid), __ATOMIC_RELAXED,
                         __HIP_MEMORY_SCOPE_AGENT));
+                    cr[u] = __hip_atomic_load(aa.part_cnt + h * 8 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
     }
     if (tid < ADD) {
         float mm = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) mm = fmaxf(mm, mr[u]);
-        float ZZ = 0.f, oo = 0.f;
+        int csum = 0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (u < nmem && mr[u] != -INFINITY) {
-                const float e = __expf(mr[u] - mm);
-                ZZ = fmaf(e, zr[u], ZZ);
-                oo = fmaf(e, orr[u], oo);
-            }
+            mm = fmaxf(mm, mr[u]);
+            csum += cr[u];
         }
-        attn_head_finalize<ADD>(mm, ZZ, oo, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
+        if (tid == 0) nnz[h] = csum;
+        if (mm == -INFINITY) {                              // no member had a token (nor a window row)
+            attn_head_empty<ADD>(out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
+        } else {
+            float ZZ = 0.f, oo = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u < nmem && mr[u] != -INFINITY) {
+                    const float e = __expf(mr[u] - mm);
+                    ZZ = fmaf(e, zr[u], ZZ);
+                    oo = fmaf(e, orr[u], oo);
+                }
+            }
+            attn_head_finalize<ADD>(mm, ZZ, oo, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
+        }
     }
     MP_STAMP(stamp, 39);
 }
@@ -761,33 +843,59 @@ __device__ __forceinline__ void lsh_head_body(
 // LSH::batch_retrieve (optionally with the query hash as its prologue)
 template <bool HASH, int CH>
 __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
-    const int2* __restrict__ bounds, const int32_t* __restrict__ table,
+    const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
-    int G, int L, int NB, int64_t M, int words, int Lpad, HashArgs ha,
+    int G, int L, int NB, int64_t M, int R, int words, int Lpad, HashArgs ha,
     unsigned long long* __restrict__ stamp) {
     const AttnArgs aa = {};
-    lsh_head_body<HASH, CH, 0, false>(bounds, table, query, results, nnz, G, L, NB, M, words, Lpad, ha, aa, stamp);
+    lsh_head_body<HASH, CH, 0, false>(bounds, table, query, results, nnz, G, L, NB, M, R, 0, words, Lpad, ha, aa, stamp);
 }
 
 // the whole sparse layer of models/attnserver.py:264-300: hash -> retrieve -> attention
 template <int CH, int AD, bool WIN>
 __global__ __launch_bounds__(RT_THREADS) void lsh_decode_kernel(
-    const int2* __restrict__ bounds, const int32_t* __restrict__ table,
+    const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     int32_t* __restrict__ results, int32_t* __restrict__ nnz,
-    int G, int L, int NB, int64_t M, int words, int Lpad, HashArgs ha, AttnArgs aa,
+    int G, int L, int NB, int64_t M, int R, int range_len, int words, int Lpad, HashArgs ha, AttnArgs aa,
     unsigned long long* __restrict__ stamp) {
-    lsh_head_body<true, CH, AD, WIN>(bounds, table, nullptr, results, nnz, G, L, NB, M, words, Lpad, ha, aa, stamp);
+    lsh_head_body<true, CH, AD, WIN>(bounds, table, nullptr, results, nnz, G, L, NB, M, R, range_len, words, Lpad,
+                                     ha, aa, stamp);
+}
+
+// The decode kernel leaves member r's selected ids / logits at column r * range_len of the head's row; this
+// moves the R segments of every row down into one contiguous list (get_score's `ind` order).  One workgroup
+// per head; a segment only ever moves to lower addresses, chunk by chunk (read, barrier, write, barrier).
+__global__ __launch_bounds__(1024) void lsh_compact_segments_kernel(uint32_t* __restrict__ rows,
+                                                                   const int* __restrict__ part_cnt, int R,
+                                                                   int range_len, int64_t M) {
+    const int64_t h = blockIdx.x;
+    uint32_t* row = rows + h * M;
+    int off = part_cnt[h * 8];
+    for (int r = 1; r < R; ++r) {
+        const int cnt = part_cnt[h * 8 + r];
+        const int64_t src = (int64_t)r * range_len;
+        if (off != src) {
+            for (int base = 0; base < cnt; base += blockDim.x) {
+                const int j = base + threadIdx.x;
+                const uint32_t v = (j < cnt) ? row[src + j] : 0u;
+                __syncthreads();
+                if (j < cnt) row[off + j] = v;
+                __syncthreads();
+            }
+        }
+        off += cnt;
+    }
 }
 
 // ---------------------------------------------------------------- LSH::get_mask (debug view)
 // Recomputes min(count, 2) per token for the last query codes; byte counters in global memory,
-// one workgroup per head, atomics on 32-bit words holding 4 counters... kept simple: each
-// workgroup zeroes its row, then applies saturating increments with atomicCAS on words.
+// one workgroup per head: each workgroup zeroes its row, then walks the probed buckets table by table.
 __global__ __launch_bounds__(256) void lsh_mask_kernel(
-    const int2* __restrict__ bounds, const int32_t* __restrict__ table,
-    const int32_t* __restrict__ query, int8_t* __restrict__ mask, int G, int L, int NB, int64_t M) {
+    const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
+    const int32_t* __restrict__ query, int8_t* __restrict__ mask, int G, int L, int NB, int64_t M, int R) {
     const int64_t h = blockIdx.x;
     const int64_t g = h / G;
+    const int RS = R + 1;
     int8_t* row = mask + h * M;
     for (int64_t i = threadIdx.x; i < M; i += blockDim.x) row[i] = 0;
     __syncthreads();
@@ -796,9 +904,10 @@ __global__ __launch_bounds__(256) void lsh_mask_kernel(
     for (int l = 0; l < L; ++l) {
         const int code = query[h * L + l];
         if (code < 0 || code >= NB) continue;
-        const int2 be = bounds[(g * L + l) * NB + code];
+        const int32_t* rec = bounds + ((g * L + l) * NB + code) * RS;
+        const int bx = rec[0], by = rec[R];
         const int32_t* src = table + (g * L + l) * M;
-        for (int j = be.x + threadIdx.x; j < be.y; j += blockDim.x) {
+        for (int j = bx + threadIdx.x; j < by; j += blockDim.x) {
             const int32_t t = src[j];
             if (t >= 0 && t < M && row[t] < 2) row[t] = row[t] + 1;
         }
@@ -825,16 +934,37 @@ struct DeviceOnce {
     }
 };
 
-size_t retrieve_lds_bytes(int64_t M, int L) {
+// dynamic LDS of the retrieve body for a workgroup that owns `tokens` tokens
+static size_t body_lds_bytes(int64_t tokens, int L) {
     const int Lpad = (L + 63) & ~63;
     // + fused-hash scratch: 128 words of query, 4 of norm, sign bits of up to 16*L planes (+ ballot slack)
-    return (size_t)(2 * ((M + 31) / 32) + 2 * Lpad + RT_TAIL_CAP + 64 + 140 + (16 * L + 31) / 32 + 2 * RT_WAVES + 4) * 4;
+    return (size_t)(2 * ((tokens + 31) / 32) + 2 * Lpad + RT_TAIL_CAP + 64 + 140 + (16 * L + 31) / 32 + 2 * RT_WAVES + 4) * 4;
+}
+size_t retrieve_lds_bytes(int64_t M, int L) { return body_lds_bytes(M, L); }
+
+// tokens per range for a head split over R workgroups (multiple of 32: whole bitmap words)
+int lsh_range_len(int64_t M, int R) { return (int)((((M + R - 1) / R) + 31) & ~(int64_t)31); }
+
+hipError_t launch_lsh_subbounds(const int32_t* table, int32_t* bounds, int rows, int NB, int R, int64_t M,
+                                hipStream_t st) {
+    if (R <= 1) return hipSuccess;
+    hipLaunchKernelGGL(lsh_subbounds_kernel, dim3(rows), dim3(256), 0, st, table, bounds, NB, R, lsh_range_len(M, R), M);
+    return hipGetLastError();
 }
 
 hipError_t launch_lsh_fill(const int16_t* codes, const int32_t* ids, int rows, int64_t n, int NB,
-                           int64_t M, int2* bounds, int32_t* table, int* err, hipStream_t st) {
-    hipLaunchKernelGGL(lsh_fill_kernel, dim3(rows), dim3(256), 0, st, codes, ids, n, NB, M, bounds,
+                           int64_t M, int R, int32_t* bounds, int32_t* table, int* err, hipStream_t st) {
+    hipLaunchKernelGGL(lsh_fill_kernel, dim3(rows), dim3(256), 0, st, codes, ids, n, NB, M, R + 1, bounds,
                        table, err);
+    return hipGetLastError();
+}
+
+hipError_t launch_lsh_unsort(const int16_t* codes, const int32_t* ids, int rows, int64_t n, int16_t* tok,
+                             hipStream_t st) {
+    int gx = (int)((n + 255) / 256);
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(lsh_unsort_kernel, dim3(gx, rows), dim3(256), 0, st, codes, ids, n, tok);
     return hipGetLastError();
 }
 
@@ -850,8 +980,9 @@ static bool build_staged_geometry(int NB, int& nw, int& tpl, size_t& lds) {
     return lds <= 160u * 1024u;
 }
 
-hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, int64_t M,
-                            int2* bounds, int32_t* table, int* err, hipStream_t st) {
+// bounds entries 0 and R + the table; launch_lsh_subbounds fills entries 1 .. R-1 afterwards
+hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, int64_t M, int R,
+                            int32_t* bounds, int32_t* table, int* err, hipStream_t st) {
     static DeviceOnce once;
     const hipError_t attr_err = once.run([] {
         const void* fns[] = {reinterpret_cast<const void*>(lsh_build_kernel<8>),
@@ -870,11 +1001,12 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     while ((1 << nbits) < NB) ++nbits;
     int nw, tpl;
     size_t lds;
+    const int RS = R + 1;
     if (build_staged_geometry(NB, nw, tpl, lds)) {
 #define MP_BUILD_CASE(TPL)                                                                         \
         if (tpl == TPL)                                                                            \
             hipLaunchKernelGGL(lsh_build_kernel<TPL>, dim3(rows), dim3(64 * nw), lds, st, codes,   \
-                               (int)n, NB, nbits, M, bounds, table, err);
+                               (int)n, NB, nbits, M, RS, bounds, table, err);
         MP_BUILD_CASE(8) MP_BUILD_CASE(16) MP_BUILD_CASE(32)
 #undef MP_BUILD_CASE
         return hipGetLastError();
@@ -883,25 +1015,30 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     if (nw > 16) nw = 16;
     lds = ((size_t)nw * NB + 64) * 4;
     hipLaunchKernelGGL(lsh_build_direct_kernel, dim3(rows), dim3(64 * nw), lds, st, codes, (int)n, NB,
-                       nbits, M, bounds, table, err);
+                       nbits, M, RS, bounds, table, err);
     return hipGetLastError();
 }
 
 // ---- where do blocks land?  The cluster hand-off of lsh_decode_kernel may stay inside one XCD's L2
 // only if block b really runs on XCD b % 8.  That is measured, once per process and device: every
-// block of two probe launches reports its XCC_ID.
+// block of two probe launches reports its XCC_ID; the decode kernel re-checks every launch.
 __global__ void xcc_probe_kernel(int* __restrict__ out) {
     if (threadIdx.x == 0) out[blockIdx.x] = (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
 }
 
-bool xcd_round_robin_verified() {
+// false = not observed; else *map gets the XCC_ID of block residue b % 8 in bits 4b .. 4b+3
+bool xcd_round_robin_map(uint32_t* map) {
     static std::mutex mu;
-    static int states[64];   // per device: 0 unknown, 1 no, 2 yes
+    static int states[64];        // per device: 0 unknown, 1 no, 2 yes
+    static uint32_t maps[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     std::lock_guard<std::mutex> lock(mu);
     int& state = states[dev];
-    if (state != 0) return state == 2;
+    if (state != 0) {
+        if (map) *map = maps[dev];
+        return state == 2;
+    }
     state = 1;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(nullptr, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
@@ -925,14 +1062,20 @@ bool xcd_round_robin_verified() {
     for (int a = 0; a < 8; ++a)
         for (int b = a + 1; b < 8; ++b)
             if (hbuf[a] == hbuf[b]) return false;                        // 8 distinct XCDs
+    uint32_t m = 0;
+    for (int a = 0; a < 8; ++a) m |= (uint32_t)hbuf[a] << (4 * a);
+    maps[dev] = m;
     state = 2;
+    if (map) *map = m;
     return true;
 }
 
-constexpr int DECODE_ID_CAP = 4096;   // ids of the fused kernel's LDS stage per workgroup (64 slices)
+bool xcd_round_robin_verified() { return xcd_round_robin_map(nullptr); }
 
-static size_t decode_lds_bytes(int64_t M, int L, int D) {
-    return retrieve_lds_bytes(M, L) + ((size_t)DECODE_ID_CAP + attn_head_lds_floats(RT_WAVES, D) + 16 + 64) * 4;
+constexpr int DECODE_ID_CAP = 4096;   // ids of the fused kernel's LDS stage per workgroup (128 slices)
+
+static size_t decode_lds_bytes(int64_t tokens, int L, int D) {
+    return body_lds_bytes(tokens, L) + ((size_t)DECODE_ID_CAP + attn_head_lds_floats(RT_WAVES, D) + 16 + 64) * 4;
 }
 
 static hipError_t retrieve_attr_set() {
@@ -955,25 +1098,25 @@ static hipError_t retrieve_attr_once() {
     return once.run(retrieve_attr_set);
 }
 
-hipError_t launch_lsh_retrieve(const int2* bounds, const int32_t* table, const int32_t* query,
+hipError_t launch_lsh_retrieve(const int32_t* bounds, const int32_t* table, const int32_t* query,
                                int32_t* results, int32_t* nnz, int BH, int G, int L, int NB,
-                               int64_t M, hipStream_t st) {
+                               int64_t M, int R, hipStream_t st) {
     const int words = (int)((M + 31) / 32);
     const int Lpad = (L + 63) & ~63;
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
     HashArgs ha = {};
     hipLaunchKernelGGL((lsh_retrieve_kernel<false, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
-                       st, bounds, table, query, results, nnz, G, L, NB, M, words, Lpad, ha, g_stamp);
+                       st, bounds, table, query, results, nnz, G, L, NB, M, R, words, Lpad, ha, g_stamp);
     return hipGetLastError();
 }
 
 // q-hash fused into the retrieve (the two-launch form of mp_decode_sparse_layer): codes and ||q||
 // are by-products
-hipError_t launch_lsh_hash_retrieve(const int2* bounds, const int32_t* table, const uint16_t* q,
+hipError_t launch_lsh_hash_retrieve(const int32_t* bounds, const int32_t* table, const uint16_t* q,
                                     const uint16_t* Wk, const float* wnorm, int D, int K, int KLpad,
                                     int32_t* codes_out, float* qnorm_out, int32_t* results,
-                                    int32_t* nnz, int BH, int G, int L, int NB, int64_t M,
+                                    int32_t* nnz, int BH, int G, int L, int NB, int64_t M, int R,
                                     hipStream_t st) {
     const int words = (int)((M + 31) / 32);
     const int Lpad = (L + 63) & ~63;
@@ -982,44 +1125,48 @@ hipError_t launch_lsh_hash_retrieve(const int2* bounds, const int32_t* table, co
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
     if (D >= 128)
         hipLaunchKernelGGL((lsh_retrieve_kernel<true, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
-                           st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, words,
+                           st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, R, words,
                            Lpad, ha, g_stamp);
     else
         hipLaunchKernelGGL((lsh_retrieve_kernel<true, 8>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
-                           st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, words,
+                           st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, R, words,
                            Lpad, ha, g_stamp);
     return hipGetLastError();
 }
 
 // the whole sparse layer in ONE launch (mp_decode_sparse_layer): hash + retrieve + attention.
-// D = 64 or 128; cluster = workgroups per head (1, 2, 4 or 8).
-bool lsh_decode_supported(int64_t M, int L, int D) {
-    return (D == 64 || D == 128) && decode_lds_bytes(M, L, D) <= 160u * 1024u;
+// D = 64 or 128; R = workgroups per head = token ranges of the tables (1, 2, 4 or 8).
+bool lsh_decode_supported(int64_t M, int L, int D, int R) {
+    return (D == 64 || D == 128) && decode_lds_bytes(lsh_range_len(M, R), L, D) <= 160u * 1024u;
 }
 
-hipError_t launch_lsh_decode(const int2* bounds, const int32_t* table, const uint16_t* q,
+hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const uint16_t* q,
                              const uint16_t* Wk, const float* wnorm, int D, int K, int KLpad,
                              int32_t* codes_out, float* qnorm_out, int32_t* results, int32_t* nnz,
-                             const uint16_t* kv, const float* kn, float* part_o, float2* part_ml,
-                             int* head_cnt, uint16_t* out, float* mve, float2* head_mz, float* score,
-                             int maxs, int cluster, bool same_xcd, const uint16_t* win_kv,
+                             const uint16_t* kv, const float* kn, float* part_o, float2* part_ml, int* part_cnt,
+                             int* head_cnt, uint16_t* out, float* mve, float2* head_mz, float* score, int* err,
+                             int maxs, int R, bool same_xcd, const uint16_t* win_kv,
                              const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
                              hipStream_t st) {
-    const int words = (int)((M + 31) / 32);
+    const int range_len = lsh_range_len(M, R);
+    const int words = range_len / 32;
     const int Lpad = (L + 63) & ~63;
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
     int clog = 0;
-    while ((2 << clog) <= cluster && clog < 3) ++clog;
+    while ((1 << clog) < R) ++clog;
+    if ((1 << clog) != R || R > 8) return hipErrorInvalidValue;
+    uint32_t xmap = 0;
+    const bool sx = same_xcd && clog > 0 && BH % 8 == 0 && xcd_round_robin_map(&xmap);
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
-    AttnArgs aa = {kv, kn, part_o, part_ml, head_cnt, out, mve, head_mz, score, BH, maxs, DECODE_ID_CAP, clog,
-                   (same_xcd && clog > 0 && BH % 8 == 0) ? 1 : 0, win_kv, win_len, win_M};
+    AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, score, err, BH, maxs,
+                   DECODE_ID_CAP, clog, sx ? 1 : 0, xmap, win_kv, win_len, win_M};
     const dim3 grid((unsigned)BH << clog);
-    const size_t lds = decode_lds_bytes(M, L, D);
+    const size_t lds = decode_lds_bytes(range_len, L, D);
 #define MP_DECODE_CASE(DD, CHH, WW)                                                                         \
     if (D == DD && (win_kv != nullptr) == WW) {                                                             \
         hipLaunchKernelGGL((lsh_decode_kernel<CHH, DD, WW>), grid, dim3(RT_THREADS), lds, st, bounds, table, \
-                           results, nnz, G, L, NB, M, words, Lpad, ha, aa, g_stamp);                        \
+                           results, nnz, G, L, NB, M, R, range_len, words, Lpad, ha, aa, g_stamp);          \
         return hipGetLastError();                                                                           \
     }
     MP_DECODE_CASE(128, 16, false)
@@ -1030,10 +1177,17 @@ hipError_t launch_lsh_decode(const int2* bounds, const int32_t* table, const uin
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_lsh_mask(const int2* bounds, const int32_t* table, const int32_t* query,
-                           int8_t* mask, int BH, int G, int L, int NB, int64_t M, hipStream_t st) {
+hipError_t launch_lsh_compact(uint32_t* rows, const int* part_cnt, int BH, int R, int64_t M, hipStream_t st) {
+    if (R <= 1) return hipSuccess;
+    hipLaunchKernelGGL(lsh_compact_segments_kernel, dim3(BH), dim3(1024), 0, st, rows, part_cnt, R,
+                       lsh_range_len(M, R), M);
+    return hipGetLastError();
+}
+
+hipError_t launch_lsh_mask(const int32_t* bounds, const int32_t* table, const int32_t* query,
+                           int8_t* mask, int BH, int G, int L, int NB, int64_t M, int R, hipStream_t st) {
     hipLaunchKernelGGL(lsh_mask_kernel, dim3(BH), dim3(256), 0, st, bounds, table, query, mask, G,
-                       L, NB, M);
+                       L, NB, M, R);
     return hipGetLastError();
 }
 

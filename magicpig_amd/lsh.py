@@ -34,6 +34,9 @@ class LSH:
         self.H, self.Hkv, self.B, self.M = (num_attention_heads, num_key_value_heads, batch_size,
                                             max_length)
         self.NB = 1 << K
+        r, rl = C.c_int(0), C.c_int(0)
+        L.check(L.lib().mp_lsh_get_ranges(self._h, C.byref(r), C.byref(rl)))
+        self.R, self.range_len = r.value, rl.value      # token ranges per table row (= workgroups per head in decode)
         self._device = L.current_device()      # the handle's state lives here (the C ABI switches to it)
         self._alloc = True
 
@@ -88,6 +91,7 @@ class LSH:
         L.check(L.lib().mp_lsh_get_tables(self._h, layer_id, C.byref(b), C.byref(t)))
         groups = self.B * self.Hkv
         dev = torch.device("cuda", self._device)
-        bounds = L.device_tensor(b.value, (groups, self.L, self.NB, 2), "<i4", device=dev)
+        # entry 0 = start, entry R = end of a bucket; entry r = first position whose token id >= r * range_len
+        bounds = L.device_tensor(b.value, (groups, self.L, self.NB, self.R + 1), "<i4", device=dev)
         table = L.device_tensor(t.value, (groups, self.L, self.M), "<i4", device=dev)
         return bounds, table

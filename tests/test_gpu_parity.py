@@ -269,7 +269,7 @@ def test_device_table_build_equals_sorted_fill(mp, name):
     bounds, table = bounds.cpu().numpy(), table.cpu().numpy()
     for (gi, l) in [(0, 0), (bounds.shape[0] - 1, bounds.shape[1] - 1)]:
         for b in range(bounds.shape[2]):
-            s, e = bounds[gi, l, b]
+            s, e = bounds[gi, l, b, 0], bounds[gi, l, b, -1]
             assert np.all(np.diff(table[gi, l, s:e]) > 0)
 
 
@@ -816,7 +816,7 @@ def test_server_fill_centres_keys(mp):
     # tables hold every offloaded token exactly once per (kv head, table)
     bounds, table = server.lsh_retriever.get_tables(0)
     assert torch.equal(table[0, 0, :n].sort().values.cpu(), torch.arange(n, dtype=torch.int32))
-    assert int((bounds[..., 1] - bounds[..., 0]).sum()) == Hkv * L * n
+    assert int((bounds[..., -1] - bounds[..., 0]).sum()) == Hkv * L * n
     q = torch.randn((1, H, 1, D), generator=gen).to(torch.bfloat16).cuda()
     out, lse = server.decode(q, 0)
     assert torch.isfinite(out.float()).all()
@@ -965,6 +965,43 @@ def test_table_build_is_a_stable_sort(mp, K, n):
     (ba, ta), (bb, tb) = a.get_tables(0), b.get_tables(0)
     assert torch.equal(ba, bb)
     assert torch.equal(ta[..., :n], tb[..., :n])
+
+
+@pytest.mark.parametrize("H,Hkv,B", [(32, 8, 1), (8, 2, 2), (32, 8, 8)])
+def test_token_range_sub_bounds_and_unstable_fill(mp, H, Hkv, B):
+    """The tables of a decode cluster: every bucket's ids ascend and its R + 1 sub-bounds cut it at the
+    token-range borders (R = workgroups per head, 8 / 8 / 1 for these head counts).  LSH.fill on codes
+    sorted by an UNSTABLE sort (ids shuffled inside every bucket, models/attnserver.py:187) must give the
+    same tables as the device counting sort: it detects the order and re-sorts on device."""
+    K, L, n, M = 6, 7, 5000, 5120
+    NB = 1 << K
+    codes_np = synth.randint(800 + H, 0, NB, (Hkv, L, n)).astype(np.int16)
+    codes_np[0, 0, :] = 3                                   # one row with a single bucket
+    codes = torch.from_numpy(codes_np).cuda()
+    a, b = mp.LSH(), mp.LSH()
+    for x in (a, b):
+        x.alloc(K, L, 1, H, Hkv, B, M)
+    R, rl = a.R, a.range_len
+    assert R == (1 if B * H >= 256 else 8) and rl % 32 == 0 and rl * R >= M
+    a.fastfill(0, B - 1, codes)
+    # unstable order: sort by (code, random key)
+    rnd = torch.from_numpy(synth.randint(9, 0, 1 << 30, (Hkv, L, n))).cuda()
+    order = torch.argsort(codes.long() * (1 << 31) + rnd, dim=-1)
+    b.fill(0, B - 1, torch.gather(codes, -1, order).contiguous(), order.int().contiguous())
+    (ba, ta), (bb, tb) = a.get_tables(0), b.get_tables(0)
+    assert torch.equal(ba, bb) and torch.equal(ta[..., :n], tb[..., :n])
+    ba, ta = ba.cpu().numpy()[(B - 1) * Hkv:], ta.cpu().numpy()[(B - 1) * Hkv:]
+    assert ba.shape == (Hkv, L, NB, R + 1)
+    assert int((ba[..., -1] - ba[..., 0]).sum()) == Hkv * L * n
+    for (g_, l) in [(0, 0), (Hkv - 1, L - 1), (0, 1)]:
+        for bk in range(NB):
+            cuts = ba[g_, l, bk]
+            assert np.all(np.diff(cuts) >= 0)
+            ids = ta[g_, l, cuts[0]:cuts[-1]]
+            assert np.all(np.diff(ids) > 0) and np.all(codes_np[g_, l, ids] == bk)
+            for r in range(R):
+                piece = ta[g_, l, cuts[r]:cuts[r + 1]]
+                assert np.all((piece >= r * rl) & (piece < (r + 1) * rl))
 
 
 def test_table_build_rejects_codes_out_of_range(mp):
