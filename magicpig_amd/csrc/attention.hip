@@ -190,19 +190,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_sparse_kernel(
             if (DENSE) {
                 z = sc * inv_sqrt_d;
             } else {
-                float cs = sc / (qn_h * kn_my);
-                cs = fminf(1.f, fmaxf(-1.f, cs));      // the reference does not clamp (NaN when
-                                                       // a bf16-rounded norm makes cos > 1)
-                const float theta = acosf(cs);
-                const float proba = 1.f - theta * 0.31830988618379067f;
-                const float p = powi_u(proba, K);
-                // w = 1 - (1-p)^(L-1) (L p + 1 - p) = P[>= 2 of L tables collide].  The reference
-                // evaluates this literally in f32 (two powf and a subtraction from 1), which loses
-                // ~3 digits to cancellation wherever w ~ 1e-4; here the same quantity is computed
-                // without the cancellation: log X = (L-1) log1p(-p) + log1p((L-1) p), w = -expm1(log X).
-                const float lm1 = (float)(L - 1);
-                const float w = -expm1f(lm1 * log1pf(-p) + log1pf(lm1 * p));
-                z = sc * inv_sqrt_d - logf(w + 1e-4f);
+                z = importance_logit(sc, qn_h * kn_my, inv_sqrt_d, K, L);
             }
             if (score != nullptr) score[(int64_t)h * M + j_my] = z;
         }
@@ -343,8 +331,7 @@ __global__ __launch_bounds__(1024) void attn_head_kernel(
         return;
     }
     const int32_t* ind_h = ind + (int64_t)h * M;
-    auto ids = [&](int k, int j) {
-        const int64_t j0 = (int64_t)k * AH_SLICE + j;
+    auto ids = [&](int j0) {
         u32x4 v = {0u, 0u, 0u, 0u};
         if (j0 + 3 < M) v = *reinterpret_cast<const u32x4*>(ind_h + j0);
         else
@@ -352,11 +339,11 @@ __global__ __launch_bounds__(1024) void attn_head_kernel(
         return v;
     };
     MP_STAMP(stamp, 33);
-    float m, Z, o;
+    float m, Z, o0, o1;
     const u32x4 qv = *reinterpret_cast<const u32x4*>(query + (int64_t)h * D + (threadIdx.x % (D / 8)) * 8);
-    attn_head_tail<D, 16>(kv + g * M * 2 * D, kn + g * M, qv, qnorm[h], nz, M, K, L, 0, 1,
-                      ids, s_merge, score ? score + (int64_t)h * M : nullptr, stamp, m, Z, o);
-    attn_head_finalize<D>(m, Z, o, out + (int64_t)h * D, mve, BH, h, head_mz);
+    attn_head_tail<D, 16, AH_SLICE>(kv + g * M * 2 * D, kn + g * M, qv, qnorm[h], nz, M, K, L, 0, 1,
+                      ids, s_merge, score ? score + (int64_t)h * M : nullptr, stamp, m, Z, o0, o1);
+    if (threadIdx.x < 64) attn_head_finalize<D>(m, Z, o0, o1, out + (int64_t)h * D, mve, BH, h, head_mz);
     MP_STAMP(stamp, 39);
 }
 

@@ -23,6 +23,67 @@ __device__ __forceinline__ float powi_u(float b, int e) {
     return r;
 }
 
+// ---- the importance weight in ~70 VALU instructions (the libm calls it replaces -- acosf, 2 x log1pf,
+// expm1f, logf -- are ~250; at 16 waves per CU a wave64 instruction occupies its SIMD for 4 cycles, so the
+// transform was 2.7 us of every 32-token round at B*H >= CUs).  All pieces stay at <= ~1e-6 relative error,
+// which the 1e-3 bound on the probabilities and 1 bf16 ulp on the output leave three orders of room for.
+// acos on [-1, 1]: sqrt(1 - |x|) * P7(|x|) (Abramowitz & Stegun 4.4.46, |error| <= 2e-8), reflected for x < 0
+__device__ __forceinline__ float acos_fast(float x) {
+    const float a = fabsf(x);
+    float p = -0.0012624911f;
+    p = fmaf(p, a, 0.0066700901f);
+    p = fmaf(p, a, -0.0170881256f);
+    p = fmaf(p, a, 0.0308918810f);
+    p = fmaf(p, a, -0.0501743046f);
+    p = fmaf(p, a, 0.0889789874f);
+    p = fmaf(p, a, -0.2145988016f);
+    p = fmaf(p, a, 1.5707963050f);
+    const float r = __fsqrt_rn(1.f - a) * p;
+    return x < 0.f ? 3.14159265358979f - r : r;
+}
+// log(1 + x), x > -1: the alternating series to x^9 where |x| < 1/4 (truncation < 4e-7 relative), the native
+// log of 1 + x elsewhere (1 + x is then exact to an ulp of a number away from 1); log1p(-1) = -inf
+__device__ __forceinline__ float log1p_fast(float x) {
+    float s = 0.11111111f;
+    s = fmaf(s, x, -0.125f);
+    s = fmaf(s, x, 0.14285714f);
+    s = fmaf(s, x, -0.16666667f);
+    s = fmaf(s, x, 0.2f);
+    s = fmaf(s, x, -0.25f);
+    s = fmaf(s, x, 0.33333333f);
+    s = fmaf(s, x, -0.5f);
+    s = fmaf(s * x, x, x);
+    return fabsf(x) < 0.25f ? s : __logf(1.f + x);
+}
+// exp(y) - 1: Taylor to y^7 where |y| < 0.3 (truncation < 2e-9 relative), native exp elsewhere (|result| > 1/4)
+__device__ __forceinline__ float expm1_fast(float y) {
+    float s = 1.984127e-4f;
+    s = fmaf(s, y, 1.3888889e-3f);
+    s = fmaf(s, y, 8.3333333e-3f);
+    s = fmaf(s, y, 4.1666667e-2f);
+    s = fmaf(s, y, 0.16666667f);
+    s = fmaf(s, y, 0.5f);
+    s = fmaf(s * y, y, y);
+    return fabsf(y) < 0.3f ? s : __expf(y) - 1.f;
+}
+// transform_kernel (sparse_attention.cc:164-184): logit of a sampled token = q.k / sqrt(D) - log(w + 1e-4),
+// w = P[>= 2 of L tables collide] = 1 - (1-p)^(L-1) (L p + 1 - p), p = (1 - acos(cos) / pi)^K.  The reference
+// evaluates w literally in f32 (two powf and a subtraction from 1), which loses ~3 digits to cancellation
+// wherever w ~ 1e-4; here the same quantity without the cancellation: log X = (L-1) log1p(-p) + log1p((L-1) p),
+// w = -expm1(log X).  cos is clamped to [-1, 1] (the reference NaNs when a bf16-rounded norm makes it > 1).
+__device__ __forceinline__ float importance_logit(float sc, float qn_kn, float inv_sqrt_d, int K, int L) {
+    const float cs = fminf(1.f, fmaxf(-1.f, sc * __frcp_rn(qn_kn)));
+    const float proba = 1.f - acos_fast(cs) * 0.31830988618379067f;
+    float p = 1.f, b = proba;
+    for (int e = K; e; e >>= 1) {          // K is wave-uniform
+        if (e & 1) p *= b;
+        b *= b;
+    }
+    const float lm1 = (float)(L - 1);
+    const float w = -expm1_fast(fmaf(lm1, log1p_fast(-p), log1p_fast(lm1 * p)));
+    return fmaf(sc, inv_sqrt_d, -__logf(w + 1e-4f));
+}
+
 // one reduce-scatter step over lanes l and l^ST: N values -> N/2 values per lane
 template <int N, int ST>
 __device__ __forceinline__ void rs_step_h(float (&v)[8], int lane, int& doff) {
@@ -40,20 +101,10 @@ __device__ __forceinline__ void rs_step_h(float (&v)[8], int lane, int& doff) {
 // LDS scratch of attn_head_tail: NW * (D + 2) floats
 __host__ __device__ constexpr int attn_head_lds_floats(int nw, int D) { return nw * (D + 2); }
 
-constexpr int AH_SLICE = 32;   // entries of the index list per wave step
+constexpr int AH_SLICE = 32;   // entries of the index list per wave step (16 for short lists, attn_head_fold)
 
-// The workgroup owns slices slice0 + slice_stride * k, k = 0, 1, ... of the head's list (a slice is
-// AH_SLICE = 32 consecutive entries); wave w takes k = w, w + NW, ...
-// IDS: callable (int k, int j) -> u32x4 holding entries j .. j+3 of the workgroup's k-th slice
-// (entries past nz are never used, but the call must not fault).
-//
-// A step gathers the K row AND the V row of 32 tokens (64 VGPRs in flight, all that a lane of a
-// 1024-thread workgroup can spare): LPR = D/8 lanes cover a row, a load instruction fetches
-// RPL = 64/LPR rows, UPS = LPR/2 load steps cover RPL * UPS = 32 tokens; token slot of (step u, row
-// group r) is r*UPS + u, so the ids a row group needs are UPS consecutive entries.  The reduce-scatter
-// of the UPS partial dot products over the LPR lanes of a row group ends one step early (st = 2) and
-// finishes with an all-reduce, so lanes c and c^1 both hold the score of slot r*UPS + (c >> 1): the
-// importance transform runs twice per token (VALU is idle anyway), sums count even lanes only.
+// The workgroup owns slices slice0 + slice_stride * k, k = 0, 1, ... of the head's list (a slice is SLICE
+// consecutive entries); wave w takes k = w, w + NW, ...  Layout of a step: see attn_head_fold.
 
 // a wave's running softmax state over the slices it has folded in
 struct AhState {
@@ -74,7 +125,17 @@ __device__ __forceinline__ AhState ah_state_init(int lane, int lpr) {
 // 0 .. nz-1 itself and the logit is q.k / sqrt(D) with no importance transform (full_attention,
 // sparse_attention.cc:988-1037; the static window of models/attnserver.py:293-296) -- `ids`, `kn_g`,
 // `qn_h`, K and L are not used.
-template <int D, int NW, bool DENSE, typename IDS>   // NW: upper bound of the workgroup's waves (blockDim.x / 64 <= NW)
+// SLICE = tokens per wave step: 32 (AH_SLICE; 64 VGPRs of rows in flight) or, for lists short enough that one
+// round of 16-token steps covers them (a decode member's ~190 ids at cfg 1), 16: twice the waves take part and
+// every wave issues, waits for and reduces half as many rows -- the step is latency, not throughput.
+// IDS: callable (int j) -> u32x4 holding entries j .. j+3 of the workgroup's list (j a multiple of 4; entries
+// past nz are never used, but the call must not fault).
+// A load instruction fetches RPL = 64/LPR rows, UPS = SLICE/RPL load steps cover the slice; token slot of
+// (step u, row group r) is r*UPS + u, so the ids a row group needs are UPS consecutive entries.  The UPS
+// partial dot products are reduce-scattered over the LPR lanes of a row group for log2(UPS) steps and
+// all-reduced for the rest, so the DUP = LPR/UPS lanes c with equal c / DUP all hold the score of slot
+// r*UPS + c/DUP: the importance transform runs DUP times per token, sums count one lane per token.
+template <int D, int NW, bool DENSE, int SLICE, typename IDS>   // NW: upper bound of the workgroup's waves
 __device__ __forceinline__ void attn_head_fold(
     AhState& st,
     const uint16_t* __restrict__ kv_g,   // kv rows of this head's kv group: [M][2][D]
@@ -84,9 +145,10 @@ __device__ __forceinline__ void attn_head_fold(
     float* __restrict__ score_h,         // [M] transformed logits (nullable)
     unsigned long long* __restrict__ stamp) {
     constexpr int LPR = D / 8;           // lanes per row (16 B each)
-    constexpr int UPS = LPR / 2;         // load steps per slice
-    constexpr int VPL = (LPR == 16) ? 2 : 1;
-    static_assert((64 / LPR) * UPS == AH_SLICE, "a step covers 32 tokens");
+    constexpr int RPL = 64 / LPR;        // rows per load instruction
+    constexpr int UPS = SLICE / RPL;     // load steps per slice
+    constexpr int DUP = LPR / UPS;       // lanes that end up with the same token's score
+    static_assert(UPS >= 4 && UPS % 4 == 0 && DUP >= 2, "ids are fetched four at a time");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int r = lane / LPR, c = lane % LPR;
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
@@ -94,14 +156,14 @@ __device__ __forceinline__ void attn_head_fold(
 
     for (int k = wave;; k += nw) {
         const int64_t s = (int64_t)slice0 + (int64_t)slice_stride * k;
-        if (s * AH_SLICE >= nz) break;
-        const int jb = (int)s * AH_SLICE;
+        if (s * SLICE >= nz) break;
+        const int jb = (int)s * SLICE;
         u32x4 idv[UPS / 4];
         if (!DENSE) {
 #pragma unroll
-            for (int v = 0; v < UPS / 4; ++v) idv[v] = ids(k, r * UPS + v * 4);
+            for (int v = 0; v < UPS / 4; ++v) idv[v] = ids(jb + r * UPS + v * 4);
         }
-        const int slot_my = r * UPS + (c >> 1);
+        const int slot_my = r * UPS + c / DUP;
         const int j_my = jb + slot_my;
         const bool valid_my = j_my < nz;
 
@@ -113,22 +175,41 @@ __device__ __forceinline__ void attn_head_fold(
         const uint32_t M32 = (uint32_t)M;                               // max_length <= 2^22
         const int id_safe = ((uint32_t)id_first < M32) ? id_first : 0;
         u32x4 kreg[UPS], vreg[UPS];
+        int idc[UPS];
         int id_my = 0;
 #pragma unroll
         for (int u = 0; u < UPS; ++u) {
             int id_u = DENSE ? (jb + r * UPS + u) : (int)idv[u / 4][u % 4];
             const bool valid_u = (jb + r * UPS + u) < nz;
             if (!valid_u || (uint32_t)id_u >= M32) id_u = id_safe;
-            if (u == (c >> 1)) id_my = id_u;
-            const uint16_t* row = kvc + (int64_t)id_u * 2 * D;
-            kreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row));
-            vreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row + D));
+            if (u == c / DUP) id_my = id_u;
+            idc[u] = id_u;
         }
+        // Loads return in issue order.  Short lists (latency regime): the key norm first (the transform needs it
+        // right after the K rows), then all K rows, then the V rows (needed last): 0.45 us per step at cfg 1.
+        // Full-size steps run with HBM saturated (B*H >= CUs): there the K and the V row of a token, which share
+        // a DRAM page, are requested back to back (splitting them cost 2 % at cfg 2).
         float kn_my = 1.f;
-        if (!DENSE) kn_my = kn_g[id_my];
+        if (SLICE < AH_SLICE) {
+            if (!DENSE) kn_my = kn_g[id_my];
+#pragma unroll
+            for (int u = 0; u < UPS; ++u)
+                kreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kvc + (int64_t)idc[u] * 2 * D));
+#pragma unroll
+            for (int u = 0; u < UPS; ++u)
+                vreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kvc + (int64_t)idc[u] * 2 * D + D));
+        } else {
+#pragma unroll
+            for (int u = 0; u < UPS; ++u) {
+                const uint16_t* row = kvc + (int64_t)idc[u] * 2 * D;
+                kreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row));
+                vreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row + D));
+            }
+            if (!DENSE) kn_my = kn_g[id_my];
+        }
         if (!DENSE && k == wave) MP_STAMP(stamp, 34);
 
-        // ---- q . K partials, reduce-scatter over the row group down to pairs, then all-reduce
+        // ---- q . K partials, reduce-scatter over the row group while more than one value is left, then all-reduce
         float part[UPS];
 #pragma unroll
         for (int u = 0; u < UPS; ++u) {
@@ -138,39 +219,39 @@ __device__ __forceinline__ void attn_head_fold(
             part[u] = a;
         }
 #pragma unroll
-        for (int stp = LPR / 2; stp >= 2; stp >>= 1) {
-            const bool upper = (c & stp) != 0;
+        for (int stp = LPR / 2, vals = UPS; stp >= 1; stp >>= 1) {
+            if (vals > 1) {
+                const int half = vals / 2;
+                const bool upper = (c & stp) != 0;
 #pragma unroll
-            for (int u = 0; u < stp / 2; ++u) {
-                const float send = upper ? part[u] : part[u + stp / 2];
-                const float keep = upper ? part[u + stp / 2] : part[u];
-                part[u] = keep + __shfl_xor(send, stp);
+                for (int u = 0; u < UPS / 2; ++u) {
+                    if (u < half) {
+                        const float send = upper ? part[u] : part[u + half];
+                        const float keep = upper ? part[u + half] : part[u];
+                        part[u] = keep + __shfl_xor(send, stp);
+                    }
+                }
+                vals = half;
+            } else {
+                part[0] += __shfl_xor(part[0], stp);
             }
         }
-        const float sc = part[0] + __shfl_xor(part[0], 1);   // = q . K[id_my] on lanes c and c^1
+        const float sc = part[0];                            // = q . K[id_my] on the DUP lanes of slot_my
         if (!DENSE && k == wave) MP_STAMP(stamp, 35);
 
-        // ---- importance-sampling transform (transform_kernel, sparse_attention.cc:164-184);
-        // cancellation-free weight and cos clamp as in attn_sparse_kernel
+        // ---- importance-sampling transform (transform_kernel, sparse_attention.cc:164-184): importance_logit
         float z = -INFINITY;
         if (valid_my) {
             if (DENSE) {
                 z = sc * inv_sqrt_d;
             } else {
-                float cs = sc / (qn_h * kn_my);
-                cs = fminf(1.f, fmaxf(-1.f, cs));
-                const float theta = acosf(cs);
-                const float proba = 1.f - theta * 0.31830988618379067f;
-                const float p = powi_u(proba, K);
-                const float lm1 = (float)(L - 1);
-                const float w = -expm1f(lm1 * log1pf(-p) + log1pf(lm1 * p));
-                z = sc * inv_sqrt_d - logf(w + 1e-4f);
+                z = importance_logit(sc, qn_h * kn_my, inv_sqrt_d, K, L);
             }
-            if (score_h != nullptr && (c & 1) == 0) score_h[j_my] = z;
+            if (score_h != nullptr && (c % DUP) == 0) score_h[j_my] = z;
         }
         const float m_w = wave_max(z);
         const float p_my = valid_my ? __expf(z - m_w) : 0.f;    // slice non-empty => m_w finite
-        const float l_w = wave_sum((c & 1) ? 0.f : p_my);
+        const float l_w = wave_sum((c % DUP) ? 0.f : p_my);
         if (!DENSE && k == wave) MP_STAMP(stamp, 36);
 
         // ---- P . V
@@ -179,7 +260,7 @@ __device__ __forceinline__ void attn_head_fold(
         for (int i = 0; i < 8; ++i) acc[i] = 0.f;
 #pragma unroll
         for (int u = 0; u < UPS; ++u) {
-            const float pu = __shfl(p_my, r * LPR + 2 * u);
+            const float pu = __shfl(p_my, r * LPR + DUP * u);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 acc[2 * i] = fmaf(pu, bf16_lo(vreg[u][i]), acc[2 * i]);
@@ -198,22 +279,24 @@ __device__ __forceinline__ void attn_head_fold(
         const float a = __expf(st.m - m_new), b = __expf(m_w - m_new);   // exp(-inf) = 0 on the first slice
         st.l = fmaf(a, st.l, b * l_w);
         st.o0 = fmaf(a, st.o0, b * acc[0]);
-        if (VPL == 2) st.o1 = fmaf(a, st.o1, b * acc[1]);
+        if (LPR == 16) st.o1 = fmaf(a, st.o1, b * acc[1]);
         st.m = m_new;
     }
 }
 
-// The waves' states meet in LDS (one barrier).  On return threads tid < D hold the workgroup's
-// merged state: m (max logit), Z (sum of exp(z - m)) and o = sum_j exp(z_j - m) V[j][tid];
-// m = -inf, Z = 0 when the workgroup had no slice.
+// The waves' states meet in LDS (one barrier).  On return the lanes of WAVE 0 hold the workgroup's merged
+// state -- m (max logit), Z (sum of exp(z - m)) and, per lane, VPL = D / 64 consecutive elements
+// o[lane * VPL ..] of sum_j exp(z_j - m) V[j] -- and the other waves are done (they have nothing left to do in
+// the kernels that use this: a hand-off by ONE wave needs no further workgroup barrier).  m = -inf, Z = 0 when
+// the workgroup had no slice.
 template <int D, int NW>
 __device__ __forceinline__ void attn_head_merge(const AhState& st, float* s_merge, float& m_out,
-                                                float& Z_out, float& o_out) {
-    constexpr int VPL = (D / 8 == 16) ? 2 : 1;
+                                                float& Z_out, float& o0_out, float& o1_out) {
+    constexpr int VPL = D / 64;          // 2 (D = 128) or 1 (D = 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     float* mine = s_merge + wave * (D + 2);
     mine[st.d0] = st.o0;
-    if (VPL == 2) mine[st.d0 + 1] = st.o1;
+    if (D / 8 == 16) mine[st.d0 + 1] = st.o1;
     if (lane == 0) {
         mine[D] = st.m;
         mine[D + 1] = st.l;
@@ -221,63 +304,79 @@ __device__ __forceinline__ void attn_head_merge(const AhState& st, float* s_merg
     __syncthreads();
     m_out = -INFINITY;
     Z_out = 0.f;
-    o_out = 0.f;
-    if (tid < D) {
+    o0_out = 0.f;
+    o1_out = 0.f;
+    if (wave == 0) {
         // all reads of a pass are issued back to back (a rolled loop over the waves serialises 2 x NW
         // dependent LDS round trips: 2.1 us measured)
-        float mw[NW], lw[NW], ow[NW];
+        float mw[NW], lw[NW], oa[NW], ob[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             const bool live = w < nw;
             mw[w] = live ? s_merge[w * (D + 2) + D] : -INFINITY;
             lw[w] = live ? s_merge[w * (D + 2) + D + 1] : 0.f;
-            ow[w] = live ? s_merge[w * (D + 2) + tid] : 0.f;
+            if (VPL == 2) {
+                const float2 t = live ? *reinterpret_cast<const float2*>(s_merge + w * (D + 2) + lane * 2)
+                                      : make_float2(0.f, 0.f);
+                oa[w] = t.x;
+                ob[w] = t.y;
+            } else {
+                oa[w] = live ? s_merge[w * (D + 2) + lane] : 0.f;
+                ob[w] = 0.f;
+            }
         }
         float m = -INFINITY;
 #pragma unroll
         for (int w = 0; w < NW; ++w) m = fmaxf(m, mw[w]);
-        float Z = 0.f, o = 0.f;
+        float Z = 0.f, o0 = 0.f, o1 = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             if (mw[w] != -INFINITY) {                    // a wave without a slice never wrote its o[]
                 const float e = __expf(mw[w] - m);
                 Z = fmaf(e, lw[w], Z);
-                o = fmaf(e, ow[w], o);
+                o0 = fmaf(e, oa[w], o0);
+                o1 = fmaf(e, ob[w], o1);
             }
         }
         m_out = m;
         Z_out = Z;
-        o_out = o;
+        o0_out = o0;
+        o1_out = o1;
     }
 }
 
 // fold the slices of ONE sparse list, then merge (attn_head_kernel)
-template <int D, int NW, typename IDS>
+template <int D, int NW, int SLICE, typename IDS>
 __device__ __forceinline__ void attn_head_tail(
     const uint16_t* __restrict__ kv_g, const float* __restrict__ kn_g, const u32x4 qv, float qn_h, int nz,
     int64_t M, int K, int L, int slice0, int slice_stride, IDS&& ids, float* s_merge,
     float* __restrict__ score_h, unsigned long long* __restrict__ stamp, float& m_out, float& Z_out,
-    float& o_out) {
+    float& o0_out, float& o1_out) {
     AhState st = ah_state_init(threadIdx.x & 63, D / 8);
-    attn_head_fold<D, NW, false>(st, kv_g, kn_g, qv, qn_h, nz, M, K, L, slice0, slice_stride, ids, score_h, stamp);
-    attn_head_merge<D, NW>(st, s_merge, m_out, Z_out, o_out);
+    attn_head_fold<D, NW, false, SLICE>(st, kv_g, kn_g, qv, qn_h, nz, M, K, L, slice0, slice_stride, ids, score_h, stamp);
+    attn_head_merge<D, NW>(st, s_merge, m_out, Z_out, o0_out, o1_out);
 }
 
-// threads tid < D: out = o / Z as bf16 (RNE); max_value_expsum[0] = m*log2e, [1] = log2 Z + m*log2e
-// (softmax_kernel, sparse_attention.cc:238-239)
+// wave 0 (the layout attn_head_merge leaves): out = o / Z as bf16 (RNE); max_value_expsum[0] = m*log2e,
+// [1] = log2 Z + m*log2e (softmax_kernel, sparse_attention.cc:238-239); Z = 0 (no token at all): out = 0,
+// LSE = -inf (SURVEY a-10)
 template <int D>
-__device__ __forceinline__ void attn_head_finalize(float m, float Z, float o, uint16_t* __restrict__ out_h,
+__device__ __forceinline__ void attn_head_finalize(float m, float Z, float o0, float o1, uint16_t* __restrict__ out_h,
                                                    float* __restrict__ mve, int BH, int h,
                                                    float2* __restrict__ head_mz) {
-    const int tid = threadIdx.x;
-    if (tid < D) {
-        out_h[tid] = f32_to_bf16_rne(o / Z);
-        if (tid == 0) {
-            const float mv = m * 1.4426950408889634f;
-            mve[h] = mv;
-            mve[BH + h] = log2f(Z) + mv;
-            head_mz[h] = make_float2(m, Z);
-        }
+    const int lane = threadIdx.x & 63;
+    const bool none = !(Z > 0.f);
+    if (D == 128) {
+        const uint32_t pk = none ? 0u : ((uint32_t)f32_to_bf16_rne(o0 / Z) | ((uint32_t)f32_to_bf16_rne(o1 / Z) << 16));
+        reinterpret_cast<uint32_t*>(out_h)[lane] = pk;
+    } else {
+        out_h[lane] = none ? (uint16_t)0 : f32_to_bf16_rne(o0 / Z);
+    }
+    if (lane == 0) {
+        const float mv = none ? -INFINITY : m * 1.4426950408889634f;
+        mve[h] = mv;
+        mve[BH + h] = none ? -INFINITY : log2f(Z) + mv;
+        head_mz[h] = make_float2(none ? -INFINITY : m, none ? 0.f : Z);
     }
 }
 

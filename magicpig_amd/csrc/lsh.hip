@@ -680,44 +680,44 @@ __device__ __forceinline__ void lsh_head_body(
     __syncthreads();                        // s_ids complete; the spilled list drained (vmcnt) and visible in L2
     MP_STAMP(stamp, 33);
     // two instantiations of the sparse fold: the LDS path carries no global load ahead of its gathers
-    float m, Z, o;
+    float m, Z, o0, o1;
     const u32x4 qv = *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADD / 8)) * 4);
     float* score_h = aa.score ? aa.score + h * M + t0 : nullptr;
     const uint16_t* kv_g = aa.kv + g * M * 2 * ADD;
     const float* kn_g = aa.kn + g * M;
-    auto ids_lds = [&](int k, int j) { return *reinterpret_cast<const u32x4*>(s_ids + k * AH_SLICE + j); };
-    auto ids_hbm = [&](int k, int j) {
+    auto ids_lds = [&](int j) { return *reinterpret_cast<const u32x4*>(s_ids + j); };
+    auto ids_hbm = [&](int j) {
         u32x4 v = {0u, 0u, 0u, 0u};
-        const int64_t j0 = (int64_t)k * AH_SLICE + j;
         for (int e = 0; e < 4; ++e)
-            v[e] = (j0 + e < (int64_t)tlen) ? (uint32_t)__builtin_nontemporal_load(out + j0 + e) : 0u;
+            v[e] = ((uint32_t)(j + e) < tlen) ? (uint32_t)__builtin_nontemporal_load(out + j + e) : 0u;
         return v;
     };
-    if (!WIN) {                             // fold + merge as one straight path per id source
-        if (!spill)
-            attn_head_tail<ADD, RT_WAVES>(kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1, ids_lds,
-                                          s_merge, score_h, stamp, m, Z, o);
-        else
-            attn_head_tail<ADD, RT_WAVES>(kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1, ids_hbm,
-                                          s_merge, score_h, stamp, m, Z, o);
-    } else {
-        AhState st = ah_state_init(lane, ADD / 8);
-        if (!spill)
-            attn_head_fold<ADD, RT_WAVES, false>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
-                                                 ids_lds, score_h, stamp);
-        else
-            attn_head_fold<ADD, RT_WAVES, false>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
-                                                 ids_hbm, score_h, stamp);
-        if (wlen > 0) {                     // the static window: dense slices rank, rank + R, ... (k runs from
+    // lists that one round of 16-token steps covers (a member's ~190 ids at cfg 1) take those: twice the waves,
+    // half the rows per wave (head_dim 128; at 64 a 16-token step would be two load instructions)
+    constexpr int SHORT = (ADD == 128) ? 16 : AH_SLICE;
+    const bool short_list = SHORT < AH_SLICE && total <= SHORT * RT_WAVES && !spill;
+    AhState st = ah_state_init(lane, ADD / 8);
+    if (short_list)
+        attn_head_fold<ADD, RT_WAVES, false, SHORT>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1, ids_lds,
+                                                    score_h, stamp);
+    else if (!spill)
+        attn_head_fold<ADD, RT_WAVES, false, AH_SLICE>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
+                                                       ids_lds, score_h, stamp);
+    else
+        attn_head_fold<ADD, RT_WAVES, false, AH_SLICE>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
+                                                       ids_hbm, score_h, stamp);
+    if (WIN && wlen > 0) {                  // the static window: dense slices rank, rank + R, ... (k runs from
                                             // `wave` again, so the waves that got no sparse slice are served first)
-            auto none = [](int, int) { return u32x4{0u, 0u, 0u, 0u}; };
-            attn_head_fold<ADD, RT_WAVES, true>(st, aa.win_kv + g * aa.win_M * 2 * ADD, nullptr, qv, 1.f, wlen,
-                                                aa.win_M, 0, 0, rank, 1 << clog, none, nullptr, stamp);
-        }
-        attn_head_merge<ADD, RT_WAVES>(st, s_merge, m, Z, o);
+        auto none = [](int) { return u32x4{0u, 0u, 0u, 0u}; };
+        attn_head_fold<ADD, RT_WAVES, true, AH_SLICE>(st, aa.win_kv + g * aa.win_M * 2 * ADD, nullptr, qv, 1.f, wlen,
+                                                      aa.win_M, 0, 0, rank, 1 << clog, none, nullptr, stamp);
     }
+    attn_head_merge<ADD, RT_WAVES>(st, s_merge, m, Z, o0, o1);
+    // from here on WAVE 0 alone holds the workgroup's state: one wave needs no workgroup barrier to order its
+    // own stores, ticket and loads, and the other fifteen are done
+    if (wave != 0) return;
     if (clog == 0) {
-        attn_head_finalize<ADD>(m, Z, o, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
+        attn_head_finalize<ADD>(m, Z, o0, o1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
         MP_STAMP(stamp, 39);
         return;
     }
@@ -729,12 +729,14 @@ __device__ __forceinline__ void lsh_head_body(
     // memory side (sc1), which takes three ~0.6 us L2 round trips instead of three ~1.8 us ones.  The
     // host enables it only after xcd_round_robin_verified() has seen the placement on this device, and every
     // member checks its own XCC_ID against that observation (err bit 4 otherwise: mp_attn_check reports it).
+    constexpr int VPL = ADD / 64;
     const int nmem = 1 << clog;
     const int64_t pre = h * aa.maxs;
-    float mr[8], zr[8], orr[8];
+    float mr[8], zr[8], oa[8], ob[8];
     int cr[8];
+    int ticket = 0;
     if (aa.same_xcd) {
-        if (tid == 0) {
+        if (lane == 0) {
             const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
             if (xcc != ((aa.xcc_expect >> (4 * (blockIdx.x & 7))) & 15u)) atomicOr(aa.err, 4);
         }
@@ -744,99 +746,99 @@ __device__ __forceinline__ void lsh_head_body(
         const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<float*>(aa.part_ml + pre), 0, (int)(aa.maxs * 8), 0x00020000);
         const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(aa.part_cnt + h * 8, 0, 32, 0x00020000);
-        if (tid < ADD)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro, (rank * ADD + tid) * 4, 0, kSc0);
-        if (tid == 0) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), ro, (rank * ADD + lane * VPL) * 4, 0, kSc0);
+        if (VPL == 2)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1), ro, (rank * ADD + lane * 2 + 1) * 4, 0, kSc0);
+        if (lane == 0) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rm, rank * 8, 0, kSc0);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Z), rm, rank * 8 + 4, 0, kSc0);
             __builtin_amdgcn_raw_buffer_store_b32((uint32_t)total, rc, rank * 4, 0, kSc0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0)
-            *s_tk = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing lane of this wave drained
+        if (lane == 0)
+            ticket = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
         MP_STAMP(stamp, 38);
-        if (*s_tk != nmem - 1) return;
-        if (tid == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (tid < ADD) {
+        if (ticket != nmem - 1) return;
+        if (lane == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                mr[u] = -INFINITY;
-                zr[u] = 0.f;
-                orr[u] = 0.f;
-                cr[u] = 0;
-                if (u < nmem) {
-                    mr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, u * 8, 0, kSc0));
-                    zr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, u * 8 + 4, 0, kSc0));
-                    orr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (u * ADD + tid) * 4, 0, kSc0));
-                    cr[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rc, u * 4, 0, kSc0);
-                }
+        for (int u = 0; u < 8; ++u) {
+            mr[u] = -INFINITY;
+            zr[u] = 0.f;
+            oa[u] = 0.f;
+            ob[u] = 0.f;
+            cr[u] = 0;
+            if (u < nmem) {
+                mr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, u * 8, 0, kSc0));
+                zr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, u * 8 + 4, 0, kSc0));
+                oa[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (u * ADD + lane * VPL) * 4, 0, kSc0));
+                if (VPL == 2)
+                    ob[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (u * ADD + lane * 2 + 1) * 4, 0, kSc0));
+                cr[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rc, u * 4, 0, kSc0);
             }
         }
     } else {
-        if (tid < ADD)
-            __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + tid),
-                               __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) {
+        __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + lane * VPL),
+                           __float_as_uint(o0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (VPL == 2)
+            __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + lane * 2 + 1),
+                               __float_as_uint(o1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
             __hip_atomic_store(reinterpret_cast<unsigned long long*>(aa.part_ml + pre + rank),
                                (unsigned long long)__float_as_uint(m) | ((unsigned long long)__float_as_uint(Z) << 32),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(aa.part_cnt + h * 8 + rank, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0)
-            *s_tk = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
+        if (lane == 0)
+            ticket = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
         MP_STAMP(stamp, 38);
-        if (*s_tk != nmem - 1) return;
-        if (tid == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < ADD) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                mr[u] = -INFINITY;
-                zr[u] = 0.f;
-                orr[u] = 0.f;
-                cr[u] = 0;
-                if (u < nmem) {
-                    const unsigned long long pk = __hip_atomic_load(
-                        reinterpret_cast<unsigned long long*>(aa.part_ml + pre + u), __ATOMIC_RELAXED,
-                        __HIP_MEMORY_SCOPE_AGENT);
-                    mr[u] = __uint_as_float((uint32_t)pk);
-                    zr[u] = __uint_as_float((uint32_t)(pk >> 32));
-                    orr[u] = __uint_as_float(__hip_atomic_load(
-                        reinterpret_cast<unsigned int*>(aa.part_o + (pre + u) * ADD + tid), __ATOMIC_RELAXED,
-                        __HIP_MEMORY_SCOPE_AGENT));
-                    cr[u] = __hip_atomic_load(aa.part_cnt + h * 8 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-    }
-    if (tid < ADD) {
-        float mm = -INFINITY;
-        int csum = 0;
+        if (ticket != nmem - 1) return;
+        if (lane == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            mm = fmaxf(mm, mr[u]);
-            csum += cr[u];
-        }
-        if (tid == 0) nnz[h] = csum;
-        if (mm == -INFINITY) {                              // no member had a token (nor a window row)
-            attn_head_empty<ADD>(out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
-        } else {
-            float ZZ = 0.f, oo = 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (u < nmem && mr[u] != -INFINITY) {
-                    const float e = __expf(mr[u] - mm);
-                    ZZ = fmaf(e, zr[u], ZZ);
-                    oo = fmaf(e, orr[u], oo);
-                }
+            mr[u] = -INFINITY;
+            zr[u] = 0.f;
+            oa[u] = 0.f;
+            ob[u] = 0.f;
+            cr[u] = 0;
+            if (u < nmem) {
+                const unsigned long long pk = __hip_atomic_load(
+                    reinterpret_cast<unsigned long long*>(aa.part_ml + pre + u), __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT);
+                mr[u] = __uint_as_float((uint32_t)pk);
+                zr[u] = __uint_as_float((uint32_t)(pk >> 32));
+                oa[u] = __uint_as_float(__hip_atomic_load(
+                    reinterpret_cast<unsigned int*>(aa.part_o + (pre + u) * ADD + lane * VPL), __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT));
+                if (VPL == 2)
+                    ob[u] = __uint_as_float(__hip_atomic_load(
+                        reinterpret_cast<unsigned int*>(aa.part_o + (pre + u) * ADD + lane * 2 + 1), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT));
+                cr[u] = __hip_atomic_load(aa.part_cnt + h * 8 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            attn_head_finalize<ADD>(mm, ZZ, oo, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
         }
     }
+    float mm = -INFINITY;
+    int csum = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        mm = fmaxf(mm, mr[u]);
+        csum += cr[u];
+    }
+    if (lane == 0) nnz[h] = csum;
+    float ZZ = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (u < nmem && mr[u] != -INFINITY) {
+            const float e = __expf(mr[u] - mm);
+            ZZ = fmaf(e, zr[u], ZZ);
+            q0 = fmaf(e, oa[u], q0);
+            q1 = fmaf(e, ob[u], q1);
+        }
+    }
+    attn_head_finalize<ADD>(mm, ZZ, q0, q1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);   // ZZ = 0: no member had a token
     MP_STAMP(stamp, 39);
 }
 

@@ -4,8 +4,10 @@ import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import magicpig_amd as mp
 import magicpig_amd._lib as L
+if os.environ.get("MP_LIB"):            # A/B builds of the library (this script only; the product reads no environment)
+    L.LIB_PATH = os.path.abspath(os.environ["MP_LIB"])
+import magicpig_amd as mp
 from bench import CONFIGS
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg1"
@@ -47,6 +49,6 @@ seg("  fused hash prologue [start|normalised|pass0|pass1|barrier|probe+zero]", [
 seg("partial  [start|prefix|gathers issued|qk+reduce|transform|pv|combine]", [32, 33, 34, 35, 36, 37, 38])
 print("kernel-to-kernel (WG0 start to WG0 start): simhash->retrieve %.2f, retrieve->partial %.2f us" % (
     np.median(a[:, 16] - a[:, 0]), np.median(a[:, 32] - a[:, 16])))
-print("nnz mean", float(server.nnz.float().mean()))
+print("lib", L.LIB_PATH)
 seg("fused decode kernel [start|hash+probe|table streamed|scan|emit|ids staged|K gathers issued|qk|transform|pv|ticket|end]",
     [16, 17, 19, 20, 21, 33, 34, 35, 36, 37, 38, 39])

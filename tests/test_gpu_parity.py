@@ -989,7 +989,11 @@ def test_token_range_sub_bounds_and_unstable_fill(mp, H, Hkv, B):
     order = torch.argsort(codes.long() * (1 << 31) + rnd, dim=-1)
     b.fill(0, B - 1, torch.gather(codes, -1, order).contiguous(), order.int().contiguous())
     (ba, ta), (bb, tb) = a.get_tables(0), b.get_tables(0)
-    assert torch.equal(ba, bb) and torch.equal(ta[..., :n], tb[..., :n])
+    assert torch.equal(ba, bb)
+    if R > 1:
+        assert torch.equal(ta[..., :n], tb[..., :n])        # re-sorted on device: ascending ids, like the build
+    else:                                                   # one workgroup per head needs no order: kept as given
+        assert torch.equal(tb[(B - 1) * Hkv:, :, :n].cpu(), order.int().cpu())
     ba, ta = ba.cpu().numpy()[(B - 1) * Hkv:], ta.cpu().numpy()[(B - 1) * Hkv:]
     assert ba.shape == (Hkv, L, NB, R + 1)
     assert int((ba[..., -1] - ba[..., 0]).sum()) == Hkv * L * n
