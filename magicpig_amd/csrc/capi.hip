@@ -26,8 +26,10 @@ bool lsh_decode_supported(int64_t M, int L, int D, int R);
 bool xcd_round_robin_verified();
 hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, const uint16_t*, const float*, int,
                              int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
-                             float*, float2*, int*, int*, uint16_t*, float*, float2*, float*, int*, int, int, bool,
-                             const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t, hipStream_t);
+                             float*, float2*, int*, int*, uint16_t*, float*, float2*, const int32_t*, float*, int*,
+                             int, int, bool, const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t,
+                             hipStream_t);
+hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
                            int32_t*, int*, hipStream_t);
 hipError_t launch_lsh_unsort(const int16_t*, const int32_t*, int, int64_t, int16_t*, hipStream_t);
@@ -70,6 +72,7 @@ struct DebugOptions {
     std::atomic<int> decode_two_launch{0};   // 1: hash+retrieve launch, then attention launch
     std::atomic<int> decode_cluster{0};      // 0 = auto, else workgroups per head (clamped to [1, min(8, slices)])
     std::atomic<int> decode_agent_scope{0};  // 1: cluster hand-off through memory even when the XCD placement was observed
+    std::atomic<int> decode_direct{-1};      // -1 = auto, 0 = never, 1 = always (when R > 1) keep direct piece slots
     std::atomic<int> attn_head_kernel{-1};   // -1 = auto, 0 = split-KV kernel, 1 = one workgroup per head
     std::atomic<int> attn_gx{0};             // 0 = auto, else split-KV workgroups per head
 };
@@ -80,6 +83,7 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "decode_two_launch")) return &g_opt.decode_two_launch;
     if (!strcmp(name, "decode_cluster")) return &g_opt.decode_cluster;
     if (!strcmp(name, "decode_agent_scope")) return &g_opt.decode_agent_scope;
+    if (!strcmp(name, "decode_direct")) return &g_opt.decode_direct;
     if (!strcmp(name, "attn_head_kernel")) return &g_opt.attn_head_kernel;
     if (!strcmp(name, "attn_gx")) return &g_opt.attn_gx;
     return nullptr;
@@ -161,6 +165,7 @@ struct mp_lsh {
     int range_len = 0;             // tokens per range (multiple of 32)
     std::vector<int32_t*> bounds;  // per layer [B*Hkv][L][NB][R+1]
     std::vector<int32_t*> table;   // per layer [B*Hkv][L][M]
+    std::vector<int32_t*> slots;   // per layer [B*Hkv][L][NB][R][32] direct piece slots, or empty (R = 1 / long pieces)
     int* part_cnt = nullptr;       // [BH][8] per-member selected counts of the last decode launch
     int32_t* last_query = nullptr; // [BH][L] staging copy of host-side query codes
     const int32_t* lastq = nullptr;// device codes of the last retrieve (for get_mask): last_query,
@@ -319,8 +324,10 @@ int mp_lsh_create(mp_lsh_t** out) {
 static void lsh_free(mp_lsh_t* h) {
     for (auto p : h->bounds) if (p) (void)hipFree(p);
     for (auto p : h->table) if (p) (void)hipFree(p);
+    for (auto p : h->slots) if (p) (void)hipFree(p);
     h->bounds.clear();
     h->table.clear();
+    h->slots.clear();
     void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->part_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->last_query = nullptr; h->err = nullptr; h->codes = nullptr; h->results = nullptr;
@@ -359,13 +366,21 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
     const size_t groups = (size_t)h->B * h->Hkv, BH = (size_t)h->B * h->H;
     h->R = decode_cluster_size((int)BH, h->M);
     h->range_len = lsh_range_len(h->M, h->R);
+    // direct piece slots (lsh.hip: lsh_slots_kernel): one 128-byte record per (table, bucket, token range)
+    // holding the piece's length and first 31 ids.  Worth their memory (groups x L x 2^K x R x 128 B per layer:
+    // 1.26 GB at cfg 1) where a head is split over several workgroups AND a piece rarely overflows a slot:
+    // mean piece length max_length / (2^K R) <= 12.5 ids (P[Poisson(12.5) > 31] = 2e-6).
+    bool direct = h->R > 1 && (double)h->M <= 12.5 * (double)h->NB * h->R;
+    if (const int o = g_opt.decode_direct.load(); o >= 0) direct = h->R > 1 && o != 0;     // A/B switch, read at alloc
     int rc = MP_OK;
     for (int i = 0; i < num_layers && rc == MP_OK; ++i) {
-        void* b = nullptr; void* t = nullptr;
+        void* b = nullptr; void* t = nullptr; void* sl = nullptr;
         rc = alloc_zero(&b, groups * L * h->NB * (size_t)(h->R + 1) * 4);
         if (rc == MP_OK) rc = alloc_zero(&t, groups * L * (size_t)h->M * 4);
+        if (rc == MP_OK && direct) rc = alloc_zero(&sl, groups * L * h->NB * (size_t)h->R * 128);
         h->bounds.push_back((int32_t*)b);
         h->table.push_back((int32_t*)t);
+        if (direct) h->slots.push_back((int32_t*)sl);
     }
     if (rc == MP_OK) rc = alloc_zero((void**)&h->part_cnt, BH * 8 * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->last_query, BH * L * 4);
@@ -452,6 +467,9 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
         if (rc) return rc;
     }
     MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, st));
+    if (!h->slots.empty())
+        MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * 32, rows,
+                                      h->NB, h->R, h->M, st));
     if (mem == MP_MEM_HOST) MP_HIP_CHECK(hipStreamSynchronize(st));
     return MP_OK;
 }
@@ -472,6 +490,9 @@ int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes
     int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
     MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, h->R, b, t, h->err, st));
     MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, st));
+    if (!h->slots.empty())
+        MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * 32, rows,
+                                      h->NB, h->R, h->M, st));
     return lsh_read_err(h, st, "mp_lsh_build");
 }
 
@@ -515,6 +536,8 @@ int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream) {
     for (int i = 0; i < h->layers; ++i) {
         MP_HIP_CHECK(hipMemsetAsync(h->bounds[i], 0, groups * h->L * h->NB * (size_t)(h->R + 1) * 4, st));
         MP_HIP_CHECK(hipMemsetAsync(h->table[i], 0, groups * h->L * (size_t)h->M * 4, st));
+        if (!h->slots.empty())
+            MP_HIP_CHECK(hipMemsetAsync(h->slots[i], 0, groups * h->L * h->NB * (size_t)h->R * 128, st));
     }
     h->last_layer = -1;
     return MP_OK;
@@ -906,7 +929,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
                                        lsh->part_cnt, attn->head_cnt, output, max_value_expsum, attn->head_mz,
-                                       attn->score, attn->err, attn_slices_per_head(attn->M), lsh->R,
+                                       lsh->slots.empty() ? nullptr : lsh->slots[layer_id], attn->score, attn->err, attn_slices_per_head(attn->M), lsh->R,
                                        attn->xcd_rr && g_opt.decode_agent_scope.load() == 0,
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
                                        lsh->L, lsh->NB, lsh->M, st));

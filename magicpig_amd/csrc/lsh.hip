@@ -116,6 +116,28 @@ __global__ __launch_bounds__(256) void lsh_subbounds_kernel(
     }
 }
 
+// direct piece slots [rows][NB][R][32] (R > 1): word 0 = length of the piece (bucket, range) in the table row,
+// words 1 .. 31 = its first ids.  The decode kernel reads a piece with ONE 128-byte access straight from the
+// query's code, without the sub-bounds round trip in front of it.  Half a wave writes a slot.
+__global__ __launch_bounds__(256) void lsh_slots_kernel(const int32_t* __restrict__ table,
+                                                        const int32_t* __restrict__ bounds,
+                                                        int32_t* __restrict__ slots, int NB, int R, int64_t M) {
+    const int64_t row = blockIdx.y;
+    const int RS = R + 1;
+    const int32_t* t = table + row * M;
+    const int32_t* b = bounds + row * NB * RS;
+    int32_t* s = slots + row * NB * R * 32;
+    const int sl = threadIdx.x & 31;
+    for (int piece = blockIdx.x * 8 + (threadIdx.x >> 5); piece < NB * R; piece += gridDim.x * 8) {
+        const int bk = piece / R, r = piece - bk * R;
+        const int lo = b[bk * RS + r], hi = b[bk * RS + r + 1];
+        int v = 0;
+        if (sl == 0) v = hi - lo;
+        else if (sl - 1 < hi - lo) v = t[lo + sl - 1];
+        s[(int64_t)piece * 32 + sl] = v;
+    }
+}
+
 // ---------------------------------------------------------------- device-side table build
 // (replacement of the half-written LSH::fastfill, lsh.cc:93-142, and of the torch.sort +
 // LSH::fill of models/attnserver.py:186-193): stable counting sort of one (kv head, table) row
@@ -374,6 +396,7 @@ struct AttnArgs {
     uint16_t* out;           // [BH][D] bf16
     float* mve;              // [2][BH]
     float2* head_mz;         // [BH]
+    const int32_t* slots;    // [B*Hkv][L][NB][R][32] direct piece slots (R > 1, short pieces) or nullptr
     float* score;            // [BH][M] (nullable); member r's logits start at column r * range_len
     int* err;                // device flag: bit 4 = a cluster member ran on another XCD than observed
     int BH, maxs, cap, cluster_log2;   // cap: ids of the LDS stage (multiple of AH_SLICE)
@@ -430,7 +453,13 @@ __device__ __forceinline__ void lsh_head_body(
     const uint32_t tlen = (AD > 0) ? (uint32_t)(trem <= 0 ? 0 : (trem < range_len ? trem : range_len)) : (uint32_t)M;
 
     MP_STAMP(stamp, 16);
-    if (tid == 0) *s_ntail = 0;
+    if (tid == 0) {
+        *s_ntail = 0;
+        s_tmp[30] = 0;                                            // pieces that overflow their direct slot
+    }
+    // collision bitmaps and piece lengths start at zero: done here, under the query row's round trip
+    for (int i = tid; i < 2 * words; i += RT_THREADS) s_u32[i] = 0u;
+    for (int l = tid; l < Lpad; l += RT_THREADS) s_len[l] = 0;
     if (HASH) {
         const int D = ha.D, KL = ha.K * L;
         const int chunks = D >> 3;                              // 16-byte plane chunks per hyperplane
@@ -536,17 +565,87 @@ __device__ __forceinline__ void lsh_head_body(
     }
     __syncthreads();
     MP_STAMP(stamp, 27);
+    const uint32_t T0 = (uint32_t)t0;                                   // M <= 2^22 (mp_lsh_alloc)
+    auto apply = [&](int32_t t) {
+        const uint32_t u = (uint32_t)t - T0;                            // token index inside the range
+        if (u < tlen) {                                                 // one unsigned compare: t0 <= t < t0 + tlen
+            const uint32_t bit = 1u << (u & 31);
+            const uint32_t old = atomicOr(&bmA[u >> 5], bit);           // first hit: 0 -> 1
+            if (old & bit) atomicOr(&bmB[u >> 5], bit);                 // any later hit: -> 2
+        }
+    };
+    auto code_of = [&](int l) {   // HASH: bit i of code l <- plane l*K + i
+        const int bp = l * ha.K, w = bp >> 5, sh = bp & 31;
+        uint32_t v = s_bits[w] >> sh;
+        if (sh + ha.K > 32) v |= s_bits[w + 1] << (32 - sh);
+        return (int)(v & ((1u << ha.K) - 1u));
+    };
+    const int32_t* slots = (AD > 0) ? aa.slots : nullptr;
+    if (AD > 0 && HASH && slots != nullptr) {
+        // ---- DIRECT pieces: the piece (table l, bucket code, range rank) has a 128-byte slot holding its length
+        // and its first 31 ids, so ONE dependent round trip (hash -> slot) replaces two (hash -> sub-bounds ->
+        // ids).  Half a wave reads a slot; a wave keeps DG loads = 2 DG pieces in flight.  Pieces longer than 31
+        // ids (rare by construction: the slots exist only where the mean piece is <= 12.5 ids) finish through
+        // the sub-bounds and the chunk pool below.
+        constexpr int DG = 6;
+        const int half = lane >> 5, sl = lane & 31;
+        const int32_t* sg = slots + ((int64_t)g * L * NB * R + rank) * 32;
+        for (int l0 = 0; l0 < L; l0 += RT_WAVES * 2 * DG) {
+            int32_t v[DG];
+            int cd[DG];
+#pragma unroll
+            for (int b = 0; b < DG; ++b) {
+                const int l = l0 + (b * RT_WAVES + wave) * 2 + half;
+                const int lc = l < L ? l : L - 1;                       // loads stay unconditional
+                cd[b] = code_of(lc);
+                v[b] = sg[((int64_t)lc * NB + cd[b]) * R * 32 + sl];
+                if (lead && sl == 0 && l < L) ha.codes_out[h * L + l] = cd[b];
+            }
+#pragma unroll
+            for (int b = 0; b < DG; ++b) {
+                const int l = l0 + (b * RT_WAVES + wave) * 2 + half;
+                const int c0 = __builtin_amdgcn_readlane(v[b], 0), c1 = __builtin_amdgcn_readlane(v[b], 32);
+                const int pl = half ? c1 : c0;                          // length of the piece
+                if (l < L) {
+                    if (sl >= 1 && sl <= pl) apply(v[b]);
+                    if (sl == 0 && pl > 31) {                           // the rest goes through the sub-bounds
+                        s_start[l] = cd[b];
+                        s_len[l] = pl - 31;
+                        atomicAdd(&s_tmp[30], 1);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        MP_STAMP(stamp, 17);
+        if (s_tmp[30] > 0) {                                            // uniform
+            for (int l = tid; l < L; l += RT_THREADS) {
+                int len = s_len[l];
+                if (len > 0) {
+                    const int32_t* rec = bnd + ((int64_t)l * NB + s_start[l]) * RS;
+                    const int lo = rec[e_lo], hi = rec[e_hi];
+                    if (lo < 0 || hi - lo - 31 < len) len = hi - lo - 31;    // never past the piece
+                    if (len < 0 || (int64_t)hi > M) len = 0;
+                    s_start[l] = lo + 31;
+                    s_len[l] = len;
+                    const int nch = (len + 63) >> 6;
+                    const int base = atomicAdd(s_ntail, nch);
+                    for (int c = 0; c < nch && base + c < RT_TAIL_CAP; ++c)
+                        s_tail[base + c] = ((uint32_t)l << 16) | (uint32_t)c;
+                }
+            }
+            __syncthreads();
+        }
+        MP_STAMP(stamp, 18);
+    } else {
     // probe: the two sub-bounds of this workgroup's token range, adjacent 4-byte words of the bucket's record
     // (issued first: longest latency)
     for (int l = tid; l < Lpad; l += RT_THREADS) {
         int st = 0, len = 0;
         if (l < L) {
             int code;
-            if (HASH) {   // bit i of code l <- plane l*K + i
-                const int bp = l * ha.K, w = bp >> 5, sh = bp & 31;
-                uint32_t v = s_bits[w] >> sh;
-                if (sh + ha.K > 32) v |= s_bits[w + 1] << (32 - sh);
-                code = (int)(v & ((1u << ha.K) - 1u));
+            if (HASH) {
+                code = code_of(l);
                 if (lead) ha.codes_out[h * L + l] = code;
             } else {
                 code = query[h * L + l];
@@ -568,22 +667,12 @@ __device__ __forceinline__ void lsh_head_body(
                 s_tail[base + c] = ((uint32_t)l << 16) | (uint32_t)(c + 2);
         }
     }
-    for (int i = tid; i < 2 * words; i += RT_THREADS) s_u32[i] = 0u;
     __syncthreads();
     MP_STAMP(stamp, 17);
     MP_STAMP(stamp, 18);
 
     // stream the probed pieces: wave w owns tables w, w+16, ...; per round it keeps RT_GROUP
     // pieces x 2 chunks of 64 ids (<= 128 ids per piece) in flight, then applies them
-    const uint32_t T0 = (uint32_t)t0;                                   // M <= 2^22 (mp_lsh_alloc)
-    auto apply = [&](int32_t t) {
-        const uint32_t u = (uint32_t)t - T0;                            // token index inside the range
-        if (u < tlen) {                                                 // one unsigned compare: t0 <= t < t0 + tlen
-            const uint32_t bit = 1u << (u & 31);
-            const uint32_t old = atomicOr(&bmA[u >> 5], bit);           // first hit: 0 -> 1
-            if (old & bit) atomicOr(&bmB[u >> 5], bit);                 // any later hit: -> 2
-        }
-    };
     for (int l0 = wave; l0 < L; l0 += RT_WAVES * RT_GROUP) {
         int32_t id0[RT_GROUP], id1[RT_GROUP];
 #pragma unroll
@@ -603,6 +692,7 @@ __device__ __forceinline__ void lsh_head_body(
             apply(id0[b]);
             apply(id1[b]);
         }
+    }
     }
     // ids beyond the first 128 of a piece (skewed data): pooled 64-id chunks, waves take them
     // round-robin with RT_TAIL_UNROLL loads in flight
@@ -624,11 +714,12 @@ __device__ __forceinline__ void lsh_head_body(
             for (int u = 0; u < RT_TAIL_UNROLL; ++u) apply(idt[u]);
         }
     } else {   // pool overflow (> 128 K extra ids per head): plain strided sweep of every long piece
+        const int first = (AD > 0 && slots != nullptr) ? 0 : 128;      // direct mode: s_start is already past the slot's ids
         for (int l = 0; l < L; ++l) {
             const int len = s_len[l];
-            if (len <= 128) continue;
+            if (len <= first) continue;
             const int32_t* row = tab + (int64_t)l * M + s_start[l];
-            for (int j = 128 + tid; j < len; j += RT_THREADS) apply(row[j]);
+            for (int j = first + tid; j < len; j += RT_THREADS) apply(row[j]);
         }
     }
     __syncthreads();
@@ -954,6 +1045,15 @@ hipError_t launch_lsh_subbounds(const int32_t* table, int32_t* bounds, int rows,
     return hipGetLastError();
 }
 
+hipError_t launch_lsh_slots(const int32_t* table, const int32_t* bounds, int32_t* slots, int rows, int NB, int R,
+                            int64_t M, hipStream_t st) {
+    if (R <= 1 || slots == nullptr) return hipSuccess;
+    int gx = (NB * R + 7) / 8;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(lsh_slots_kernel, dim3(gx, rows), dim3(256), 0, st, table, bounds, slots, NB, R, M);
+    return hipGetLastError();
+}
+
 hipError_t launch_lsh_fill(const int16_t* codes, const int32_t* ids, int rows, int64_t n, int NB,
                            int64_t M, int R, int32_t* bounds, int32_t* table, int* err, hipStream_t st) {
     hipLaunchKernelGGL(lsh_fill_kernel, dim3(rows), dim3(256), 0, st, codes, ids, n, NB, M, R + 1, bounds,
@@ -1146,8 +1246,8 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                              const uint16_t* Wk, const float* wnorm, int D, int K, int KLpad,
                              int32_t* codes_out, float* qnorm_out, int32_t* results, int32_t* nnz,
                              const uint16_t* kv, const float* kn, float* part_o, float2* part_ml, int* part_cnt,
-                             int* head_cnt, uint16_t* out, float* mve, float2* head_mz, float* score, int* err,
-                             int maxs, int R, bool same_xcd, const uint16_t* win_kv,
+                             int* head_cnt, uint16_t* out, float* mve, float2* head_mz, const int32_t* slots,
+                             float* score, int* err, int maxs, int R, bool same_xcd, const uint16_t* win_kv,
                              const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
                              hipStream_t st) {
     const int range_len = lsh_range_len(M, R);
@@ -1161,7 +1261,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     uint32_t xmap = 0;
     const bool sx = same_xcd && clog > 0 && BH % 8 == 0 && xcd_round_robin_map(&xmap);
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
-    AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, score, err, BH, maxs,
+    AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, slots, score, err, BH, maxs,
                    DECODE_ID_CAP, clog, sx ? 1 : 0, xmap, win_kv, win_len, win_M};
     const dim3 grid((unsigned)BH << clog);
     const size_t lds = decode_lds_bytes(range_len, L, D);

@@ -675,6 +675,49 @@ def test_fused_decode_unusual_shapes_equal_two_kernel_path(mp, B, H, Hkv, D, K, 
         assert np.allclose(lse.reshape(-1).cpu().numpy()[live], mve[1].cpu().numpy()[live], atol=2e-3)
 
 
+@pytest.mark.parametrize("direct", [1, 0])
+@pytest.mark.parametrize("K,L,n,M", [(4, 30, 6000, 6144),      # 16 buckets: every piece overflows its 31-id slot
+                                     (6, 75, 6000, 6144),      # mean piece 12 ids: a mix of both
+                                     (10, 150, 20000, 20480)]) # mean piece 2.5 ids: slots only
+def test_fused_decode_direct_slots_and_overflow(mp, K, L, n, M, direct):
+    """R = 8 workgroups per head with the direct piece slots forced on (also where pieces are far longer than a
+    slot: the rest of such a piece comes through the sub-bounds + chunk pool) and forced off (sub-bounds only),
+    against hash -> batch_retrieve -> attention_wrapper on the same stores: same nnz, same ids, outputs equal up
+    to summation order."""
+    import magicpig_amd._lib as L_
+
+    B, H, Hkv, D = 1, 8, 2, 128
+    L_.set_option("decode_direct", direct)
+    try:
+        server, _ = _fused_server(mp, B, H, Hkv, n, M, D, K, L, 3000 + K)
+    finally:
+        L_.set_option("decode_direct", -1)
+    assert server.lsh_retriever.R == 8
+    BH = B * H
+    gen = torch.Generator(device="cuda").manual_seed(K * L + direct)
+    for it in range(3):
+        q = torch.randn((B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16)
+        out, lse = server.decode(q, 0)
+        nz1 = server.nnz.clone()
+        probs1 = server.attn_server.get_score().reshape(BH, M).clone()
+        codes, qn = server.hasher.query(q.reshape(BH, D))
+        res = torch.zeros((BH, M), dtype=torch.int32, device="cuda")
+        nz = torch.zeros((BH,), dtype=torch.int32, device="cuda")
+        server.lsh_retriever.batch_retrieve(0, codes, res, nz)
+        assert torch.equal(nz, nz1)
+        o_ref = torch.zeros((BH, D), dtype=torch.bfloat16, device="cuda")
+        mve = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
+        server.attn_server.attention_wrapper(0, K, L, o_ref, mve, q.reshape(BH, D), qn, res, nz)
+        probs2 = server.attn_server.get_score().reshape(BH, M)
+        live = (nz > 0).cpu().numpy()
+        a = out.reshape(BH, D).float().cpu().numpy()
+        assert np.allclose(a[live], o_ref.float().cpu().numpy()[live], rtol=2 ** -6, atol=2e-3)
+        assert np.allclose(lse.reshape(-1).cpu().numpy()[live], mve[1].cpu().numpy()[live], atol=2e-3)
+        for h in range(BH):      # get_score after the decode entry: per-member segments compacted into `ind` order
+            z = int(nz[h])
+            assert np.allclose(probs1[h, :z].cpu().numpy(), probs2[h, :z].cpu().numpy(), rtol=2e-3, atol=1e-7)
+
+
 def test_cfg1_shaped_fused_decode_properties(mp):
     """BASELINE cfg 1 shape (B=1, H=32, Hkv=8, n=97 932, M=98 304, K=10, L=150), one layer, through
     size-independent properties: (1) the one-launch entry equals hash -> batch_retrieve ->
