@@ -143,7 +143,8 @@ __device__ __forceinline__ void attn_head_fold(
     const u32x4 qv,                      // this lane's 8 query elements: bf16 q[(lane % LPR)*8 ..]
     float qn_h, int nz, int64_t M, int K, int L, int slice0, int slice_stride, IDS&& ids,
     float* __restrict__ score_h,         // [M] transformed logits (nullable)
-    unsigned long long* __restrict__ stamp) {
+    unsigned long long* __restrict__ stamp,
+    int j0 = 0) {                        // first entry of the list to fold (a multiple of 32): slices start there
     constexpr int LPR = D / 8;           // lanes per row (16 B each)
     constexpr int RPL = 64 / LPR;        // rows per load instruction
     constexpr int UPS = SLICE / RPL;     // load steps per slice
@@ -156,8 +157,8 @@ __device__ __forceinline__ void attn_head_fold(
 
     for (int k = wave;; k += nw) {
         const int64_t s = (int64_t)slice0 + (int64_t)slice_stride * k;
-        if (s * SLICE >= nz) break;
-        const int jb = (int)s * SLICE;
+        if (j0 + s * SLICE >= nz) break;
+        const int jb = j0 + (int)s * SLICE;
         u32x4 idv[UPS / 4];
         if (!DENSE) {
 #pragma unroll

@@ -29,6 +29,7 @@ hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, co
                              float*, float2*, int*, int*, uint16_t*, float*, float2*, const int32_t*, float*, int*,
                              int, int, bool, const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t,
                              hipStream_t);
+hipError_t set_stamp_stride(int);
 hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
                            int32_t*, int*, hipStream_t);
@@ -840,6 +841,10 @@ int mp_debug_set_stamp_buffer(void* dev_u64x64) {
 int mp_debug_xcd_round_robin(void) { return xcd_round_robin_verified() ? 1 : 0; }
 
 int mp_debug_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "stamp_stride")) {      // every workgroup of the decode kernel records (lsh.hip)
+        MP_HIP_CHECK(set_stamp_stride(value));
+        return MP_OK;
+    }
     std::atomic<int>* o = debug_option(name);
     MP_REQUIRE(o != nullptr, MP_ERR_INVALID, std::string("mp_debug_set_option: unknown option '") + (name ? name : "(null)") + "'");
     o->store(value);

@@ -70,11 +70,24 @@ __device__ __forceinline__ void dot_settle(float& acc) { asm("s_nop 3" : "+v"(ac
 // ---------------------------------------------------------------- debug phase timestamps
 // stamp == nullptr in production; set through mp_debug_set_stamp_buffer (scripts/phase_times.py).
 // One lane of workgroup 0 records the 100 MHz wall clock at phase boundaries.
+// A translation unit that defines MP_STAMP_STRIDE (an int lvalue in device memory) lets EVERY workgroup record:
+// workgroup b writes at [b * stride + slot] when the stride is > 0 (scripts/phase_spread.py).
+#ifdef MP_STAMP_STRIDE
+#define MP_STAMP(stamp, slot)                                                               \
+    do {                                                                                    \
+        if ((stamp) != nullptr && threadIdx.x == 0) {                                       \
+            const int _ss = MP_STAMP_STRIDE;                                                \
+            if (_ss > 0) (stamp)[(size_t)blockIdx.x * _ss + (slot)] = wall_clock64();       \
+            else if ((blockIdx.x | blockIdx.y | blockIdx.z) == 0) (stamp)[(slot)] = wall_clock64(); \
+        }                                                                                   \
+    } while (0)
+#else
 #define MP_STAMP(stamp, slot)                                                               \
     do {                                                                                    \
         if ((stamp) != nullptr && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) \
             (stamp)[(slot)] = wall_clock64();                                               \
     } while (0)
+#endif
 
 // ---------------------------------------------------------------- wave / block primitives
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }

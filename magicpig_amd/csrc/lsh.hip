@@ -27,12 +27,23 @@
 // library/lsh/test.py:43-56).
 #include <mutex>
 
+#include <hip/hip_runtime.h>
+
+namespace mp {
+__device__ int d_stamp_stride = 0;    // debug: > 0 = every workgroup records its phase stamps (set_stamp_stride)
+}
+#define MP_STAMP_STRIDE ::mp::d_stamp_stride
+
 #include "common.h"
 #include "attn_head.h"
 
 namespace mp {
 
 extern unsigned long long* g_stamp;   // simhash.hip
+
+hipError_t set_stamp_stride(int stride) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(d_stamp_stride), &stride, sizeof(int));
+}
 
 constexpr int RT_THREADS = 1024;           // 16 waves: one workgroup per query head
 constexpr int RT_WAVES = RT_THREADS / 64;
@@ -525,7 +536,7 @@ __device__ __forceinline__ void lsh_head_body(
         for (int c0 = 0; c0 < KL; c0 += RT_THREADS) {
             const int c = c0 + tid, cn = c + RT_THREADS;
             const int cnc = cn < ha.KLpad ? cn : ha.KLpad - 1;
-            bool bit = false;
+            bool bit = false, near = false;
             float acc = 0.f;
             if (c0 + RT_THREADS < KL) {                              // uniform: another pass follows
 #pragma unroll
@@ -542,18 +553,24 @@ __device__ __forceinline__ void lsh_head_body(
                     dot8_bf16_chain(acc, q4[kc], Wk4[c + (int64_t)kc * ha.KLpad]);
                 dot_settle(acc);
                 bit = acc > 0.f;
-                if (fabsf(acc) <= (1.0f / 65536.0f) * rn * ha.wnorm[c]) {   // 2^-16 guard band (simhash.hip SH_EPS)
-                    double ex = 0.0;
-                    for (int kc = 0; kc < chunks; ++kc) {
-                        const u32x4 wv = Wk4[c + (int64_t)kc * ha.KLpad];
-                        const u32x4 x = q4[kc];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            ex += (double)bf16_lo(x[j]) * (double)bf16_lo(wv[j]) +
-                                  (double)bf16_hi(x[j]) * (double)bf16_hi(wv[j]);
-                    }
-                    bit = ex > 0.0;
-                }
+                near = fabsf(acc) <= (1.0f / 65536.0f) * rn * ha.wnorm[c];   // 2^-16 guard band (simhash.hip SH_EPS)
+            }
+            // exact sign of the columns inside the guard band, one column at a time by the WHOLE wave: lane j
+            // takes elements j*per .. of the dot product (exact f64 products of bf16 pairs), a DPP wave sum adds
+            // them (exact and order-free).  One parallel round of loads: ~0.6 us.  The same loop run by the owning
+            // thread alone (16 dependent 16-byte loads) took ~2.5 us, and with eight members per head almost every
+            // cluster had such a member somewhere -- it was the tail of the whole launch.
+            for (unsigned long long fm = __ballot(near); fm; fm &= fm - 1) {   // wave-uniform
+                const int src = __ffsll((long long)fm) - 1;
+                const int cs = c0 + (wave << 6) + src;
+                const int d0 = lane * per;
+                const uint16_t* wp = ha.Wk + ((int64_t)(d0 >> 3) * ha.KLpad + cs) * 8 + (d0 & 7);
+                const uint16_t* qp = reinterpret_cast<const uint16_t*>(s_q) + d0;
+                double part = 0.0;
+                for (int i = 0; i < per; ++i)
+                    part += (double)bf16_bits_to_f32(qp[i]) * (double)bf16_bits_to_f32(wp[i]);
+                const double ex = wave_sum(part);
+                if (lane == src) bit = ex > 0.0;
             }
             const unsigned long long bm = __ballot(bit);
             if (lane == 0) {
@@ -784,7 +801,9 @@ __device__ __forceinline__ void lsh_head_body(
         return v;
     };
     // lists that one round of 16-token steps covers (a member's ~190 ids at cfg 1) take those: twice the waves,
-    // half the rows per wave (head_dim 128; at 64 a 16-token step would be two load instructions)
+    // half the rows per wave (head_dim 128; at 64 a 16-token step would be two load instructions).  Measured and
+    // rejected: 16-token steps for the last partial round of a long list (cfg 2: 641 ids = one round of 32-token
+    // steps + 129 ids) -- 37.2 us per layer against 35.6 with HBM saturated.
     constexpr int SHORT = (ADD == 128) ? 16 : AH_SLICE;
     const bool short_list = SHORT < AH_SLICE && total <= SHORT * RT_WAVES && !spill;
     AhState st = ah_state_init(lane, ADD / 8);

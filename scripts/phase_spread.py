@@ -1,0 +1,60 @@
+"""Phase stamps of EVERY workgroup of the decode kernel at a BASELINE config shape: per phase boundary the
+median / max over the workgroups of (stamp - earliest kernel start), i.e. where the critical path runs.
+usage: python scripts/phase_spread.py [cfg1|cfg2|cfg3|cfg4] [reps]"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import magicpig_amd._lib as L
+if os.environ.get("MP_LIB"):
+    L.LIB_PATH = os.path.abspath(os.environ["MP_LIB"])
+import magicpig_amd as mp
+from bench import CONFIGS
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg1"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+cfg = CONFIGS[name]
+B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
+dev = torch.device("cuda:0")
+NLAYER = 2
+server = mp.LSHSparseAttnServer(NLAYER, H, Hkv, D, K=K, L=Lt, batch_size=B, max_length=M, dense_layers=(), device="cuda:0")
+for li in range(NLAYER):
+    for b in range(B):
+        gen = torch.Generator(device=dev).manual_seed(100 * li + b)
+        kc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
+        vc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
+        server.fill(li, b, kc, vc, P); server.build_table(li, b, P)
+R = server.lsh_retriever.R
+grid = B * H * R
+STRIDE = 64
+stamp = torch.zeros(grid * STRIDE, dtype=torch.int64, device=dev)
+qs = torch.randn((reps, NLAYER, B, H, 1, D), device=dev).to(torch.bfloat16)
+server.collect_nnz = False
+for r in range(3):
+    for li in range(NLAYER): server.decode(qs[r % reps, li], li)
+torch.cuda.synchronize()
+L.set_option("stamp_stride", STRIDE)
+L.check(L.lib().mp_debug_set_stamp_buffer(L.ptr(stamp)))
+slots = [16, 22, 27, 17, 19, 20, 21, 33, 34, 35, 36, 37, 38, 39]
+names = ["start", "normalised", "hashed", "pieces in", "stream done", "scanned", "emitted", "ids staged", "gathers issued",
+         "qk", "transform", "pv", "ticket", "end (merger)"]
+acc = []
+for r in range(reps):
+    for li in range(NLAYER):
+        stamp.zero_()
+        server.decode(qs[r, li], li)
+        torch.cuda.synchronize()
+        a = stamp.cpu().numpy().reshape(grid, STRIDE)[:, slots].astype(np.float64) * 0.01
+        a[a == 0] = np.nan
+        acc.append(a - np.nanmin(a[:, 0]))
+L.check(L.lib().mp_debug_set_stamp_buffer(None))
+L.set_option("stamp_stride", 0)
+a = np.array(acc)                    # [runs, grid, phases]
+print(f"{name}: grid {grid} workgroups (R = {R}); us after the first workgroup's start, median over runs of the per-launch")
+print(f"{'phase':>16} {'min':>7} {'median':>7} {'p90':>7} {'max':>7}   rank-0 median / other ranks median")
+BH = B * H
+for i, nm in enumerate(names):
+    x = a[:, :, i]
+    st = [np.nanmedian(f(x, axis=1)) for f in (np.nanmin, np.nanmedian, lambda v, axis: np.nanpercentile(v, 90, axis=axis), np.nanmax)]
+    r0 = np.nanmedian(x[:, :BH]); ro = np.nanmedian(x[:, BH:]) if R > 1 else float("nan")
+    print(f"{nm:>16} {st[0]:7.2f} {st[1]:7.2f} {st[2]:7.2f} {st[3]:7.2f}   {r0:7.2f} / {ro:7.2f}")
