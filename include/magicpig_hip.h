@@ -181,7 +181,8 @@ int mp_debug_xcd_round_robin(void);
  *   "decode_direct"      -1 = auto, 0 = never, 1 = always (where R > 1): keep 128-byte direct slots (length + first
  *                        31 ids) for every (table, bucket, token range) piece; read by mp_lsh_alloc
  *   "attn_head_kernel"   -1 = auto, 0 = split-KV kernel with the in-launch ticket merge, 1 = one workgroup per head
- *   "attn_gx"            0 = auto, n = split-KV workgroups per head */
+ *   "attn_gx"            0 = auto, n = split-KV workgroups per head
+ *   "attn_dense_grouped" 1 = mp_attn_full reads K/V once per kv group (default), 0 = once per query head */
 int mp_debug_set_option(const char* name, int value);
 int mp_debug_get_option(const char* name, int* value);
 

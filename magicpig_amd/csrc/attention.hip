@@ -347,6 +347,238 @@ __global__ __launch_bounds__(1024) void attn_head_kernel(
     MP_STAMP(stamp, 39);
 }
 
+// ---------------------------------------------------------------- full_attention, K/V shared by the group
+// SparseAttentionServer::full_attention (sparse_attention.cc:988-1037) loops over kv heads and scores the G
+// query heads of a group against every loaded K row (qk_kernel_full :106-160, wv_kernel_dim128_full :386-451).
+// Same here: a workgroup owns a range of 32-row slices of ONE kv head and folds every row into the softmax
+// states of all G query heads, so K and V cross HBM once per group instead of once per query head (the
+// per-head DENSE instantiation of attn_sparse_kernel reads them G times: 4x the bytes at Llama's G = 4 --
+// it is what the two dense layers of the f-3 decode step were made of).
+// grid = groups * split workgroups of 4 waves, group fastest (XCD spread); slice s of the group's rows belongs
+// to workgroup x = s / 4 % split, wave s % 4.  Every workgroup publishes one partial per head (m, Z, o[D]; empty:
+// m = -inf) and takes that head's arrival ticket; the last of the `split` arrivals merges (agent scope, as
+// attn_sparse_kernel).
+template <int D, int G, bool QBF16>
+__global__ __launch_bounds__(256) void attn_dense_kernel(
+    const uint16_t* __restrict__ kv,     // [groups][M][2][D]
+    const void* __restrict__ query,      // [BH][D] bf16 or f32
+    const int32_t* __restrict__ nnz,     // [BH] rows [0, nnz[h]) take part for head h
+    float* __restrict__ part_o,          // [BH][maxs][D]
+    float2* __restrict__ part_ml,        // [BH][maxs]
+    int* __restrict__ head_cnt,          // [BH] arrival tickets, zero between launches
+    uint16_t* __restrict__ out, float* __restrict__ mve, float2* __restrict__ head_mz,
+    float* __restrict__ score,           // [BH][M] logits (nullable)
+    int BH, int groups, int64_t M, int maxs, int split) {
+    constexpr int NW = 4;
+    constexpr int LPR = D / 8, UPS = LPR / 2, VPL = D / 64;   // 32-row slices, as attn_head_fold<.., AH_SLICE>
+    constexpr int QW = QBF16 ? D / 2 : D;                      // 32-bit words of one query row in LDS
+    __shared__ __attribute__((aligned(16))) uint32_t s_q[G * QW];
+    __shared__ float s_merge[G * NW * (D + 2)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane / LPR, c = lane % LPR;
+    const int gidx = blockIdx.x % groups, x = blockIdx.x / groups;
+    const int h0 = gidx * G;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
+    // the group's queries -> LDS (every lane needs elements c*8 .. c*8+7 of all G rows)
+    for (int i = tid; i < G * QW; i += 256)
+        s_q[i] = reinterpret_cast<const uint32_t*>(query)[(int64_t)h0 * QW + i];
+    int nz[G], nzmax = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        int z = nnz[h0 + g];
+        z = z < 0 ? 0 : ((int64_t)z > M ? (int)M : z);
+        nz[g] = z;
+        nzmax = z > nzmax ? z : nzmax;
+    }
+    __syncthreads();
+    AhState st[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) st[g] = ah_state_init(lane, LPR);
+    const uint16_t* kvc = kv + (int64_t)gidx * M * 2 * D + c * 8;
+
+    for (int64_t s = (int64_t)x * NW + wave; s * AH_SLICE < nzmax; s += (int64_t)split * NW) {
+        const int jb = (int)s * AH_SLICE;
+        const int j_my = jb + r * UPS + (c >> 1);
+        u32x4 kreg[UPS], vreg[UPS];
+#pragma unroll
+        for (int u = 0; u < UPS; ++u) {
+            int row = jb + r * UPS + u;
+            row = row < nzmax ? row : jb;                    // loads stay unconditional
+            const uint16_t* p = kvc + (int64_t)row * 2 * D;
+            kreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+            vreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + D));
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (jb >= nz[g]) continue;                      // wave-uniform: this head's list ended before the slice
+            float part[UPS];
+            if (QBF16) {
+                const u32x4 qv = *reinterpret_cast<const u32x4*>(s_q + g * QW + c * 4);
+#pragma unroll
+                for (int u = 0; u < UPS; ++u) {
+                    float a = 0.f;
+                    dot8_bf16_chain(a, kreg[u], qv);
+                    dot_settle(a);
+                    part[u] = a;
+                }
+            } else {
+                const float* qf = reinterpret_cast<const float*>(s_q) + g * QW + c * 8;
+                const float4 qa = *reinterpret_cast<const float4*>(qf), qb = *reinterpret_cast<const float4*>(qf + 4);
+#pragma unroll
+                for (int u = 0; u < UPS; ++u) {
+                    float a = 0.f;
+                    a = fmaf(bf16_lo(kreg[u][0]), qa.x, a);
+                    a = fmaf(bf16_hi(kreg[u][0]), qa.y, a);
+                    a = fmaf(bf16_lo(kreg[u][1]), qa.z, a);
+                    a = fmaf(bf16_hi(kreg[u][1]), qa.w, a);
+                    a = fmaf(bf16_lo(kreg[u][2]), qb.x, a);
+                    a = fmaf(bf16_hi(kreg[u][2]), qb.y, a);
+                    a = fmaf(bf16_lo(kreg[u][3]), qb.z, a);
+                    a = fmaf(bf16_hi(kreg[u][3]), qb.w, a);
+                    part[u] = a;
+                }
+            }
+#pragma unroll
+            for (int stp = LPR / 2; stp >= 2; stp >>= 1) {
+                const bool upper = (c & stp) != 0;
+#pragma unroll
+                for (int u = 0; u < UPS / 2; ++u) {
+                    if (u < stp / 2) {
+                        const float send = upper ? part[u] : part[u + stp / 2];
+                        const float keep = upper ? part[u + stp / 2] : part[u];
+                        part[u] = keep + __shfl_xor(send, stp);
+                    }
+                }
+            }
+            const float sc = part[0] + __shfl_xor(part[0], 1);   // q_g . K[j_my] on lanes c and c^1
+            const bool valid = j_my < nz[g];
+            const float z = valid ? sc * inv_sqrt_d : -INFINITY;
+            if (valid && score != nullptr && (c & 1) == 0) score[(int64_t)(h0 + g) * M + j_my] = z;
+            const float m_w = wave_max(z);                       // finite: jb < nz[g]
+            const float p_my = valid ? __expf(z - m_w) : 0.f;
+            const float l_w = wave_sum((c & 1) ? 0.f : p_my);
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int u = 0; u < UPS; ++u) {
+                const float pu = __shfl(p_my, r * LPR + 2 * u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[2 * i] = fmaf(pu, bf16_lo(vreg[u][i]), acc[2 * i]);
+                    acc[2 * i + 1] = fmaf(pu, bf16_hi(vreg[u][i]), acc[2 * i + 1]);
+                }
+            }
+            int doff = 0;
+            rs_step_h<8, 32>(acc, lane, doff);
+            rs_step_h<4, 16>(acc, lane, doff);
+            if (LPR == 8) rs_step_h<2, 8>(acc, lane, doff);
+            st[g].d0 = c * 8 + doff;
+            const float m_new = fmaxf(st[g].m, m_w);
+            const float a = __expf(st[g].m - m_new), b = __expf(m_w - m_new);
+            st[g].l = fmaf(a, st[g].l, b * l_w);
+            st[g].o0 = fmaf(a, st[g].o0, b * acc[0]);
+            if (LPR == 16) st[g].o1 = fmaf(a, st[g].o1, b * acc[1]);
+            st[g].m = m_new;
+        }
+    }
+    // the four waves' states of every head meet in LDS; wave g % 4 takes head g, g + 4 from there
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float* mine = s_merge + (g * NW + wave) * (D + 2);
+        mine[st[g].d0] = st[g].o0;
+        if (LPR == 16) mine[st[g].d0 + 1] = st[g].o1;
+        if (lane == 0) {
+            mine[D] = st[g].m;
+            mine[D + 1] = st[g].l;
+        }
+    }
+    __syncthreads();
+    for (int g = wave; g < G; g += NW) {
+        const int h = h0 + g;
+        float mw[NW], lw[NW], oa[NW], ob[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float* sw = s_merge + (g * NW + w) * (D + 2);
+            mw[w] = sw[D];
+            lw[w] = sw[D + 1];
+            oa[w] = sw[lane * VPL];
+            ob[w] = VPL == 2 ? sw[lane * 2 + 1] : 0.f;
+        }
+        float m = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
+        float Z = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            if (mw[w] != -INFINITY) {                    // a wave without a slice never wrote its o[]
+                const float e = __expf(mw[w] - m);
+                Z = fmaf(e, lw[w], Z);
+                o0 = fmaf(e, oa[w], o0);
+                o1 = fmaf(e, ob[w], o1);
+            }
+        }
+        if (split == 1) {
+            attn_head_finalize<D>(m, Z, o0, o1, out + (int64_t)h * D, mve, BH, h, head_mz);
+            continue;
+        }
+        // publish this workgroup's partial of head h write-through, drain, ticket; the last arrival merges
+        const int64_t pidx = (int64_t)h * maxs + x;
+        __hip_atomic_store(reinterpret_cast<unsigned int*>(part_o + pidx * D + lane * VPL), __float_as_uint(o0),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (VPL == 2)
+            __hip_atomic_store(reinterpret_cast<unsigned int*>(part_o + pidx * D + lane * 2 + 1), __float_as_uint(o1),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(part_ml + pidx),
+                               (unsigned long long)__float_as_uint(m) | ((unsigned long long)__float_as_uint(Z) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != split - 1) continue;
+        if (lane == 0) __hip_atomic_store(head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t pre = (int64_t)h * maxs;
+        float mm = -INFINITY;
+        for (int t = lane; t < split; t += 64) {
+            const unsigned long long pk = __hip_atomic_load(reinterpret_cast<unsigned long long*>(part_ml + pre + t),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mm = fmaxf(mm, __uint_as_float((uint32_t)pk));
+        }
+        mm = wave_max(mm);
+        float ZZ = 0.f, q0 = 0.f, q1 = 0.f;
+        for (int t0 = 0; t0 < split; t0 += 8) {
+            unsigned long long ml[8];
+            uint32_t va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ml[u] = 0ull;
+                va[u] = vb[u] = 0u;
+                if (t0 + u < split) {
+                    ml[u] = __hip_atomic_load(reinterpret_cast<unsigned long long*>(part_ml + pre + t0 + u),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    va[u] = __hip_atomic_load(reinterpret_cast<unsigned int*>(part_o + (pre + t0 + u) * D + lane * VPL),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (VPL == 2)
+                        vb[u] = __hip_atomic_load(
+                            reinterpret_cast<unsigned int*>(part_o + (pre + t0 + u) * D + lane * 2 + 1),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float mu = __uint_as_float((uint32_t)ml[u]);
+                if (t0 + u < split && mu != -INFINITY) {
+                    const float e = __expf(mu - mm);
+                    ZZ = fmaf(e, __uint_as_float((uint32_t)(ml[u] >> 32)), ZZ);
+                    q0 = fmaf(e, __uint_as_float(va[u]), q0);
+                    q1 = fmaf(e, __uint_as_float(vb[u]), q1);
+                }
+            }
+        }
+        attn_head_finalize<D>(mm, ZZ, q0, q1, out + (int64_t)h * D, mve, BH, h, head_mz);
+    }
+}
+
 // get_score: logits z_j -> probabilities exp(z_j - m)/Z in place (first nnz entries per head).
 __global__ void attn_normalize_kernel(float* __restrict__ score, const int32_t* __restrict__ nnz,
                                       const float2* __restrict__ head_mz, int64_t M) {
@@ -492,6 +724,33 @@ hipError_t launch_attn_sparse(int D, bool dense, bool qbf16, const uint16_t* kv,
     MP_AT_CASE(64, true, false)
 #undef MP_AT_CASE
     return hipErrorInvalidValue;
+}
+
+// full_attention with the group's K/V read once (G = 1, 2, 4 or 8); false = shape not covered, use the per-head kernel
+bool launch_attn_dense(int D, int G, bool qbf16, const uint16_t* kv, const void* q, const int32_t* nnz, float* part_o,
+                       float2* part_ml, int* head_cnt, uint16_t* out, float* mve, float2* head_mz, float* score,
+                       int BH, int64_t M, int cus, hipStream_t st, hipError_t* err) {
+    if (!(D == 64 || D == 128) || !(G == 1 || G == 2 || G == 4 || G == 8) || BH % G != 0) return false;
+    const int groups = BH / G;
+    const int maxs = attn_slices_per_head(M);
+    // ~4 workgroups of 4 waves per CU; never more workgroups per group than 4-slice bundles of its rows
+    int split = (cus * 4 + groups - 1) / groups;
+    const int64_t bundles = (M + 4 * AH_SLICE - 1) / (4 * AH_SLICE);
+    if (split > bundles) split = (int)bundles;
+    if (split > maxs) split = maxs;
+    if (split < 1) split = 1;
+#define MP_DENSE_CASE(DD, GG, QB)                                                                            \
+    if (D == DD && G == GG && qbf16 == QB) {                                                                 \
+        hipLaunchKernelGGL((attn_dense_kernel<DD, GG, QB>), dim3(groups * split), dim3(256), 0, st, kv, q, nnz, \
+                           part_o, part_ml, head_cnt, out, mve, head_mz, score, BH, groups, M, maxs, split);  \
+        *err = hipGetLastError();                                                                             \
+        return true;                                                                                          \
+    }
+#define MP_DENSE_G(DD, QB) MP_DENSE_CASE(DD, 1, QB) MP_DENSE_CASE(DD, 2, QB) MP_DENSE_CASE(DD, 4, QB) MP_DENSE_CASE(DD, 8, QB)
+    MP_DENSE_G(128, true) MP_DENSE_G(128, false) MP_DENSE_G(64, true) MP_DENSE_G(64, false)
+#undef MP_DENSE_G
+#undef MP_DENSE_CASE
+    return false;
 }
 
 hipError_t launch_attn_normalize(float* score, const int32_t* nnz, const float2* head_mz, int BH,

@@ -50,6 +50,8 @@ int attn_supported_head_dim(int D);
 hipError_t launch_attn_sparse(int, bool, bool, const uint16_t*, const float*, const void*, const float*,
                               const int32_t*, const int32_t*, float*, float2*, int*, uint16_t*, float*,
                               float2*, float*, int, int, int64_t, int, int, int, bool, hipStream_t);
+bool launch_attn_dense(int, int, bool, const uint16_t*, const void*, const int32_t*, float*, float2*, int*, uint16_t*,
+                       float*, float2*, float*, int, int64_t, int, hipStream_t, hipError_t*);
 hipError_t launch_attn_normalize(float*, const int32_t*, const float2*, int, int64_t, hipStream_t);
 hipError_t launch_attn_fill(const uint16_t*, const uint16_t*, const float*, int, int64_t, int,
                             int64_t, uint16_t*, float*, hipStream_t);
@@ -76,6 +78,7 @@ struct DebugOptions {
     std::atomic<int> decode_direct{-1};      // -1 = auto, 0 = never, 1 = always (when R > 1) keep direct piece slots
     std::atomic<int> attn_head_kernel{-1};   // -1 = auto, 0 = split-KV kernel, 1 = one workgroup per head
     std::atomic<int> attn_gx{0};             // 0 = auto, else split-KV workgroups per head
+    std::atomic<int> attn_dense_grouped{1};  // full_attention: 1 = K/V read once per kv group, 0 = once per query head
 };
 static DebugOptions g_opt;
 
@@ -87,6 +90,7 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "decode_direct")) return &g_opt.decode_direct;
     if (!strcmp(name, "attn_head_kernel")) return &g_opt.attn_head_kernel;
     if (!strcmp(name, "attn_gx")) return &g_opt.attn_gx;
+    if (!strcmp(name, "attn_dense_grouped")) return &g_opt.attn_dense_grouped;
     return nullptr;
 }
 
@@ -743,6 +747,18 @@ static int attn_run(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint16
     if (const int o = g_opt.attn_head_kernel.load(); o >= 0) head_kernel = o != 0 && (h->D == 64 || h->D == 128);
     int grid = h->grid;
     if (const int o = g_opt.attn_gx.load(); o >= 1) grid = o;
+    if (dense && g_opt.attn_dense_grouped.load() != 0) {     // K/V once per kv group (G = 1, 2, 4, 8)
+        hipError_t e = hipSuccess;
+        if (launch_attn_dense(h->D, h->G, query_dtype == MP_DTYPE_BF16, h->kv[layer_id], query, nnz, h->part_o,
+                              h->part_ml, h->head_cnt, output, mve, h->head_mz, h->score, BH, h->M, h->cus, st, &e)) {
+            MP_HIP_CHECK(e);
+            h->lastz = nnz;
+            h->score_state = 1;
+            h->seg_cnt = nullptr;
+            h->seg_R = 1;
+            return MP_OK;
+        }
+    }
     MP_HIP_CHECK(launch_attn_sparse(h->D, dense, query_dtype == MP_DTYPE_BF16, h->kv[layer_id],
                                     h->kn[layer_id], query, qn, ind, nnz, h->part_o, h->part_ml,
                                     h->head_cnt, output, mve, h->head_mz, h->score, BH, h->G, h->M, K, L,
