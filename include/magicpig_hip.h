@@ -122,6 +122,16 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads,
  * kn f32 [Hkv, n]. */
 int mp_attn_fill(mp_attn_t* h, int layer_id, int request_id, const uint16_t* k,
                  const uint16_t* v, const float* kn, int64_t n, int mem, mp_stream_t stream);
+/* The sparse-layer branch of LSHSparseAttnServer.fill (models/attnserver.py:126-175) for one request, on device
+ * buffers: key_cache / value_cache bf16 [seq_len, Hkv, D] (token-major, as the model's KV cache holds them).  The
+ * offloaded tokens [num_sink, seq_len - num_local): avg_k = their per-(kv head, dim) mean (bf16 [Hkv, D], written
+ * to `avg_k`, :142), keys centred with it (:145), key norms (:146), K|V rows stored (SparseAttentionServer::fill,
+ * :174) and, when `codes` is not NULL, the key SimHash of the centred keys (:159-168; int16 [Hkv, L, n], n =
+ * seq_len - num_sink - num_local; `s` = the hasher) -- three passes over the KV cache instead of torch's mean / sub /
+ * norm / transpose().contiguous() kernels.  Sums are exact (f64); see csrc/attention.hip for the rounding points. */
+int mp_attn_fill_offload(mp_attn_t* h, mp_simhash_t* s, int layer_id, int request_id, const uint16_t* key_cache,
+                         const uint16_t* value_cache, int64_t seq_len, int num_sink, int num_local,
+                         uint16_t* avg_k, int16_t* codes, mp_stream_t stream);
 /* SparseAttentionServer::attention_wrapper (and attention / scheduled_attention / *_bf16:
  * one function on the GPU), sparse_attention.cc:629-986, 1039-1211.
  *   output bf16 [B*H, D]; max_value_expsum f32 [2, B*H] (row 0 = max*log2e, row 1 = base-2

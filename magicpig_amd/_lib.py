@@ -68,6 +68,7 @@ def lib() -> C.CDLL:
         "mp_attn_destroy": ([p], i32),
         "mp_attn_alloc": ([p, i32, i32, i32, i32, i32, i32], i32),
         "mp_attn_fill": ([p, i32, i32, p, p, p, i64, i32, p], i32),
+        "mp_attn_fill_offload": ([p, p, i32, i32, p, p, i64, i32, i32, p, p, p], i32),
         "mp_attn_sparse": ([p, i32, i32, i32, p, p, p, i32, p, p, p, i32, p], i32),
         "mp_attn_full": ([p, i32, p, p, p, i32, p, i32, p], i32),
         "mp_attn_clear": ([p, p], i32),

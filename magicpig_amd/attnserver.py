@@ -88,13 +88,12 @@ class LSHSparseAttnServer:
         """models/attnserver.py:112-175, sparse-layer branch.  key_cache / value_cache:
         bf16 [seq_len, Hkv, D] on the device."""
         s, l = self.num_sink_tokens, self.num_local_tokens
-        offload_key = key_cache[s:seq_len - l].transpose(0, 1).contiguous()
-        offload_value = value_cache[s:seq_len - l].transpose(0, 1).contiguous()
-        avg_k = offload_key.mean(dim=1, keepdim=True)
-        offload_key = offload_key - avg_k
-        kn = offload_key.norm(p=2, dim=-1).float()
+        # offloaded tokens: mean, centring, norms, K|V store and key SimHash (:136-175) in the store's own kernels
+        # -- three passes over the KV cache, no transposed / centred intermediates
+        avg_k, self.hash_code_buffer = self.attn_server.fill_offload(
+            layer_idx, request_id, key_cache, value_cache, seq_len, s, l, hasher=self.hasher)
         self.avg_k[layer_idx][request_id] = avg_k
-        # sink + local tokens -> the static window, centred with the same avg_k (:126-153)
+        # sink + local tokens -> the static window, centred with the same avg_k (:126-153): a few dozen rows
         if s + l > 0:
             wkey = torch.cat([key_cache[:s], key_cache[seq_len - l:seq_len]], dim=0).transpose(0, 1) - avg_k
             wval = torch.cat([value_cache[:s], value_cache[seq_len - l:seq_len]], dim=0).transpose(0, 1)
@@ -102,9 +101,6 @@ class LSHSparseAttnServer:
             self.window_server.fill(layer_idx, request_id, wkey, wval.contiguous(),
                                     wkey.norm(p=2, dim=-1).float())
         self.set_window_rows(request_id, s + l)
-        # key SimHash (:159-168) -> int16 [Hkv, L, n] on device
-        self.hash_code_buffer = self.hasher.keys(offload_key)
-        self.attn_server.fill(layer_idx, request_id, offload_key, offload_value, kn)
 
     def build_table(self, layer_idx: int, request_id: int, seq_len: int) -> None:
         """models/attnserver.py:178-193: sort the codes of every (kv head, table) row, then

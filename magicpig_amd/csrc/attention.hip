@@ -613,6 +613,79 @@ __global__ void attn_fill_kernel(const uint16_t* __restrict__ k, const uint16_t*
     }
 }
 
+// ---------------------------------------------------------------- prefill: centre + store the offloaded keys
+// models/attnserver.py:136-148 for one request: avg_k = offload_key.mean(dim=1) (bf16), offload_key - avg_k
+// (bf16), kn = that.norm(p=2, dim=-1).float(), then SparseAttentionServer::fill -- as two passes over the model's
+// KV cache (token-major bf16 [seq_len][Hkv*D]) instead of torch's mean / sub / norm / transpose().contiguous()
+// kernels and their intermediates.  Definitions (the oracle's, oracle.centre_keys): the column sum is taken in
+// f64 (exact: bf16 addends, < 2^29 of them), the mean rounded f64 -> f32 -> bf16 RNE; k - avg is the f32
+// difference of two bf16 numbers rounded RNE to bf16; the norm is sqrt of the exact f64 sum of squares, rounded
+// f64 -> f32 -> bf16.  torch sums in f32 in an order of its own, so it can land one bf16 ulp off where the exact
+// value sits within ~1e-6 of a rounding boundary (tests/golden/fill_centre.npz lists those).
+//
+// pass 1a: per-block column sums of tokens [t0, t0 + n): grid = nblk, thread handles 4 adjacent columns
+__global__ __launch_bounds__(256) void key_colsum_kernel(const uint16_t* __restrict__ key_cache, int64_t t0,
+                                                         int64_t n, int cols, double* __restrict__ partial) {
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t a = (int64_t)blockIdx.x * per, b = (a + per < n) ? a + per : n;
+    for (int cb = threadIdx.x * 4; cb < cols; cb += blockDim.x * 4) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int64_t t = a; t < b; ++t) {
+            const uint2 v = *reinterpret_cast<const uint2*>(key_cache + (t0 + t) * cols + cb);
+            acc[0] += (double)bf16_lo(v.x);
+            acc[1] += (double)bf16_hi(v.x);
+            acc[2] += (double)bf16_lo(v.y);
+            acc[3] += (double)bf16_hi(v.y);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) partial[(int64_t)blockIdx.x * cols + cb + i] = acc[i];
+    }
+}
+// pass 1b: avg[c] = bf16(float(sum_b partial[b][c] / n))
+__global__ void key_colmean_kernel(const double* __restrict__ partial, int nblk, int cols, int64_t n,
+                                   uint16_t* __restrict__ avg) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * cols + c];
+    avg[c] = f32_to_bf16_rne((float)(s / (double)n));
+}
+// pass 2: row t of kv head g of the store <- (bf16(k - avg) | v), kn <- norm; one thread per 16 bytes of a row
+__global__ __launch_bounds__(256) void key_centre_fill_kernel(
+    const uint16_t* __restrict__ key_cache, const uint16_t* __restrict__ value_cache, int64_t t0, int64_t n,
+    int Hkv, int D, const uint16_t* __restrict__ avg, int64_t M, uint16_t* __restrict__ kv, float* __restrict__ kn) {
+    const int cpr = D / 8, cols = Hkv * D;
+    const int64_t total = n * Hkv * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ((total + 63) & ~(int64_t)63);
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const bool live = i < total;
+        const int64_t ii = live ? i : total - 1;
+        const int ch = (int)(ii % cpr);
+        const int g = (int)((ii / cpr) % Hkv);
+        const int64_t t = ii / ((int64_t)cpr * Hkv);
+        const int64_t src = (t0 + t) * cols + g * D + ch * 8;
+        u32x4 a = *reinterpret_cast<const u32x4*>(key_cache + src);
+        const u32x4 b = *reinterpret_cast<const u32x4*>(value_cache + src);
+        const u32x4 m = *reinterpret_cast<const u32x4*>(avg + g * D + ch * 8);
+        double ss = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = f32_to_bf16_rne(bf16_lo(a[j]) - bf16_lo(m[j]));
+            const uint32_t hi = f32_to_bf16_rne(bf16_hi(a[j]) - bf16_hi(m[j]));
+            a[j] = lo | (hi << 16);
+            const double dl = (double)bf16_lo(a[j]), dh = (double)bf16_hi(a[j]);
+            ss += dl * dl + dh * dh;
+        }
+        for (int sft = 1; sft < cpr; sft <<= 1) ss += __shfl_xor(ss, sft);    // the cpr chunks of a row: adjacent lanes
+        if (live) {
+            uint16_t* dst = kv + ((int64_t)g * M + t) * 2 * D + ch * 8;
+            *reinterpret_cast<u32x4*>(dst) = a;
+            *reinterpret_cast<u32x4*>(dst + D) = b;
+            if (ch == 0) kn[(int64_t)g * M + t] = bf16_bits_to_f32(f32_to_bf16_rne((float)sqrt(ss)));
+        }
+    }
+}
+
 // flashinfer.append_paged_kv_cache as used at models/attnserver.py:281-290: write this step's
 // (k, v) of every request at row pos[b] of its kv heads.  k, v: bf16 [B][Hkv][D].
 __global__ void attn_append_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
@@ -769,6 +842,21 @@ hipError_t launch_attn_fill(const uint16_t* k, const uint16_t* v, const float* k
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(attn_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, k, v, knorm, Hkv,
                        n, D, M, kv, kn);
+    return hipGetLastError();
+}
+
+// avg bf16 [Hkv*D] (device), partial f64 [nblk][Hkv*D] scratch
+hipError_t launch_key_centre_fill(const uint16_t* key_cache, const uint16_t* value_cache, int64_t t0, int64_t n,
+                                  int Hkv, int D, int64_t M, double* partial, int nblk, uint16_t* avg, uint16_t* kv,
+                                  float* kn, hipStream_t st) {
+    const int cols = Hkv * D;
+    hipLaunchKernelGGL(key_colsum_kernel, dim3(nblk), dim3(256), 0, st, key_cache, t0, n, cols, partial);
+    hipLaunchKernelGGL(key_colmean_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, partial, nblk, cols, n, avg);
+    int64_t blocks = (n * Hkv * (D / 8) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(key_centre_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, key_cache, value_cache, t0, n,
+                       Hkv, D, avg, M, kv, kn);
     return hipGetLastError();
 }
 

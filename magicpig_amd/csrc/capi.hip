@@ -55,6 +55,10 @@ bool launch_attn_dense(int, int, bool, const uint16_t*, const void*, const int32
 hipError_t launch_attn_normalize(float*, const int32_t*, const float2*, int, int64_t, hipStream_t);
 hipError_t launch_attn_fill(const uint16_t*, const uint16_t*, const float*, int, int64_t, int,
                             int64_t, uint16_t*, float*, hipStream_t);
+hipError_t launch_key_centre_fill(const uint16_t*, const uint16_t*, int64_t, int64_t, int, int, int64_t, double*, int,
+                                  uint16_t*, uint16_t*, float*, hipStream_t);
+hipError_t launch_simhash_keys_strided(const uint16_t*, int64_t, int64_t, const uint16_t*, const float*, int, int64_t,
+                                       int, int, int, int16_t*, hipStream_t);
 hipError_t launch_merge_state(const uint16_t*, const float*, const uint16_t*, const float*, int,
                               int, uint16_t*, float*, hipStream_t);
 hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, int, const uint16_t*, int, int, int, int64_t,
@@ -197,6 +201,7 @@ struct mp_attn {
     float2* head_mz = nullptr;     // [BH] (max logit, Z) of the last call
     int* head_cnt = nullptr;       // [BH] arrival tickets of the in-launch merge (zero between calls)
     int* err = nullptr;            // device-side validation flag (append past max_length)
+    double* colsum = nullptr;      // [FILL_BLOCKS][Hkv*D] scratch of mp_attn_fill_offload
     int32_t* last_nnz = nullptr;   // [BH] staging copy of host-side nnz
     const int32_t* lastz = nullptr;// device nnz of the last call (for get_score): last_nnz or the
                                    // caller's own device buffer (valid until it changes)
@@ -604,10 +609,10 @@ static void attn_free(mp_attn_t* h) {
     for (auto p : h->kn) if (p) (void)hipFree(p);
     h->kv.clear();
     h->kn.clear();
-    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt, h->err};
+    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt, h->err, h->colsum};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->score = nullptr; h->part_o = nullptr; h->part_ml = nullptr; h->head_mz = nullptr;
-    h->last_nnz = nullptr; h->head_cnt = nullptr; h->err = nullptr;
+    h->last_nnz = nullptr; h->head_cnt = nullptr; h->err = nullptr; h->colsum = nullptr;
     h->allocated = false;
 }
 
@@ -694,6 +699,42 @@ int mp_attn_fill(mp_attn_t* h, int layer_id, int request_id, const uint16_t* k, 
     MP_HIP_CHECK(launch_attn_fill((const uint16_t*)kd, (const uint16_t*)vd, (const float*)nd, h->Hkv,
                                   n, h->D, h->M, kv, knd, st));
     if (mem == MP_MEM_HOST) MP_HIP_CHECK(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
+// models/attnserver.py:126-175 (sparse-layer branch of fill) for one request, device buffers only
+constexpr int FILL_BLOCKS = 1024;
+
+int mp_attn_fill_offload(mp_attn_t* h, mp_simhash_t* s, int layer_id, int request_id, const uint16_t* key_cache,
+                         const uint16_t* value_cache, int64_t seq_len, int num_sink, int num_local,
+                         uint16_t* avg_k, int16_t* codes, mp_stream_t stream) {
+    MP_ON_DEVICE(h);
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_fill_offload: not allocated");
+    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_attn_fill_offload: layer_id out of range");
+    MP_REQUIRE(request_id >= 0 && request_id < h->B, MP_ERR_INVALID, "mp_attn_fill_offload: request_id out of range");
+    MP_REQUIRE(key_cache && value_cache && avg_k, MP_ERR_INVALID, "mp_attn_fill_offload: null argument");
+    MP_REQUIRE(num_sink >= 0 && num_local >= 0 && seq_len > (int64_t)num_sink + num_local, MP_ERR_INVALID,
+               "mp_attn_fill_offload: nothing to offload (seq_len <= sink + local)");
+    const int64_t n = seq_len - num_sink - num_local;
+    MP_REQUIRE(n <= h->M, MP_ERR_INVALID, "mp_attn_fill_offload: more offloaded tokens than max_length");
+    MP_REQUIRE((h->Hkv * h->D) % 4 == 0, MP_ERR_UNSUPPORTED, "mp_attn_fill_offload: Hkv * head_dim must be a multiple of 4");
+    if (codes != nullptr) {
+        MP_REQUIRE(s && s->Wt, MP_ERR_STATE, "mp_attn_fill_offload: SimHash planes not set");
+        MP_REQUIRE(s->D == h->D && s->device == h->device, MP_ERR_INVALID,
+                   "mp_attn_fill_offload: hasher disagrees on head_dim / device");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (h->colsum == nullptr)
+        MP_HIP_CHECK(hipMalloc((void**)&h->colsum, (size_t)FILL_BLOCKS * h->Hkv * h->D * sizeof(double)));
+    int nblk = (int)((n + 63) / 64);
+    if (nblk > FILL_BLOCKS) nblk = FILL_BLOCKS;
+    uint16_t* kv = h->kv[layer_id] + (size_t)request_id * h->Hkv * h->M * 2 * h->D;
+    float* knd = h->kn[layer_id] + (size_t)request_id * h->Hkv * h->M;
+    MP_HIP_CHECK(launch_key_centre_fill(key_cache, value_cache, num_sink, n, h->Hkv, h->D, h->M, h->colsum, nblk,
+                                        avg_k, kv, knd, st));
+    if (codes != nullptr)   // key SimHash straight from the store's (centred) K rows: row stride 2D, head stride M*2D
+        MP_HIP_CHECK(launch_simhash_keys_strided(kv, h->M * 2 * h->D, 2 * h->D, s->Wt, s->wnorm, h->Hkv, n, s->D,
+                                                 s->K, s->L, codes, st));
     return MP_OK;
 }
 

@@ -248,7 +248,8 @@ constexpr int SK_MAX_TABLES = 32;
 
 template <int D>
 __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void simhash_keys_kernel(
-    const uint16_t* __restrict__ x,       // [heads][n][D] bf16 (centred keys)
+    const uint16_t* __restrict__ x,       // bf16 (centred keys): row r of head h at x + h*head_stride + r*row_stride
+    int64_t head_stride, int64_t row_stride,   // elements: n*D, D for keys [heads][n][D]; M*2D, 2D for the K|V store
     const uint16_t* __restrict__ Wt,      // [KLpad][D]
     const float* __restrict__ wnorm,      // [KLpad]
     int64_t n, int K, int L, int tables_per_wg, int tiles_per_wg, int chunk_tiles, int wgs_x, int chunks,
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
     const int head = (int)(unit / chunks), chunk = (int)(unit % chunks);
     const int table0 = colgrp * tables_per_wg;
     const int col0 = table0 * K, KL = K * L;   // col0 is NOT tile aligned: Wt is row-per-plane, any start works
-    x += (int64_t)head * n * D;
+    x += (int64_t)head * head_stride;
     codes += (int64_t)head * L * n;
     const int64_t row_base = (int64_t)chunk * CROWS;
     int nt = (int)((n - row_base + SH_ROWS - 1) / SH_ROWS);
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
             c = c < NCH ? c : NCH - 1;
             int64_t gr = row_base + (int64_t)t * SH_ROWS + c / CPR;
             gr = gr < n ? gr : n - 1;
-            st[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + gr * D + (c % CPR) * 8));
+            st[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + gr * row_stride + (c % CPR) * 8));
         }
     };
     auto tile_store = [&](int buf, const u32x4 (&st)[QN]) {
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
         const int l16 = tid & 15;
         double part = 0.0;
         for (int d8 = l16; d8 < CPR; d8 += 16) {
-            const u32x4 a = *reinterpret_cast<const u32x4*>(x + (row_base + crow) * D + d8 * 8);
+            const u32x4 a = *reinterpret_cast<const u32x4*>(x + (row_base + crow) * row_stride + d8 * 8);
             const u32x4 w = *reinterpret_cast<const u32x4*>(Wt + (int64_t)(col0 + coff) * D + d8 * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
             if (col0 + coff >= KL || row_base + crow >= n) continue;
             double ex = 0.0;
             for (int d = 0; d < D; ++d)
-                ex += (double)bf16_bits_to_f32(x[(row_base + crow) * D + d]) *
+                ex += (double)bf16_bits_to_f32(x[(row_base + crow) * row_stride + d]) *
                       (double)bf16_bits_to_f32(Wt[(int64_t)(col0 + coff) * D + d]);
             uint32_t* wd = &s_rowbits[crow * BW + (coff >> 5)];
             const uint32_t m = 1u << (coff & 31);
@@ -605,8 +606,9 @@ static int keys_chunk_tiles(int64_t n, int64_t wgs_x, int tables_per_wg) {
 
 // keys [heads][n][D] -> codes int16 [heads][L][n]; all kv heads in ONE launch so that the tail
 // round of one head is filled by the next
-hipError_t launch_simhash_keys(const uint16_t* keys, const uint16_t* Wt, const float* wnorm,
-                               int heads, int64_t n, int D, int K, int L, int16_t* codes, hipStream_t st) {
+hipError_t launch_simhash_keys_strided(const uint16_t* keys, int64_t head_stride, int64_t row_stride,
+                                       const uint16_t* Wt, const float* wnorm, int heads, int64_t n, int D, int K,
+                                       int L, int16_t* codes, hipStream_t st) {
     int tp, tiles;
     simhash_keys_geometry(K, tp, tiles);
     const int wgs_x = (L + tp - 1) / tp;
@@ -628,8 +630,9 @@ hipError_t launch_simhash_keys(const uint16_t* keys, const uint16_t* Wt, const f
     const size_t lds = (size_t)crows * (SK_WAVES + 1) * sizeof(uint32_t);   // the chunk's sign matrix
 #define MP_SK_CASE(DD)                                                                              \
     if (D == DD) {                                                                                  \
-        hipLaunchKernelGGL((simhash_keys_kernel<DD>), grid, block, lds, st, keys, Wt, wnorm, n, K,  \
-                           L, tp, tiles, ch, wgs_x, (int)chunks, heads, codes, g_stamp);            \
+        hipLaunchKernelGGL((simhash_keys_kernel<DD>), grid, block, lds, st, keys, head_stride,      \
+                           row_stride, Wt, wnorm, n, K, L, tp, tiles, ch, wgs_x, (int)chunks, heads, \
+                           codes, g_stamp);                                                         \
         return hipGetLastError();                                                                   \
     }
     MP_SK_CASE(128)
@@ -637,6 +640,11 @@ hipError_t launch_simhash_keys(const uint16_t* keys, const uint16_t* Wt, const f
     MP_SK_CASE(256)
 #undef MP_SK_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_simhash_keys(const uint16_t* keys, const uint16_t* Wt, const float* wnorm,
+                               int heads, int64_t n, int D, int K, int L, int16_t* codes, hipStream_t st) {
+    return launch_simhash_keys_strided(keys, n * D, D, Wt, wnorm, heads, n, D, K, L, codes, st);
 }
 
 }  // namespace mp

@@ -45,6 +45,27 @@ class SparseAttentionServer:
         L.check(L.lib().mp_attn_fill(self._h, layer_id, request_id, L.ptr(k), L.ptr(v), L.ptr(kn), n,
                                      mem, L.current_stream(k, self._device)))
 
+    def fill_offload(self, layer_id: int, request_id: int, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                     seq_len: int, num_sink: int, num_local: int, hasher=None):
+        """Not in the reference class: the torch lines around SparseAttentionServer::fill in
+        LSHSparseAttnServer.fill (models/attnserver.py:126-175) folded into the store's own kernels.
+        key_cache / value_cache: bf16 CUDA tensors [>= seq_len, Hkv, D] (token-major).  Stores the centred keys,
+        values and key norms of tokens [num_sink, seq_len - num_local) and returns (avg_k bf16 [Hkv, 1, D],
+        key codes int16 [Hkv, L, n] or None when no hasher is given)."""
+        L.expect(key_cache[:seq_len], torch.bfloat16, (seq_len, self.Hkv, self.D), "key_cache")
+        L.expect(value_cache[:seq_len], torch.bfloat16, (seq_len, self.Hkv, self.D), "value_cache")
+        if not (key_cache.is_cuda and value_cache.is_cuda):
+            raise ValueError("fill_offload takes CUDA tensors")
+        n = seq_len - num_sink - num_local
+        avg = torch.empty((self.Hkv, 1, self.D), dtype=torch.bfloat16, device=key_cache.device)
+        codes = None
+        if hasher is not None:
+            codes = torch.empty((self.Hkv, hasher.L, n), dtype=torch.int16, device=key_cache.device)
+        L.check(L.lib().mp_attn_fill_offload(self._h, hasher._h if hasher is not None else None, layer_id, request_id,
+                                             L.ptr(key_cache), L.ptr(value_cache), seq_len, num_sink, num_local,
+                                             L.ptr(avg), L.ptr(codes), L.current_stream(key_cache, self._device)))
+        return avg, codes
+
     def attention_wrapper(self, layer_id: int, K: int, L_: int, output: torch.Tensor,
                           max_value_expsum: torch.Tensor, query: torch.Tensor,
                           query_norm: torch.Tensor, ind: torch.Tensor, nnz: torch.Tensor) -> None:

@@ -8,6 +8,7 @@ from .oracle import (  # noqa: F401
     LSH,
     SparseAttentionServer,
     build,
+    centre_keys,
     lib,
     merge_state,
     simhash_keys,

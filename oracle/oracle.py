@@ -153,6 +153,28 @@ def simhash_keys(keys, hash_func, K: int, L: int) -> np.ndarray:
     return codes
 
 
+def centre_keys(key_cache, value_cache, seq_len: int, num_sink: int, num_local: int):
+    """models/attnserver.py:136-148 for one request, as DEFINED for the HIP path (csrc/attention.hip,
+    key_centre_fill_kernel): key_cache / value_cache bf16 [>= seq_len, Hkv, D] ->
+        avg_k   bf16 bits [Hkv, D]    mean over the offloaded tokens [num_sink, seq_len - num_local): exact sum
+                                      (f64 of bf16 addends), rounded f64 -> f32 -> bf16 (RNE)
+        keys    bf16 bits [Hkv, n, D] bf16(f32(k) - f32(avg_k)) (RNE)
+        values  bf16 bits [Hkv, n, D]
+        kn      f32 [Hkv, n]          sqrt of the exact sum of squares of the centred key, f64 -> f32 -> bf16
+    torch evaluates the same three lines with f32 sums in its own order: equal except where the exact value sits
+    within ~1e-6 relative of a bf16 rounding boundary (tests/golden/fill_centre.npz lists those positions)."""
+    kb = bf16_bits(key_cache)[num_sink:seq_len - num_local]
+    vb = bf16_bits(value_cache)[num_sink:seq_len - num_local]
+    kf = bf16_to_f32(kb).astype(np.float64)                                   # [n, Hkv, D]
+    avg32 = (kf.sum(axis=0) / kf.shape[0]).astype(np.float32)
+    avg = bf16_bits(avg32)                                                    # RNE
+    cen = bf16_bits((bf16_to_f32(kb) - bf16_to_f32(avg)[None]).astype(np.float32))
+    cf = bf16_to_f32(cen).astype(np.float64)
+    kn = bf16_to_f32(bf16_bits(np.sqrt((cf * cf).sum(-1)).astype(np.float32)))
+    return (avg, np.ascontiguousarray(cen.transpose(1, 0, 2)), np.ascontiguousarray(vb.transpose(1, 0, 2)),
+            np.ascontiguousarray(kn.T))
+
+
 def merge_state(va, sa, vb, sb):
     """flashinfer.merge_state restated (models/attnserver.py:308; pinned by tests/golden/window_merge.npz)."""
     a = bf16_bits(va)

@@ -105,3 +105,16 @@ def window_merge_inputs(c):
     wk = [synth.normal_bf16_bits(seed + 100 + b, (Hkv, c["win_rows"][b], D)) for b in range(B)]
     wv = [synth.normal_bf16_bits(seed + 200 + b, (Hkv, c["win_rows"][b], D)) for b in range(B)]
     return keys, kns, vals, W, qb, wk, wv
+
+
+# ---- prefill fixture (tests/golden/fill_centre.npz, SURVEY f-1): key / value caches of one request
+FILL_CENTRE = dict(seed=71, seq_len=3000, Hkv=4, D=128, num_sink=4, num_local=64)
+
+
+def fill_centre_inputs(c):
+    """Token-major bf16 caches [seq_len, Hkv, D] whose keys have a clear per-column mean (as RoPE'd keys do)."""
+    T, Hkv, D = c["seq_len"], c["Hkv"], c["D"]
+    mean = synth.normal_f32(c["seed"] + 2, (1, Hkv, D)) * np.float32(0.75)
+    k = synth.f32_to_bf16_bits((synth.normal_f32(c["seed"], (T, Hkv, D)) + mean).astype(np.float32))
+    v = synth.normal_bf16_bits(c["seed"] + 1, (T, Hkv, D))
+    return k, v

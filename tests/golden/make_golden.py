@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import synth  # noqa: E402
-from cases import (FULL_DENSE_CASES, WINDOW_MERGE, full_dense_inputs, full_dense_seed,  # noqa: E402
-                   window_merge_inputs)
+from cases import (FILL_CENTRE, FULL_DENSE_CASES, WINDOW_MERGE, fill_centre_inputs,  # noqa: E402
+                   full_dense_inputs, full_dense_seed, window_merge_inputs)
 from oracle.build_ref import load_ref, ref_uses_bf16_family  # noqa: E402
 
 
@@ -369,6 +369,44 @@ def run_window_merge(name, out):
     print(f"{name}: nnz {nnz.tolist()} lse window {w_lse[:3].tolist()} sparse {sp_lse[:3].tolist()}")
 
 
+def run_fill_centre(name, out):
+    """models/attnserver.py:133-146 verbatim on CPU tensors (sparse-layer branch of fill): the offloaded keys'
+    mean, the centred keys and their norms, for one request.  torch's bf16 mean / norm accumulate in f32 in an
+    order of the library's choosing, so next to torch's outputs the fixture lists where they differ from the
+    exactly-summed definition (oracle.centre_keys) -- one bf16 ulp at a rounding boundary, by construction."""
+    from oracle import oracle as orc
+
+    c = FILL_CENTRE
+    k, v = fill_centre_inputs(c)
+    T, s_, l_ = c["seq_len"], c["num_sink"], c["num_local"]
+    key_cache, value_cache = synth.to_torch_bf16(k), synth.to_torch_bf16(v)
+    offload_key = key_cache[s_:T - l_]                                        # :133
+    offload_value = value_cache[s_:T - l_]
+    offload_key = offload_key.transpose(0, 1).contiguous()                    # :136
+    offload_value = offload_value.transpose(0, 1).contiguous()
+    avg_k = offload_key.mean(dim=1, keepdim=True)                             # :139
+    offload_key = offload_key - avg_k                                         # :142
+    kn = offload_key.norm(p=2, dim=-1).float()                                # :143
+    bits = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+    t_avg, t_key, t_kn = bits(avg_k)[:, 0], bits(offload_key), kn.numpy().copy()
+    e_avg, e_key, e_val, e_kn = orc.centre_keys(k, v, T, s_, l_)
+    assert np.array_equal(e_val, bits(offload_value))
+    avg_ties = np.argwhere(t_avg != e_avg)
+    # centred keys / norms given TORCH's avg_k must follow the definition exactly, ties in the norm aside
+    cen_t = synth.f32_to_bf16_bits((synth.bf16_bits_to_f32(k[s_:T - l_]) - synth.bf16_bits_to_f32(t_avg)[None]).astype(np.float32))
+    assert np.array_equal(cen_t.transpose(1, 0, 2), t_key)
+    cf = synth.bf16_bits_to_f32(t_key).astype(np.float64)
+    kn_exact = synth.bf16_bits_to_f32(synth.f32_to_bf16_bits(np.sqrt((cf * cf).sum(-1)).astype(np.float32)))
+    kn_ties = np.argwhere(kn_exact != t_kn)
+    out[name] = dict(meta=np.array([c["seed"], T, c["Hkv"], c["D"], s_, l_], np.int64),
+                     avg_k=t_avg, kn=t_kn, key_sha=np.frombuffer(hashlib.sha256(t_key.tobytes()).digest(), np.uint8),
+                     key_head0_tok0=t_key[0, 0].copy(), avg_ties=avg_ties.astype(np.int64),
+                     avg_exact_at_ties=e_avg[tuple(avg_ties.T)] if len(avg_ties) else np.zeros((0,), np.uint16),
+                     kn_ties=kn_ties.astype(np.int64),
+                     kn_exact_at_ties=kn_exact[tuple(kn_ties.T)] if len(kn_ties) else np.zeros((0,), np.float32))
+    print(f"{name}: {len(avg_ties)} of {t_avg.size} means and {len(kn_ties)} of {t_kn.size} norms are summation-order ties")
+
+
 def main():
     only = set(sys.argv[1:])            # fixture names to (re)generate; none = all
     ref_lsh, ref_attn = load_ref()
@@ -392,6 +430,7 @@ def main():
     run_cfg1_retrieve_sha("cfg1_retrieve_sha", 51, ref_lsh, cases)
     run_full_dense("full_dense", 55, ref_attn, cases)
     run_window_merge("window_merge", cases)
+    run_fill_centre("fill_centre", cases)
     wrote = 0
     for name, d in cases.items():
         if only and name not in only:

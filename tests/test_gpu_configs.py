@@ -320,3 +320,51 @@ def test_cfg2_full_size_fused_decode_properties(mp):
     ref = server4.decode_full(q, k_new, v_new, 0).float().cpu().numpy().reshape(BH, D)
     assert torch.equal(server.nnz, server4.nnz)
     assert np.allclose(got, ref, rtol=2 ** -6, atol=4e-3)
+
+
+# ------------------------------------------------------------------ f-1: prefill fill on device vs the torch fixture
+
+def test_fill_offload_vs_torch_fixture(mp):
+    """mp_attn_fill_offload (column mean, centring, norms, K|V store and key SimHash in the store's kernels) against
+    tests/golden/fill_centre.npz -- the torch-CPU execution of models/attnserver.py:133-146 -- and the oracle's
+    exactly-summed definition: avg_k, centred keys, values and norms bit for bit; key codes bit for bit against the
+    oracle's SimHash of the centred keys; and LSHSparseAttnServer.fill end to end (window rows, tables)."""
+    c = cases.FILL_CENTRE
+    g = cases.load_golden("fill_centre")
+    T, Hkv, D, s_, l_ = c["seq_len"], c["Hkv"], c["D"], c["num_sink"], c["num_local"]
+    n = T - s_ - l_
+    k, v = cases.fill_centre_inputs(c)
+    e_avg, e_keys, e_vals, e_kn = oracle.centre_keys(k, v, T, s_, l_)
+    K, L, H, M = 8, 20, 2 * Hkv, 3072
+    W = synth.normal_bf16_bits(77, (D, K * L))
+    server = mp.LSHSparseAttnServer(2, H, Hkv, D, K=K, L=L, batch_size=2, num_sink_tokens=s_, num_local_tokens=l_,
+                                    max_length=M, dense_layers=(), hash_func=bf16_t(W, "cuda"))
+    kc, vc = bf16_t(k, "cuda"), bf16_t(v, "cuda")
+    server.fill(1, 1, kc, vc, T)
+    codes = server.hash_code_buffer.cpu().numpy()
+    server.build_table(1, 1, T)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits_of(server.avg_k[1][1, :, 0]), e_avg)
+    if len(g["avg_ties"]) == 0:
+        assert np.array_equal(e_avg, g["avg_k"])                                   # == torch's mean
+    srv = server.attn_server
+    assert np.array_equal(bits_of(srv.get_key_cache(1)[1, :, :n]), e_keys)
+    assert np.array_equal(bits_of(srv.get_value_cache(1)[1, :, :n]), e_vals)
+    kn = srv.get_key_norm(1)[1, :, :n].cpu().numpy()
+    assert np.array_equal(kn, e_kn)
+    if len(g["kn_ties"]) == 0 and len(g["avg_ties"]) == 0:
+        assert np.array_equal(kn, g["kn"])                                        # == torch's norms
+        assert np.array_equal(bits_of(srv.get_key_cache(1)[1, 0, 0]), g["key_head0_tok0"])
+    assert np.array_equal(codes, oracle.simhash_keys(e_keys, W, K, L))              # hashed from the store's rows
+    # request 0 / layer 0 untouched
+    assert not bits_of(srv.get_key_cache(1)[0, :, :8]).any() and not bits_of(srv.get_key_cache(0)[1, :, :8]).any()
+    # static window: sink + local rows, centred with the same avg_k (attnserver.py:126-153)
+    wk = bits_of(server.window_server.get_key_cache(1)[1, :, :s_ + l_])
+    rows = np.concatenate([k[:s_], k[T - l_:T]]).transpose(1, 0, 2)
+    want = synth.f32_to_bf16_bits((synth.bf16_bits_to_f32(rows) - synth.bf16_bits_to_f32(e_avg)[:, None]).astype(np.float32))
+    assert np.array_equal(wk, want)
+    assert server.kv_last_page_len.tolist() == [0, s_ + l_]
+    # the tables hold every offloaded token once per (kv head, table)
+    bounds, table = server.lsh_retriever.get_tables(1)
+    assert int((bounds[Hkv:, ..., -1] - bounds[Hkv:, ..., 0]).sum()) == Hkv * L * n
+    assert torch.equal(table[Hkv, 0, :n].sort().values.cpu(), torch.arange(n, dtype=torch.int32))

@@ -848,14 +848,12 @@ def test_server_fill_centres_keys(mp):
     server.fill(0, 0, kc, vc, seq)
     server.build_table(0, 0, seq)
     n = seq - 68
-    off = kc[4:seq - 64].transpose(0, 1).contiguous()
-    avg = off.mean(dim=1, keepdim=True)
-    cen = off - avg
-    kcache = server.attn_server.get_key_cache(0)[0, :, :n]
-    vcache = server.attn_server.get_value_cache(0)[0, :, :n]
-    assert torch.equal(kcache, cen)
-    assert torch.equal(vcache, vc[4:seq - 64].transpose(0, 1))
-    assert torch.equal(server.attn_server.get_key_norm(0)[0, :, :n], cen.norm(p=2, dim=-1).float())
+    # the oracle's exactly-summed statement of attnserver.py:136-146 (pinned to torch by tests/golden/fill_centre.npz)
+    e_avg, e_keys, e_vals, e_kn = oracle.centre_keys(kc.cpu(), vc.cpu(), seq, 4, 64)
+    assert np.array_equal(bits_of(server.avg_k[0][0, :, 0]), e_avg)
+    assert np.array_equal(bits_of(server.attn_server.get_key_cache(0)[0, :, :n]), e_keys)
+    assert np.array_equal(bits_of(server.attn_server.get_value_cache(0)[0, :, :n]), e_vals)
+    assert np.array_equal(server.attn_server.get_key_norm(0)[0, :, :n].cpu().numpy(), e_kn)
     # tables hold every offloaded token exactly once per (kv head, table)
     bounds, table = server.lsh_retriever.get_tables(0)
     assert torch.equal(table[0, 0, :n].sort().values.cpu(), torch.arange(n, dtype=torch.int32))

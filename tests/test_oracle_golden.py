@@ -295,3 +295,31 @@ def test_window_merge_matches_torch_statement():
     v2, s2 = oracle.merge_state(w_out, w_mve[1], sp_out, sp_mve[1])
     assert np.allclose(s2, g["joint_lse"], atol=5e-3)
     assert np.allclose(synth.bf16_bits_to_f32(v2), g["joint_out"], rtol=1e-2, atol=1e-2)
+
+
+# ------------------------------------------------------------------ f-1: key centring / norms of the prefill
+
+def test_fill_centre_matches_torch():
+    """oracle.centre_keys (exact sums; the definition the HIP fill kernels implement) against the torch-CPU
+    execution of models/attnserver.py:133-146 (tests/golden/make_golden.py: run_fill_centre): equal bit for bit,
+    except at the listed summation-order ties (torch sums in f32), where the fixture holds both values."""
+    c = cases.FILL_CENTRE
+    g = cases.load_golden("fill_centre")
+    k, v = cases.fill_centre_inputs(c)
+    avg, keys, vals, kn = oracle.centre_keys(k, v, c["seq_len"], c["num_sink"], c["num_local"])
+    n = c["seq_len"] - c["num_sink"] - c["num_local"]
+    assert keys.shape == (c["Hkv"], n, c["D"]) and kn.shape == (c["Hkv"], n)
+    t_avg = g["avg_k"].copy()
+    assert len(g["avg_ties"]) <= 2 and len(g["kn_ties"]) <= 4            # rounding-boundary cases only
+    for (i, j), e in zip(g["avg_ties"], g["avg_exact_at_ties"]):
+        assert abs(int(t_avg[i, j]) - int(e)) == 1                       # one bf16 ulp apart
+        t_avg[i, j] = e
+    assert np.array_equal(avg, t_avg)
+    t_kn = g["kn"].copy()
+    for (i, j), e in zip(g["kn_ties"], g["kn_exact_at_ties"]):
+        t_kn[i, j] = e
+    if len(g["avg_ties"]) == 0:      # same avg_k => same centred keys
+        assert np.array_equal(np.frombuffer(hashlib.sha256(keys.tobytes()).digest(), np.uint8), g["key_sha"])
+        assert np.array_equal(keys[0, 0], g["key_head0_tok0"])
+        assert np.array_equal(kn, t_kn)
+    assert np.array_equal(vals, np.ascontiguousarray(v[c["num_sink"]:c["seq_len"] - c["num_local"]].transpose(1, 0, 2)))
