@@ -750,6 +750,53 @@ __global__ void merge_state_kernel(const uint16_t* __restrict__ va, const float*
     if (s != nullptr && threadIdx.x == 0) s[rr] = lse;
 }
 
+// ---------------------------------------------------------------- host-buffer mode: ragged rows <-> one packed buffer
+// The reference's callers hand over CPU tensors results / ind [BH][M] of which only the first nnz[h] entries of
+// row h mean anything (models/attnserver.py:299-300).  Instead of one hipMemcpy per head, the rows cross PCIe as
+// ONE packed buffer: offs = exclusive prefix of min(nnz, M) (one workgroup), rows <-> packed by position.
+__global__ __launch_bounds__(1024) void ragged_offsets_kernel(const int32_t* __restrict__ nnz, int BH, int64_t M,
+                                                              int32_t* __restrict__ offs) {   // [BH + 1]
+    __shared__ int s_tmp[32];
+    int carry = 0;
+    for (int base = 0; base < BH; base += 1024) {
+        const int i = base + threadIdx.x;
+        int v = 0;
+        if (i < BH) {
+            v = nnz[i];
+            v = v < 0 ? 0 : ((int64_t)v > M ? (int)M : v);
+        }
+        int total;
+        __syncthreads();
+        const int ex = block_excl_scan(v, s_tmp, total) + carry;
+        if (i < BH) offs[i] = ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) offs[BH] = carry;
+}
+template <bool PACK>
+__global__ void ragged_copy_kernel(int32_t* __restrict__ rows, int32_t* __restrict__ packed,
+                                   const int32_t* __restrict__ offs, int64_t M) {
+    const int h = blockIdx.y;
+    const int o = offs[h], n = offs[h + 1] - o;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        if (PACK) packed[o + j] = rows[(int64_t)h * M + j];
+        else rows[(int64_t)h * M + j] = packed[o + j];
+    }
+}
+
+hipError_t launch_ragged_offsets(const int32_t* nnz, int BH, int64_t M, int32_t* offs, hipStream_t st) {
+    hipLaunchKernelGGL(ragged_offsets_kernel, dim3(1), dim3(1024), 0, st, nnz, BH, M, offs);
+    return hipGetLastError();
+}
+hipError_t launch_ragged_copy(bool pack, int32_t* rows, int32_t* packed, const int32_t* offs, int BH, int64_t M,
+                              hipStream_t st) {
+    int gx = (int)((M + 255) / 256);
+    if (gx > 16) gx = 16;
+    if (pack) hipLaunchKernelGGL(ragged_copy_kernel<true>, dim3(gx, BH), dim3(256), 0, st, rows, packed, offs, M);
+    else hipLaunchKernelGGL(ragged_copy_kernel<false>, dim3(gx, BH), dim3(256), 0, st, rows, packed, offs, M);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- host launchers
 // partial records per head: one per 64-entry slice of the index list
 int attn_slices_per_head(int64_t M) { return (int)((M + 63) / 64); }

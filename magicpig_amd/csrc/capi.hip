@@ -59,6 +59,8 @@ hipError_t launch_key_centre_fill(const uint16_t*, const uint16_t*, int64_t, int
                                   uint16_t*, uint16_t*, float*, hipStream_t);
 hipError_t launch_simhash_keys_strided(const uint16_t*, int64_t, int64_t, const uint16_t*, const float*, int, int64_t,
                                        int, int, int, int16_t*, hipStream_t);
+hipError_t launch_ragged_offsets(const int32_t*, int, int64_t, int32_t*, hipStream_t);
+hipError_t launch_ragged_copy(bool, int32_t*, int32_t*, const int32_t*, int, int64_t, hipStream_t);
 hipError_t launch_merge_state(const uint16_t*, const float*, const uint16_t*, const float*, int,
                               int, uint16_t*, float*, hipStream_t);
 hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, int, const uint16_t*, int, int, int, int64_t,
@@ -144,6 +146,30 @@ static int stage_in(const void* src, size_t bytes, int mem, DevBuf& buf, const v
     return MP_OK;
 }
 
+// Persistent staging of the host-buffer mode: a pinned host block and a device block of the same size, grown on
+// demand and kept by the handle (no hipMalloc / hipFree per call).
+struct Stage {
+    void* hp = nullptr;   // pinned host
+    void* dp = nullptr;   // device
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return MP_OK;
+        size_t want = cap ? cap : 4096;
+        while (want < bytes) want *= 2;
+        release();
+        MP_HIP_CHECK(hipHostMalloc(&hp, want, hipHostMallocDefault));
+        MP_HIP_CHECK(hipMalloc(&dp, want));
+        cap = want;
+        return MP_OK;
+    }
+    void release() {
+        if (hp) (void)hipHostFree(hp);
+        if (dp) (void)hipFree(dp);
+        hp = dp = nullptr;
+        cap = 0;
+    }
+};
+
 static int alloc_zero(void** p, size_t bytes) {
     MP_HIP_CHECK(hipMalloc(p, bytes ? bytes : 1));
     MP_HIP_CHECK(hipMemset(*p, 0, bytes));
@@ -176,6 +202,7 @@ struct mp_lsh {
     std::vector<int32_t*> table;   // per layer [B*Hkv][L][M]
     std::vector<int32_t*> slots;   // per layer [B*Hkv][L][NB][R][32] direct piece slots, or empty (R = 1 / long pieces)
     int* part_cnt = nullptr;       // [BH][8] per-member selected counts of the last decode launch
+    Stage small, big;              // host-buffer mode: (nnz | offsets) and the packed result rows
     int32_t* last_query = nullptr; // [BH][L] staging copy of host-side query codes
     const int32_t* lastq = nullptr;// device codes of the last retrieve (for get_mask): last_query,
                                    // `codes`, or the caller's own device buffer (valid until it changes)
@@ -202,6 +229,8 @@ struct mp_attn {
     int* head_cnt = nullptr;       // [BH] arrival tickets of the in-launch merge (zero between calls)
     int* err = nullptr;            // device-side validation flag (append past max_length)
     double* colsum = nullptr;      // [FILL_BLOCKS][Hkv*D] scratch of mp_attn_fill_offload
+    Stage small, big;              // host-buffer mode: (q | qn | nnz | offsets | out | mve) and the packed index rows
+    int32_t* ind_rows = nullptr;   // host-buffer mode: [BH][M] device copy of `ind`
     int32_t* last_nnz = nullptr;   // [BH] staging copy of host-side nnz
     const int32_t* lastz = nullptr;// device nnz of the last call (for get_score): last_nnz or the
                                    // caller's own device buffer (valid until it changes)
@@ -342,6 +371,8 @@ static void lsh_free(mp_lsh_t* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->last_query = nullptr; h->err = nullptr; h->codes = nullptr; h->results = nullptr;
     h->nnz = nullptr; h->qnorm = nullptr; h->part_cnt = nullptr;
+    h->small.release();
+    h->big.release();
     h->allocated = false;
 }
 
@@ -522,19 +553,35 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
                                          nnz, BH, h->G, h->L, h->NB, h->M, h->R, st));
         return MP_OK;
     }
-    // host callers (models/attnserver.py:299 passes pinned CPU tensors): stage through the
-    // handle's step buffers; only the first nnz[h] entries of each row are copied back.
-    MP_HIP_CHECK(hipMemcpy(h->last_query, query, qb, hipMemcpyHostToDevice));
+    // host callers (models/attnserver.py:299 passes pinned CPU tensors): stage through the handle's step buffers;
+    // only the first nnz[h] entries of each row mean anything, and they come back as ONE packed copy
+    int rc = h->small.reserve((size_t)(2 * BH + 1) * 4);
+    if (rc) return rc;
+    MP_HIP_CHECK(hipMemcpyAsync(h->last_query, query, qb, hipMemcpyHostToDevice, st));
     h->lastq = h->last_query;
     h->last_layer = layer_id;
     MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], h->last_query,
                                      h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, st));
+    int32_t* d_offs = reinterpret_cast<int32_t*>(h->small.dp) + BH;           // dp: [nnz BH | offs BH + 1]
+    MP_HIP_CHECK(launch_ragged_offsets(h->nnz, BH, h->M, d_offs, st));
+    MP_HIP_CHECK(hipMemcpyAsync(h->small.dp, h->nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));
+    MP_HIP_CHECK(hipMemcpyAsync(h->small.hp, h->small.dp, (size_t)(2 * BH + 1) * 4, hipMemcpyDeviceToHost, st));
     MP_HIP_CHECK(hipStreamSynchronize(st));
-    MP_HIP_CHECK(hipMemcpy(nnz, h->nnz, (size_t)BH * 4, hipMemcpyDeviceToHost));
-    for (int i = 0; i < BH; ++i)
-        if (nnz[i] > 0)
-            MP_HIP_CHECK(hipMemcpy(results + (size_t)i * h->M, h->results + (size_t)i * h->M,
-                                   (size_t)nnz[i] * 4, hipMemcpyDeviceToHost));
+    const int32_t* hs = reinterpret_cast<const int32_t*>(h->small.hp);
+    memcpy(nnz, hs, (size_t)BH * 4);
+    const int32_t* offs = hs + BH;
+    const size_t total = (size_t)offs[BH];
+    if (total > 0) {
+        rc = h->big.reserve(total * 4);
+        if (rc) return rc;
+        MP_HIP_CHECK(launch_ragged_copy(true, h->results, reinterpret_cast<int32_t*>(h->big.dp), d_offs, BH, h->M, st));
+        MP_HIP_CHECK(hipMemcpyAsync(h->big.hp, h->big.dp, total * 4, hipMemcpyDeviceToHost, st));
+        MP_HIP_CHECK(hipStreamSynchronize(st));
+        const int32_t* packed = reinterpret_cast<const int32_t*>(h->big.hp);
+        for (int i = 0; i < BH; ++i)
+            if (offs[i + 1] > offs[i])
+                memcpy(results + (size_t)i * h->M, packed + offs[i], (size_t)(offs[i + 1] - offs[i]) * 4);
+    }
     return MP_OK;
 }
 
@@ -613,6 +660,10 @@ static void attn_free(mp_attn_t* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->score = nullptr; h->part_o = nullptr; h->part_ml = nullptr; h->head_mz = nullptr;
     h->last_nnz = nullptr; h->head_cnt = nullptr; h->err = nullptr; h->colsum = nullptr;
+    if (h->ind_rows) (void)hipFree(h->ind_rows);
+    h->ind_rows = nullptr;
+    h->small.release();
+    h->big.release();
     h->allocated = false;
 }
 
@@ -826,36 +877,55 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
     const int BH = h->B * h->H;
     if (mem == MP_MEM_DEVICE)
         return attn_run(h, layer_id, dense, K, L, output, mve, query, query_dtype, qn, ind, nnz, st);
-    DevBuf dout, dmve, dq, dqn, dind;
+    // host buffers: ONE block of small arguments up (q | qn | nnz | offsets), the index rows packed to their first
+    // nnz[h] entries in ONE copy, unpacked on device into the handle's [BH][M] rows; (out | mve) come back in ONE
+    // copy.  All staging is pinned and owned by the handle.
     const size_t qbytes = (size_t)BH * h->D * (query_dtype == MP_DTYPE_BF16 ? 2 : 4);
-    MP_HIP_CHECK(dout.alloc((size_t)BH * h->D * 2));
-    MP_HIP_CHECK(dmve.alloc((size_t)2 * BH * 4));
-    const void *qd, *qnd = nullptr, *indd = nullptr, *nnzd;
-    int rc = stage_in(query, qbytes, mem, dq, &qd);
-    if (rc == MP_OK) {   // nnz must outlive this call for get_score: stage into the handle
-        MP_HIP_CHECK(hipMemcpy(h->last_nnz, nnz, (size_t)BH * 4, hipMemcpyHostToDevice));
-        nnzd = h->last_nnz;
+    const size_t o_q = 0, o_qn = o_q + ((qbytes + 15) & ~(size_t)15), o_nnz = o_qn + (size_t)BH * 4,
+                 o_offs = o_nnz + (size_t)BH * 4, o_out = (o_offs + (size_t)(BH + 1) * 4 + 15) & ~(size_t)15,
+                 o_mve = o_out + (size_t)BH * h->D * 2, o_end = o_mve + (size_t)2 * BH * 4;
+    int rc = h->small.reserve(o_end);
+    if (rc) return rc;
+    char* hp = reinterpret_cast<char*>(h->small.hp);
+    char* dp = reinterpret_cast<char*>(h->small.dp);
+    memcpy(hp + o_q, query, qbytes);
+    if (!dense) memcpy(hp + o_qn, qn, (size_t)BH * 4);
+    memcpy(hp + o_nnz, nnz, (size_t)BH * 4);
+    int32_t* offs = reinterpret_cast<int32_t*>(hp + o_offs);
+    size_t total = 0;
+    for (int i = 0; i < BH; ++i) {
+        offs[i] = (int32_t)total;
+        int64_t z = nnz[i];
+        z = z < 0 ? 0 : (z > h->M ? h->M : z);
+        total += dense ? 0 : (size_t)z;
     }
-    if (!dense && rc == MP_OK) rc = stage_in(qn, (size_t)BH * 4, mem, dqn, &qnd);
-    if (!dense && rc == MP_OK) {
-        // only the first nnz[h] entries of each row are meaningful: stage just those
-        MP_HIP_CHECK(dind.alloc((size_t)BH * h->M * 4));
-        for (int i = 0; i < BH; ++i) {
-            int64_t z = nnz[i];
-            if (z > h->M) z = h->M;
-            if (z > 0)
-                MP_HIP_CHECK(hipMemcpy(dind.as<int32_t>() + (size_t)i * h->M, ind + (size_t)i * h->M,
-                                       (size_t)z * 4, hipMemcpyHostToDevice));
+    offs[BH] = (int32_t)total;
+    MP_REQUIRE(total <= (size_t)INT32_MAX, MP_ERR_UNSUPPORTED, std::string(who) + ": more than 2^31 index entries in one call");
+    MP_HIP_CHECK(hipMemcpyAsync(dp, hp, o_out, hipMemcpyHostToDevice, st));
+    MP_HIP_CHECK(hipMemcpyAsync(h->last_nnz, dp + o_nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));   // outlives the call (get_score)
+    const int32_t* indd = nullptr;
+    if (!dense) {
+        if (h->ind_rows == nullptr) MP_HIP_CHECK(hipMalloc((void**)&h->ind_rows, (size_t)BH * h->M * 4));
+        if (total > 0) {
+            rc = h->big.reserve(total * 4);
+            if (rc) return rc;
+            int32_t* packed = reinterpret_cast<int32_t*>(h->big.hp);
+            for (int i = 0; i < BH; ++i)
+                if (offs[i + 1] > offs[i])
+                    memcpy(packed + offs[i], ind + (size_t)i * h->M, (size_t)(offs[i + 1] - offs[i]) * 4);
+            MP_HIP_CHECK(hipMemcpyAsync(h->big.dp, h->big.hp, total * 4, hipMemcpyHostToDevice, st));
+            MP_HIP_CHECK(launch_ragged_copy(false, h->ind_rows, reinterpret_cast<int32_t*>(h->big.dp),
+                                            reinterpret_cast<const int32_t*>(dp + o_offs), BH, h->M, st));
         }
-        indd = dind.p;
+        indd = h->ind_rows;
     }
+    rc = attn_run(h, layer_id, dense, K, L, reinterpret_cast<uint16_t*>(dp + o_out), reinterpret_cast<float*>(dp + o_mve),
+                  dp + o_q, query_dtype, reinterpret_cast<const float*>(dp + o_qn), indd, h->last_nnz, st);
     if (rc) return rc;
-    rc = attn_run(h, layer_id, dense, K, L, dout.as<uint16_t>(), dmve.as<float>(), qd, query_dtype,
-                  (const float*)qnd, (const int32_t*)indd, (const int32_t*)nnzd, st);
-    if (rc) return rc;
+    MP_HIP_CHECK(hipMemcpyAsync(hp + o_out, dp + o_out, o_end - o_out, hipMemcpyDeviceToHost, st));
     MP_HIP_CHECK(hipStreamSynchronize(st));
-    MP_HIP_CHECK(hipMemcpy(output, dout.p, (size_t)BH * h->D * 2, hipMemcpyDeviceToHost));
-    MP_HIP_CHECK(hipMemcpy(mve, dmve.p, (size_t)2 * BH * 4, hipMemcpyDeviceToHost));
+    memcpy(output, hp + o_out, (size_t)BH * h->D * 2);
+    memcpy(mve, hp + o_mve, (size_t)2 * BH * 4);
     return MP_OK;
 }
 

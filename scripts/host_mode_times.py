@@ -1,0 +1,70 @@
+"""Cost of the host-buffer compatibility mode at a BASELINE config shape: the decode lines of the UNCHANGED
+models/attnserver.py:264-308 (q hash on the GPU, codes + query copied to pinned CPU tensors, batch_retrieve and
+attention_wrapper on CPU tensors, output + LSE copied back) against the device-resident entries, per layer.
+usage: python scripts/host_mode_times.py [cfg1|cfg2|...] [reps]"""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import magicpig_amd as mp
+from bench import CONFIGS
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg1"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+cfg = CONFIGS[name]
+B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
+dev = torch.device("cuda:0")
+BH = B * H
+server = mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=Lt, batch_size=B, max_length=M, dense_layers=(), device="cuda:0")
+for b in range(B):
+    gen = torch.Generator(device=dev).manual_seed(b)
+    kc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
+    vc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
+    server.fill(0, b, kc, vc, P); server.build_table(0, b, P)
+qs = torch.randn((reps + 5, B, H, 1, D), device=dev).to(torch.bfloat16)
+# pinned CPU tensors of the reference (attnserver.py:59-66)
+pin = lambda *shape, dtype: torch.zeros(shape, dtype=dtype).pin_memory()
+pinned_hashcode, pinned_query = pin(BH, Lt, dtype=torch.int32), pin(BH, D, dtype=torch.bfloat16)
+results, nnz = pin(BH, M, dtype=torch.int32), pin(BH, dtype=torch.int32)
+output, mve = pin(BH, D, dtype=torch.bfloat16), pin(2, BH, dtype=torch.float32)
+out_cuda, lse_cuda = torch.zeros((BH, D), dtype=torch.bfloat16, device=dev), torch.zeros((BH,), device=dev)
+lsh, srv, hasher = server.lsh_retriever, server.attn_server, server.hasher
+
+def host_layer(q):
+    codes, _ = hasher.query(q.reshape(BH, D))                       # :264-270 on the GPU
+    pinned_hashcode.copy_(codes)                                    # :272
+    pinned_query.copy_(q.reshape(BH, D))                            # :273
+    lsh.batch_retrieve(0, pinned_hashcode, results, nnz)            # :299
+    srv.attention_wrapper(0, K, Lt, output, mve, pinned_query, pinned_query.float().norm(p=2, dim=-1), results, nnz)   # :300
+    lse_cuda.copy_(mve[1], non_blocking=True)                       # :302-303
+    out_cuda.copy_(output, non_blocking=True)
+    torch.cuda.synchronize()
+
+d_res = torch.zeros((BH, M), dtype=torch.int32, device=dev)
+d_nnz = torch.zeros((BH,), dtype=torch.int32, device=dev)
+d_out = torch.zeros((BH, D), dtype=torch.bfloat16, device=dev)
+d_mve = torch.zeros((2, BH), dtype=torch.float32, device=dev)
+
+def device_three_call(q):
+    codes, qn = hasher.query(q.reshape(BH, D))
+    lsh.batch_retrieve(0, codes, d_res, d_nnz)
+    srv.attention_wrapper(0, K, Lt, d_out, d_mve, q.reshape(BH, D), qn, d_res, d_nnz)
+    torch.cuda.synchronize()
+
+def device_one_launch(q):
+    server.decode(q, 0)
+    torch.cuda.synchronize()
+
+for fn, label in ((host_layer, "host buffers (unchanged attnserver.py decode lines)"),
+                  (device_three_call, "device buffers, three calls"),
+                  (device_one_launch, "device buffers, mp_decode_sparse_layer")):
+    for i in range(5):
+        fn(qs[i])
+    t0 = time.perf_counter()
+    for i in range(reps):
+        fn(qs[5 + i])
+    dt = (time.perf_counter() - t0) / reps * 1e6
+    print(f"{label:58s} {dt:9.1f} us per layer (eager, synchronised after every layer)")
+host_layer(qs[0]); a = out_cuda.clone(); device_three_call(qs[0])
+# (the host path takes ||q|| from torch's CPU norm, attnserver.py:300: f32 sums in another order than the kernel's)
+print("max |host - device| output:", float((a.float() - d_out.float()).abs().max()), " nnz equal:", torch.equal(nnz.cuda(), d_nnz))
