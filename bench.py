@@ -46,9 +46,12 @@ CONFIGS = {
     # per-GPU share of cfg 3 (B=64 over 8 GPUs) -- the N-GPU weak-scaling unit
     "cfg3": dict(model="Llama-3.1-8B", layers=32, dense=(0, 16), H=32, Hkv=8, D=128, B=8, P=32768,
                  M=32960, K=10, L=150),
-    # per-GPU share of cfg 4 (70B TP=8: 1 kv head + 8 q heads per GPU)
+    # cfg 4 (Llama-3.1-70B, H = 64, Hkv = 8, TP = 8).  Default (--shard batch): the per-GPU share of the TP = 8
+    # layout, 1 kv head + 8 query heads, as an independent replica per rank.  --shard head: the WHOLE model's heads
+    # are partitioned over the ranks (sharding.partition(mode="head"): Hkv_full // world kv heads each, exactly
+    # attnserver_dist.py:252-254) -- total work fixed, strong scaling, outputs all_gathered for a checksum.
     "cfg4": dict(model="Llama-3.1-70B/TP8-shard", layers=80, dense=(0, 16, 32, 48, 64), H=8, Hkv=1,
-                 D=128, B=1, P=131072, M=131264, K=11, L=300),
+                 D=128, B=1, P=131072, M=131264, K=11, L=300, H_full=64, Hkv_full=8),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
@@ -65,6 +68,9 @@ def parse():
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # tests: control flow on CPU / gloo
     ap.add_argument("--table-build", default="counting", choices=["sort", "counting"])
+    ap.add_argument("--shard", default="batch", choices=["batch", "head"],
+                    help="batch: every rank serves its own B requests (weak scaling); head: the kv heads of the "
+                         "whole model are partitioned over the ranks like the reference's TP variant (strong scaling)")
     ap.add_argument("--two-launch", action="store_true",
                     help="A/B: the decode entry as (hash + retrieve) then attention instead of one launch")
     ap.add_argument("--end-to-end", action="store_true",
@@ -253,11 +259,21 @@ def dry_run(args, rank, world):
         time.sleep(0.001 * (1 + rank))          # ranks differ: the slowest one sets the time
     sync_all()
     dt = sharding.max_over_ranks(time.perf_counter() - t0)
+    line = {"metric": "dry-run", "value": world * cfg["B"] * args.steps / dt, "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "planes_checksum": int(hash_func.view(torch.int16).to(torch.int64).sum())}
+    if args.shard == "head":
+        # the head-sharded layout of main(): partition -> (stand-in outputs: element = global head index) ->
+        # all_gather at the edge -> the same checksum on every rank
+        H_full, Hkv_full, B, D = cfg.get("H_full", cfg["H"]), cfg.get("Hkv_full", cfg["Hkv"]), cfg["B"], cfg["D"]
+        shard = sharding.partition(B, H_full, Hkv_full, world, rank, mode="head")
+        local = torch.tensor(list(shard.heads), dtype=torch.float32).view(1, -1, 1).expand(B, -1, D).to(torch.bfloat16)
+        full = sharding.gather_outputs(local.contiguous(), shard, B, H_full)
+        line.update({"value": B * args.steps / dt, "scaling": "strong", "heads_per_rank": shard.local_heads,
+                     "gathered_shape": list(full.shape), "gathered_checksum": float(full.float().sum())})
     if rank == 0:
-        print(json.dumps({"metric": "dry-run", "value": world * cfg["B"] * args.steps / dt, "unit": "tokens/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "planes_checksum": int(hash_func.view(torch.int16).to(torch.int64).sum())}))
+        print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -294,6 +310,13 @@ def main():
     if args.end_to_end:
         return end_to_end(args, cfg, rank, world, dev, dist)
     B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
+    shard = None
+    if args.shard == "head":
+        # the model's heads over the ranks (evaluations/RULER/pred/attnserver_dist.py:252-254): rank r owns kv heads
+        # [r * Hkv_full / world, ...) and their query heads; nothing is exchanged inside the path
+        H_full, Hkv_full = cfg.get("H_full", H), cfg.get("Hkv_full", Hkv)
+        shard = sharding.partition(B, H_full, Hkv_full, world, rank, mode="head")
+        H, Hkv = shard.local_heads, shard.local_kv_heads
     sparse_layers = [i for i in range(cfg["layers"]) if i not in cfg["dense"]]
     NL = len(sparse_layers)
     BH = B * H
@@ -378,8 +401,21 @@ def main():
     dt = time.perf_counter() - t0
     dt = sharding.max_over_ranks(dt, device=dev)
     ms_per_step = dt / args.steps * 1e3
-    tokens_per_s = world * B * args.steps / dt
+    # batch sharding: every rank decodes its own B requests; head sharding: all ranks share the same B requests
+    tokens_per_s = (B if shard is not None else world * B) * args.steps / dt
     us_per_layer = ms_per_step * 1e3 / NL
+    gathered = None
+    if shard is not None:
+        # the edge of the path (outside the timed region): every rank's [B, H_loc, D] outputs of the last layer
+        # all_gathered through RCCL into [B, H_full, D]; the checksum is the same on every rank
+        q_static.copy_(qs[0])
+        o_loc, _ = server.decode(q_static[NL - 1], NL - 1)
+        torch.cuda.synchronize()
+        t_g = time.perf_counter()
+        full = sharding.gather_outputs(o_loc.clone(), shard, B, cfg.get("H_full", H))
+        torch.cuda.synchronize()
+        gathered = {"allgather_us": (time.perf_counter() - t_g) * 1e6, "shape": list(full.shape),
+                    "checksum": int(full.view(torch.int16).to(torch.int64).sum().item())}
 
     # ---- roofline leg.  A sparse layer is ONE launch (lsh_decode_kernel: hash -> retrieve -> attention),
     # so the dominant kernel is the step itself: its average duration is taken from HIP events recorded
@@ -410,14 +446,18 @@ def main():
                         + 2 * D + 8) + 2 * D * K * Lt + BH * (2 * D + 4 * Lt)
     achieved = bytes_layer / (k_us * 1e-6) / 1e9
     fused = not args.two_launch
-    traffic = None
+    # HBM traffic per launch cannot be counted from inside this process (the PMC counters need rocprofv3 around
+    # it): the line carries the figure of the last committed PMC passes over this same command and says so
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and shard is None:
         try:
             with open(tpath) as f:
                 tj = json.load(f)
             key = "lsh_decode_bytes_per_launch" if fused else "two_launch_bytes_per_layer"
             traffic = (tj.get(key) or {}).get(args.config)
+            if traffic is not None:
+                traffic_source = "not measured in this run: rocprofv3 PMC passes of " + str(tj.get("source", "profiles/"))
         except Exception:
             traffic = None
 
@@ -426,10 +466,13 @@ def main():
                   f" P={P} K{K}L{Lt}",
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "strong" if shard is not None else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.config}: {cfg['model']} B={B} P={P} K={K} L={Lt}, "
                                f"{NL} sparse layers/step, H={H} Hkv={Hkv} D={D}, KV+tables resident in HBM",
-                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world} (requests sharded)",
+                   "batch_per_gpu": B, "global_batch": B if shard is not None else B * world,
+                   "parallelism": (f"tp{world} (kv heads sharded: {Hkv} of {cfg.get('Hkv_full', Hkv)} kv heads, "
+                                   f"{H} of {cfg.get('H_full', H)} query heads per GPU)") if shard is not None
+                                  else f"dp{world} (requests sharded)",
                    "launch": "eager" if graph is None else "hipGraph"},
         "sparse_attn_us_per_layer": us_per_layer,
         "observed": {"nnz_per_head": nnz_mean, "candidates_per_head": cand_mean,
@@ -437,9 +480,11 @@ def main():
         "roofline": {"bound": "hbm",
                      "kernel": "lsh_decode_kernel" if fused else "lsh_retrieve_kernel + attn_sparse_kernel",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "bytes_per_launch": bytes_layer, "avg_launch_us": k_us,
-                     "launches_timed": n_timed},
+                     "traffic": traffic, "traffic_source": traffic_source, "bytes_per_launch": bytes_layer,
+                     "avg_launch_us": k_us, "launches_timed": n_timed},
     }
+    if gathered is not None:
+        out["head_shard_gather"] = gathered
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

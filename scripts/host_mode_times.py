@@ -6,6 +6,9 @@ import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import magicpig_amd._lib as L
+if os.environ.get("MP_LIB"):            # A/B builds of the library (this script only; the product reads no environment)
+    L.LIB_PATH = os.path.abspath(os.environ["MP_LIB"])
 import magicpig_amd as mp
 from bench import CONFIGS
 

@@ -134,3 +134,29 @@ def test_bench_launch_contract_two_ranks_dry_run():
     assert single.returncode == 0, single.stderr[-2000:]
     d1 = json.loads([ln for ln in single.stdout.splitlines() if ln.startswith("{")][0])
     assert d1["n_gpus"] == 1 and d1["planes_checksum"] == d["planes_checksum"]   # rank 0's planes everywhere
+
+
+def test_bench_head_shard_two_ranks_dry_run():
+    """bench.py --shard head under torch.distributed.run with 2 ranks (gloo, --dry-run): the kv heads of the whole
+    model (cfg 4: H = 64, Hkv = 8) are partitioned as evaluations/RULER/pred/attnserver_dist.py:252-254 does, each
+    rank's outputs are all_gathered at the edge, and the gathered tensor holds every head exactly once."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run", "--config", "cfg4", "--shard", "head"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["heads_per_rank"] == 32 and d["gathered_shape"] == [1, 64, 128]
+    assert d["gathered_checksum"] == float(sum(range(64)) * 128)          # every global head once, in place
