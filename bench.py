@@ -144,11 +144,10 @@ def cpu_worker(path: str) -> None:
     print("CPU_BASELINE_JSON " + json.dumps(res))
 
 
-def run_cpu_baseline(cfg, server, qs, steps):
-    """Dump the first sparse layer (tables, KV, queries) and time the CPU path on it."""
-    import magicpig_amd._lib as L
-
-    B, H, Hkv, D, M, K, Lt = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L"))
+def run_cpu_baseline(cfg, server, qs, steps, H, Hkv):
+    """Dump the first sparse layer (tables, KV, queries) and time the CPU path on it.  H, Hkv: the heads this
+    process actually serves (cfg's, or the head shard's)."""
+    B, D, M, K, Lt = (cfg[k] for k in ("B", "D", "M", "K", "L"))
     n = cfg["P"] - 68
     layer = 0
     bounds, table = server.lsh_retriever.get_tables(layer)
@@ -488,7 +487,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cb = run_cpu_baseline(cfg, server, qs, args.cpu_steps)
+            cb = run_cpu_baseline(cfg, server, qs, args.cpu_steps, H, Hkv)
             t_layer = cb["t_retrieve_us"] + cb["t_attention_us"]
             out["cpu_baseline"] = {
                 "value": B / (NL * t_layer * 1e-6), "unit": "tokens/s", "cores": cb["cores"],
