@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--shard", default="batch", choices=["batch", "head"],
                     help="batch: every rank serves its own B requests (weak scaling); head: the kv heads of the "
                          "whole model are partitioned over the ranks like the reference's TP variant (strong scaling)")
+    ap.add_argument("--mfma-hash", action="store_true",
+                    help="A/B: query SimHash by the MFMA kernel as its own launch, then the decode kernel")
     ap.add_argument("--two-launch", action="store_true",
                     help="A/B: the decode entry as (hash + retrieve) then attention instead of one launch")
     ap.add_argument("--end-to-end", action="store_true",
@@ -306,6 +308,8 @@ def main():
     cfg = CONFIGS[args.config]
     if args.two_launch:
         L.set_option("decode_two_launch", 1)
+    if args.mfma_hash:
+        L.set_option("decode_mfma_hash", 1)
     if args.end_to_end:
         return end_to_end(args, cfg, rank, world, dev, dist)
     B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))

@@ -28,7 +28,7 @@ hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, co
                              int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
                              float*, float2*, int*, int*, uint16_t*, float*, float2*, const int32_t*, float*, int*,
                              int, int, bool, const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t,
-                             hipStream_t);
+                             bool, hipStream_t);
 hipError_t set_stamp_stride(int);
 hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
@@ -81,6 +81,7 @@ struct DebugOptions {
     std::atomic<int> decode_two_launch{0};   // 1: hash+retrieve launch, then attention launch
     std::atomic<int> decode_cluster{0};      // 0 = auto, else workgroups per head (clamped to [1, min(8, slices)])
     std::atomic<int> decode_agent_scope{0};  // 1: cluster hand-off through memory even when the XCD placement was observed
+    std::atomic<int> decode_mfma_hash{0};    // 1: query SimHash by the MFMA kernel in a launch of its own, then the decode
     std::atomic<int> decode_direct{-1};      // -1 = auto, 0 = never, 1 = always (when R > 1) keep direct piece slots
     std::atomic<int> attn_head_kernel{-1};   // -1 = auto, 0 = split-KV kernel, 1 = one workgroup per head
     std::atomic<int> attn_gx{0};             // 0 = auto, else split-KV workgroups per head
@@ -94,6 +95,7 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "decode_cluster")) return &g_opt.decode_cluster;
     if (!strcmp(name, "decode_agent_scope")) return &g_opt.decode_agent_scope;
     if (!strcmp(name, "decode_direct")) return &g_opt.decode_direct;
+    if (!strcmp(name, "decode_mfma_hash")) return &g_opt.decode_mfma_hash;
     if (!strcmp(name, "attn_head_kernel")) return &g_opt.attn_head_kernel;
     if (!strcmp(name, "attn_gx")) return &g_opt.attn_gx;
     if (!strcmp(name, "attn_dense_grouped")) return &g_opt.attn_dense_grouped;
@@ -1057,6 +1059,11 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         // a-1 .. a-12 (models/attnserver.py:264-300) in ONE launch: hash -> retrieve -> attention of a
         // head inside a cluster of lsh->R workgroups, each owning one token range of the head's tables;
         // the selected ids stay in LDS.
+        // A/B (north_star names MFMA for the query projection): the hash as simhash_query_kernel's own launch
+        const bool mfma_hash = win == nullptr && g_opt.decode_mfma_hash.load() != 0;
+        if (mfma_hash)
+            MP_HIP_CHECK(launch_simhash_query(q, s->Wt, s->wnorm, BH, s->D, s->K, s->L, lsh->codes, lsh->qnorm,
+                                              nullptr, st));
         MP_HIP_CHECK(launch_lsh_decode(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk, s->wnorm, s->D,
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
@@ -1064,7 +1071,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
                                        lsh->slots.empty() ? nullptr : lsh->slots[layer_id], attn->score, attn->err, attn_slices_per_head(attn->M), lsh->R,
                                        attn->xcd_rr && g_opt.decode_agent_scope.load() == 0,
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
-                                       lsh->L, lsh->NB, lsh->M, st));
+                                       lsh->L, lsh->NB, lsh->M, mfma_hash, st));
         attn->lastz = lsh->nnz;
         attn->score_state = 1;
         attn->seg_cnt = lsh->R > 1 ? lsh->part_cnt : nullptr;

@@ -420,7 +420,10 @@ struct AttnArgs {
     int64_t win_M;
 };
 
-template <bool HASH, int CH, int AD, bool WIN>   // CH = min(16, D / 8): plane chunks kept in registers (HASH only);
+// HASH: 0 = the codes are given (`query`), 1 = fused SimHash prologue, 2 = (decode only) codes + ||q|| were written
+// to ha.codes_out / ha.qnorm_out by simhash_query_kernel (the MFMA kernel) in a launch of its own: the A/B
+// variant of the decode entry behind the decode_mfma_hash option.
+template <int HASH, int CH, int AD, bool WIN>    // CH = min(16, D / 8): plane chunks kept in registers (HASH only);
                                                  // WIN: fold the static window in (its own instantiation, so the
                                                  // plain decode kernel carries none of its code)
 __device__ __forceinline__ void lsh_head_body(
@@ -471,7 +474,16 @@ __device__ __forceinline__ void lsh_head_body(
     // collision bitmaps and piece lengths start at zero: done here, under the query row's round trip
     for (int i = tid; i < 2 * words; i += RT_THREADS) s_u32[i] = 0u;
     for (int l = tid; l < Lpad; l += RT_THREADS) s_len[l] = 0;
-    if (HASH) {
+    if (HASH == 2) {   // the hash ran as its own launch: only the raw query row (for q.k) and ||q|| are fetched here
+        const int per = ha.D >> 6;
+        if (wave == 0) {
+            const uint16_t* src = ha.q + h * ha.D + lane * per;
+            uint16_t* raw = reinterpret_cast<uint16_t*>(s_qraw) + lane * per;
+            for (int i = 0; i < per; ++i) raw[i] = src[i];
+            if (lane == 0) s_rn[1] = ha.qnorm_out[h];
+        }
+    }
+    if (HASH == 1) {
         const int D = ha.D, KL = ha.K * L;
         const int chunks = D >> 3;                              // 16-byte plane chunks per hyperplane
         const u32x4* Wk4 = reinterpret_cast<const u32x4*>(ha.Wk);
@@ -591,14 +603,15 @@ __device__ __forceinline__ void lsh_head_body(
             if (old & bit) atomicOr(&bmB[u >> 5], bit);                 // any later hit: -> 2
         }
     };
-    auto code_of = [&](int l) {   // HASH: bit i of code l <- plane l*K + i
+    auto code_of = [&](int l) {   // HASH 1: bit i of code l <- plane l*K + i
+        if (HASH == 2) return (int)ha.codes_out[h * L + l];
         const int bp = l * ha.K, w = bp >> 5, sh = bp & 31;
         uint32_t v = s_bits[w] >> sh;
         if (sh + ha.K > 32) v |= s_bits[w + 1] << (32 - sh);
         return (int)(v & ((1u << ha.K) - 1u));
     };
     const int32_t* slots = (AD > 0) ? aa.slots : nullptr;
-    if (AD > 0 && HASH && slots != nullptr) {
+    if (AD > 0 && HASH != 0 && slots != nullptr) {
         // ---- DIRECT pieces: the piece (table l, bucket code, range rank) has a 128-byte slot holding its length
         // and its first 31 ids, so ONE dependent round trip (hash -> slot) replaces two (hash -> sub-bounds ->
         // ids).  Half a wave reads a slot; a wave keeps DG loads = 2 DG pieces in flight.  Pieces longer than 31
@@ -616,7 +629,7 @@ __device__ __forceinline__ void lsh_head_body(
                 const int lc = l < L ? l : L - 1;                       // loads stay unconditional
                 cd[b] = code_of(lc);
                 v[b] = sg[((int64_t)lc * NB + cd[b]) * R * 32 + sl];
-                if (lead && sl == 0 && l < L) ha.codes_out[h * L + l] = cd[b];
+                if (HASH == 1 && lead && sl == 0 && l < L) ha.codes_out[h * L + l] = cd[b];
             }
 #pragma unroll
             for (int b = 0; b < DG; ++b) {
@@ -661,9 +674,9 @@ __device__ __forceinline__ void lsh_head_body(
         int st = 0, len = 0;
         if (l < L) {
             int code;
-            if (HASH) {
+            if (HASH != 0) {
                 code = code_of(l);
-                if (lead) ha.codes_out[h * L + l] = code;
+                if (HASH == 1 && lead) ha.codes_out[h * L + l] = code;
             } else {
                 code = query[h * L + l];
             }
@@ -953,7 +966,7 @@ __device__ __forceinline__ void lsh_head_body(
 }
 
 // LSH::batch_retrieve (optionally with the query hash as its prologue)
-template <bool HASH, int CH>
+template <int HASH, int CH>
 __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
     const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
@@ -964,13 +977,13 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
 }
 
 // the whole sparse layer of models/attnserver.py:264-300: hash -> retrieve -> attention
-template <int CH, int AD, bool WIN>
+template <int CH, int AD, bool WIN, int HASH = 1>
 __global__ __launch_bounds__(RT_THREADS) void lsh_decode_kernel(
     const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     int32_t* __restrict__ results, int32_t* __restrict__ nnz,
     int G, int L, int NB, int64_t M, int R, int range_len, int words, int Lpad, HashArgs ha, AttnArgs aa,
     unsigned long long* __restrict__ stamp) {
-    lsh_head_body<true, CH, AD, WIN>(bounds, table, nullptr, results, nnz, G, L, NB, M, R, range_len, words, Lpad,
+    lsh_head_body<HASH, CH, AD, WIN>(bounds, table, nullptr, results, nnz, G, L, NB, M, R, range_len, words, Lpad,
                                      ha, aa, stamp);
 }
 
@@ -1200,9 +1213,11 @@ static size_t decode_lds_bytes(int64_t tokens, int L, int D) {
 }
 
 static hipError_t retrieve_attr_set() {
-    const void* fns[] = {reinterpret_cast<const void*>(lsh_retrieve_kernel<false, 16>),
-                         reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 16>),
-                         reinterpret_cast<const void*>(lsh_retrieve_kernel<true, 8>),
+    const void* fns[] = {reinterpret_cast<const void*>(lsh_retrieve_kernel<0, 16>),
+                         reinterpret_cast<const void*>(lsh_retrieve_kernel<1, 16>),
+                         reinterpret_cast<const void*>(lsh_retrieve_kernel<1, 8>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, false, 2>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, false, 2>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, false>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, false>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, true>),
@@ -1227,7 +1242,7 @@ hipError_t launch_lsh_retrieve(const int32_t* bounds, const int32_t* table, cons
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
     HashArgs ha = {};
-    hipLaunchKernelGGL((lsh_retrieve_kernel<false, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+    hipLaunchKernelGGL((lsh_retrieve_kernel<0, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                        st, bounds, table, query, results, nnz, G, L, NB, M, R, words, Lpad, ha, g_stamp);
     return hipGetLastError();
 }
@@ -1245,11 +1260,11 @@ hipError_t launch_lsh_hash_retrieve(const int32_t* bounds, const int32_t* table,
     if (e != hipSuccess) return e;
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
     if (D >= 128)
-        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+        hipLaunchKernelGGL((lsh_retrieve_kernel<1, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, R, words,
                            Lpad, ha, g_stamp);
     else
-        hipLaunchKernelGGL((lsh_retrieve_kernel<true, 8>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
+        hipLaunchKernelGGL((lsh_retrieve_kernel<1, 8>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, R, words,
                            Lpad, ha, g_stamp);
     return hipGetLastError();
@@ -1268,7 +1283,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                              int* head_cnt, uint16_t* out, float* mve, float2* head_mz, const int32_t* slots,
                              float* score, int* err, int maxs, int R, bool same_xcd, const uint16_t* win_kv,
                              const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
-                             hipStream_t st) {
+                             bool codes_given, hipStream_t st) {
     const int range_len = lsh_range_len(M, R);
     const int words = range_len / 32;
     const int Lpad = (L + 63) & ~63;
@@ -1284,6 +1299,16 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                    DECODE_ID_CAP, clog, sx ? 1 : 0, xmap, win_kv, win_len, win_M};
     const dim3 grid((unsigned)BH << clog);
     const size_t lds = decode_lds_bytes(range_len, L, D);
+    if (codes_given) {   // A/B: the codes and ||q|| come from simhash_query_kernel (plain decode only)
+        if (win_kv != nullptr) return hipErrorInvalidValue;
+        if (D == 128)
+            hipLaunchKernelGGL((lsh_decode_kernel<16, 128, false, 2>), grid, dim3(RT_THREADS), lds, st, bounds, table,
+                               results, nnz, G, L, NB, M, R, range_len, words, Lpad, ha, aa, g_stamp);
+        else
+            hipLaunchKernelGGL((lsh_decode_kernel<8, 64, false, 2>), grid, dim3(RT_THREADS), lds, st, bounds, table,
+                               results, nnz, G, L, NB, M, R, range_len, words, Lpad, ha, aa, g_stamp);
+        return hipGetLastError();
+    }
 #define MP_DECODE_CASE(DD, CHH, WW)                                                                         \
     if (D == DD && (win_kv != nullptr) == WW) {                                                             \
         hipLaunchKernelGGL((lsh_decode_kernel<CHH, DD, WW>), grid, dim3(RT_THREADS), lds, st, bounds, table, \

@@ -718,6 +718,31 @@ def test_fused_decode_direct_slots_and_overflow(mp, K, L, n, M, direct):
             assert np.allclose(probs1[h, :z].cpu().numpy(), probs2[h, :z].cpu().numpy(), rtol=2e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize("B,H,Hkv,D", [(1, 32, 8, 128), (8, 32, 8, 128), (2, 6, 3, 64)])
+def test_decode_with_mfma_hash_launch_equals_fused_hash(mp, B, H, Hkv, D):
+    """The decode entry with the query SimHash computed by the MFMA kernel in a launch of its own
+    (decode_mfma_hash option: the A/B variant north_star's "the projection uses MFMA" asks about) against the
+    default, where the hash is the decode kernel's prologue: same codes, nnz, ids -> bit-identical outputs."""
+    import magicpig_amd._lib as L_
+
+    n, M, K, L = 5000, 5120, 9, 40
+    server, _ = _fused_server(mp, B, H, Hkv, n, M, D, K, L, 555)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    for it in range(3):
+        q = torch.randn((B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16)
+        out, lse = server.decode(q, 0)
+        o1, l1, z1 = out.clone(), lse.clone(), server.nnz.clone()
+        m1 = server.lsh_retriever.get_mask().clone()
+        L_.set_option("decode_mfma_hash", 1)
+        try:
+            out2, lse2 = server.decode(q, 0)
+            torch.cuda.synchronize()
+        finally:
+            L_.set_option("decode_mfma_hash", 0)
+        assert torch.equal(server.nnz, z1) and torch.equal(out2, o1) and torch.equal(lse2, l1)
+        assert torch.equal(server.lsh_retriever.get_mask(), m1)        # recomputed from the codes each variant wrote
+
+
 def test_cfg1_shaped_fused_decode_properties(mp):
     """BASELINE cfg 1 shape (B=1, H=32, Hkv=8, n=97 932, M=98 304, K=10, L=150), one layer, through
     size-independent properties: (1) the one-launch entry equals hash -> batch_retrieve ->
