@@ -521,8 +521,9 @@ __device__ __forceinline__ void lsh_head_body(
                 const double v = (double)bf16_bits_to_f32(e[i]);
                 ss += v * v;                                   // exact, order-free
             }
+            MP_STAMP(stamp, 28);                               // the query row has arrived
             ss = wave_sum(ss);
-            const float nrm = (float)sqrt((double)(float)ss);
+            const float nrm = (float)sqrt((double)(float)ss);   // (__fsqrt_rn measured no faster here, and not bit-identical)
             const float nb = bf16_bits_to_f32(f32_to_bf16_rne(nrm));
             if (lane == 0 && lead && ha.qnorm_out != nullptr) ha.qnorm_out[h] = nrm;
             uint16_t* dst = reinterpret_cast<uint16_t*>(s_q) + lane * per;
@@ -538,6 +539,7 @@ __device__ __forceinline__ void lsh_head_body(
                 s_rn[0] = (nrm / nb) * 1.005f;
                 s_rn[1] = nrm;
             }
+            MP_STAMP(stamp, 29);                               // normalised row written to LDS
         }
         __syncthreads();
         MP_STAMP(stamp, 22);

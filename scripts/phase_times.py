@@ -45,7 +45,7 @@ def seg(name, slots):
     print(f"{name}: total {np.median(t[:, -1] - t[:, 0]):.2f} us; phases " + ", ".join(f"{x:.2f}" for x in np.median(d, axis=0)))
 seg("simhash  [start|planes+rows staged|mfma+guard|pack]", [0, 1, 2, 3])
 seg("retrieve [start|probe+zero|chunk table|ids+atomics|scan|emit]", [16, 17, 18, 19, 20, 21])
-seg("  fused hash prologue [start|normalised|pass0|pass1|barrier|probe+zero]", [16, 22, 23, 24, 27, 17])
+seg("  fused hash prologue [start|q arrived|row normalised|barrier|pass0|pass1|barrier|pieces in]", [16, 28, 29, 22, 23, 24, 27, 17])
 seg("partial  [start|prefix|gathers issued|qk+reduce|transform|pv|combine]", [32, 33, 34, 35, 36, 37, 38])
 print("kernel-to-kernel (WG0 start to WG0 start): simhash->retrieve %.2f, retrieve->partial %.2f us" % (
     np.median(a[:, 16] - a[:, 0]), np.median(a[:, 32] - a[:, 16])))
