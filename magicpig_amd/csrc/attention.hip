@@ -641,14 +641,15 @@ __global__ __launch_bounds__(256) void key_colsum_kernel(const uint16_t* __restr
         for (int i = 0; i < 4; ++i) partial[(int64_t)blockIdx.x * cols + cb + i] = acc[i];
     }
 }
-// pass 1b: avg[c] = bf16(float(sum_b partial[b][c] / n))
-__global__ void key_colmean_kernel(const double* __restrict__ partial, int nblk, int cols, int64_t n,
-                                   uint16_t* __restrict__ avg) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// pass 1b: avg[c] = bf16(float(sum_b partial[b][c] / n)); one wave per column (f64 adds of exact values: order-free)
+__global__ __launch_bounds__(256) void key_colmean_kernel(const double* __restrict__ partial, int nblk, int cols,
+                                                          int64_t n, uint16_t* __restrict__ avg) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= cols) return;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * cols + c];
-    avg[c] = f32_to_bf16_rne((float)(s / (double)n));
+    for (int b = lane; b < nblk; b += 64) s += partial[(int64_t)b * cols + c];
+    s = wave_sum(s);
+    if (lane == 0) avg[c] = f32_to_bf16_rne((float)(s / (double)n));
 }
 // pass 2: row t of kv head g of the store <- (bf16(k - avg) | v), kn <- norm; one thread per 16 bytes of a row
 __global__ __launch_bounds__(256) void key_centre_fill_kernel(
@@ -898,7 +899,7 @@ hipError_t launch_key_centre_fill(const uint16_t* key_cache, const uint16_t* val
                                   float* kn, hipStream_t st) {
     const int cols = Hkv * D;
     hipLaunchKernelGGL(key_colsum_kernel, dim3(nblk), dim3(256), 0, st, key_cache, t0, n, cols, partial);
-    hipLaunchKernelGGL(key_colmean_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, partial, nblk, cols, n, avg);
+    hipLaunchKernelGGL(key_colmean_kernel, dim3((cols + 3) / 4), dim3(256), 0, st, partial, nblk, cols, n, avg);
     int64_t blocks = (n * Hkv * (D / 8) + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     if (blocks < 1) blocks = 1;

@@ -103,27 +103,24 @@ __global__ void lsh_unsort_kernel(const int16_t* __restrict__ codes, const int32
 }
 
 // entries 1 .. R-1 of every bucket: first position of the bucket whose token id is >= r * range_len
-// (ids ascend inside a bucket).  One workgroup per (kv head, table) row, one thread per bucket, R - 1
-// binary searches each over a table row that was just written (L2 hits).
+// (ids ascend inside a bucket).  One workgroup per (kv head, table) row, one thread per (bucket, cut): a binary
+// search over a table row that was just written (L2 hits).
 __global__ __launch_bounds__(256) void lsh_subbounds_kernel(
     const int32_t* __restrict__ table, int32_t* __restrict__ bounds, int NB, int R, int range_len, int64_t M) {
     const int64_t row = blockIdx.x;
     const int RS = R + 1;
     const int32_t* t = table + row * M;
     int32_t* b = bounds + row * NB * RS;
-    for (int i = threadIdx.x; i < NB; i += blockDim.x) {
-        const int st = b[i * RS], en = b[i * RS + R];
-        int lo = st;
-        for (int r = 1; r < R; ++r) {
-            const int target = r * range_len;
-            int hi = en;                                  // first position in [lo, en) with t[p] >= target
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (t[mid] < target) lo = mid + 1;
-                else hi = mid;
-            }
-            b[i * RS + r] = lo;
+    for (int i = threadIdx.x; i < NB * (R - 1); i += blockDim.x) {
+        const int bk = i / (R - 1), r = 1 + i % (R - 1);
+        int lo = b[bk * RS], hi = b[bk * RS + R];            // first position in [start, end) with t[p] >= target
+        const int target = r * range_len;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (t[mid] < target) lo = mid + 1;
+            else hi = mid;
         }
+        b[bk * RS + r] = lo;
     }
 }
 
@@ -139,13 +136,26 @@ __global__ __launch_bounds__(256) void lsh_slots_kernel(const int32_t* __restric
     const int32_t* b = bounds + row * NB * RS;
     int32_t* s = slots + row * NB * R * 32;
     const int sl = threadIdx.x & 31;
-    for (int piece = blockIdx.x * 8 + (threadIdx.x >> 5); piece < NB * R; piece += gridDim.x * 8) {
-        const int bk = piece / R, r = piece - bk * R;
-        const int lo = b[bk * RS + r], hi = b[bk * RS + r + 1];
-        int v = 0;
-        if (sl == 0) v = hi - lo;
-        else if (sl - 1 < hi - lo) v = t[lo + sl - 1];
-        s[(int64_t)piece * 32 + sl] = v;
+    constexpr int U = 4;                                 // pieces in flight per half-wave
+    const int total = NB * R;
+    for (int p0 = (blockIdx.x * 8 + (threadIdx.x >> 5)) * U; p0 < total; p0 += gridDim.x * 8 * U) {
+        int lo[U], hi[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int piece = p0 + u < total ? p0 + u : total - 1;
+            const int bk = piece / R, r = piece - bk * R;
+            lo[u] = b[bk * RS + r];
+            hi[u] = b[bk * RS + r + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = 0;
+            if (sl == 0) v[u] = hi[u] - lo[u];
+            else if (sl - 1 < hi[u] - lo[u]) v[u] = t[lo[u] + sl - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (p0 + u < total) s[(int64_t)(p0 + u) * 32 + sl] = v[u];
     }
 }
 
@@ -1082,8 +1092,8 @@ hipError_t launch_lsh_subbounds(const int32_t* table, int32_t* bounds, int rows,
 hipError_t launch_lsh_slots(const int32_t* table, const int32_t* bounds, int32_t* slots, int rows, int NB, int R,
                             int64_t M, hipStream_t st) {
     if (R <= 1 || slots == nullptr) return hipSuccess;
-    int gx = (NB * R + 7) / 8;
-    if (gx > 256) gx = 256;
+    int gx = (NB * R + 31) / 32;
+    if (gx > 64) gx = 64;
     hipLaunchKernelGGL(lsh_slots_kernel, dim3(gx, rows), dim3(256), 0, st, table, bounds, slots, NB, R, M);
     return hipGetLastError();
 }
