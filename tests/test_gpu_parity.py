@@ -370,12 +370,16 @@ def test_attention_edge_cases(mp):
 
 # ------------------------------------------------------------------ the reference's own test logic
 
-@pytest.mark.parametrize("K,L,seq_len,delta,G,bsz", [(4, 50, 1024, 128, 4, 1), (8, 100, 4096, 1024, 8, 4),
-                                                     (8, 50, 8192, 128, 4, 4), (4, 100, 4096, 128, 8, 1)])
-def test_batch_retrieve_like_reference_test(mp, K, L, seq_len, delta, G, bsz):
-    """library/lsh/test.py:5-76 restated: random codes, nnz == ((codes == q).sum(L) > 1).sum(),
-    every returned index inside that mask; a second query re-checks the state reset."""
-    H = 32
+# the reference's grid, library/lsh/test.py:5-12 (192 combinations; num_layers only picks which layer is used: here
+# always 2 layers, layer 1), plus its trailing call (K = 2, L = 4, one head)
+_LSH_GRID = [(K, L, s, d, G, b, 32) for K in (4, 8) for L in (50, 100) for s in (1024, 4096, 8192)
+             for d in (128, 1024) for G in (4, 8) for b in (1, 4)] + [(2, 4, 128, 16, 1, 1, 1)]
+
+
+@pytest.mark.parametrize("K,L,seq_len,delta,G,bsz,H", _LSH_GRID)
+def test_batch_retrieve_like_reference_test(mp, K, L, seq_len, delta, G, bsz, H):
+    """library/lsh/test.py:5-76 restated over the reference's whole grid: random codes, nnz == ((codes == q).sum(L) > 1)
+    .sum(), every returned index inside that mask; a second query re-checks the state reset."""
     Hkv = H // G
     NB = 1 << K
     gen = torch.Generator().manual_seed(K * 1000 + L + seq_len + G + bsz)
@@ -399,14 +403,18 @@ def test_batch_retrieve_like_reference_test(mp, K, L, seq_len, delta, G, bsz):
             assert torch.all(ri[1:] > ri[:-1])            # ascending, hence duplicate-free
 
 
-@pytest.mark.parametrize("G,batch_size,H,D,delta", [(4, 1, 32, 128, 128), (8, 4, 64, 128, 1024),
-                                                    (4, 2, 32, 64, 128)])
-def test_sparse_attention_like_reference_test(mp, G, batch_size, H, D, delta):
-    """library/sparse_attention/test_sparse.py:6-92 / test.py:6-91 restated with the reference's
-    torch formula and its rtol = atol = 1e-2."""
+# the reference's grid, library/sparse_attention/test.py:6-14 (288 combinations; num_layers only picks the layer)
+_ATTN_GRID = [(G, b, H, D, d, s) for s in (1024, 4096, 8192) for d in (128, 1024) for G in (4, 8) for b in (1, 4)
+              for H in (32, 64) for D in (64, 128)]
+
+
+@pytest.mark.parametrize("G,batch_size,H,D,delta,seq_len", _ATTN_GRID)
+def test_sparse_attention_like_reference_test(mp, G, batch_size, H, D, delta, seq_len):
+    """library/sparse_attention/test_sparse.py:6-92 / test.py:6-91 restated over the reference's whole grid (f32 and
+    bf16 queries alternate) with the reference's torch formula and its rtol = atol = 1e-2."""
     import math
 
-    K, L, seq_len = 10, 150, 8192
+    K, L = 10, 150
     M = seq_len + delta
     Hkv = H // G
     gen = torch.Generator().manual_seed(G * 100 + batch_size * 10 + H + D)
@@ -417,8 +425,10 @@ def test_sparse_attention_like_reference_test(mp, G, batch_size, H, D, delta):
     srv.alloc(2, H, Hkv, D, batch_size, M)
     for i in range(batch_size):
         srv.fill(1, i, key[i].contiguous(), value[i].contiguous(), key_norm[i].contiguous())
-    query = torch.randn((batch_size, H, 1, D), generator=gen).to(torch.bfloat16)
-    query_norm = query.norm(p=2, dim=-1).float()
+    query = torch.randn((batch_size, H, 1, D), generator=gen)
+    if (G + batch_size + H // 32 + D // 64 + seq_len // 1024) % 2 == 0:
+        query = query.to(torch.bfloat16)                      # attention_wrapper_bf16's query (models/attnserver.py:300)
+    query_norm = query.norm(p=2, dim=-1).float()              # else f32 as library/sparse_attention/test.py:44
     BH = batch_size * H
     nnz = torch.randint(1, seq_len, (BH,), generator=gen).int()
     ind = torch.zeros((BH, M)).int()
@@ -433,7 +443,7 @@ def test_sparse_attention_like_reference_test(mp, G, batch_size, H, D, delta):
     valr = value[:, :, None].repeat(1, 1, G, 1, 1).reshape(BH, seq_len, D).cuda().float()
     knr = key_norm[:, :, None].repeat(1, 1, G, 1).reshape(BH, seq_len).cuda()
     qf = query.reshape(BH, D).cuda().float()
-    for i in range(BH):
+    for i in range(0, BH, max(1, BH // 48)):                  # <= ~48 heads per combination checked densely
         idx = ind[i][:nnz[i]].long().cuda()
         ref = keyr[i][idx] @ qf[i]
         cs = ref / (query_norm.reshape(BH)[i].cuda() * knr[i][idx])
