@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--shard", default="batch", choices=["batch", "head"],
                     help="batch: every rank serves its own B requests (weak scaling); head: the kv heads of the "
                          "whole model are partitioned over the ranks like the reference's TP variant (strong scaling)")
+    ap.add_argument("--cluster", type=int, default=0,
+                    help="A/B: workgroups per query head of the decode kernel (1, 2, 4, 8; default: by B*H and CUs)")
+    ap.add_argument("--no-direct-slots", action="store_true", help="A/B: sub-bounds + ids instead of direct piece slots")
     ap.add_argument("--mfma-hash", action="store_true",
                     help="A/B: query SimHash by the MFMA kernel as its own launch, then the decode kernel")
     ap.add_argument("--two-launch", action="store_true",
@@ -310,6 +313,10 @@ def main():
         L.set_option("decode_two_launch", 1)
     if args.mfma_hash:
         L.set_option("decode_mfma_hash", 1)
+    if args.cluster:
+        L.set_option("decode_cluster", args.cluster)
+    if args.no_direct_slots:
+        L.set_option("decode_direct", 0)
     if args.end_to_end:
         return end_to_end(args, cfg, rank, world, dev, dist)
     B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))

@@ -414,16 +414,30 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
     // 1.26 GB at cfg 1) where a head is split over several workgroups AND a piece rarely overflows a slot:
     // mean piece length max_length / (2^K R) <= 12.5 ids (P[Poisson(12.5) > 31] = 2e-6).
     bool direct = h->R > 1 && (double)h->M <= 12.5 * (double)h->NB * h->R;
+    const size_t slot_bytes = groups * L * h->NB * (size_t)h->R * 128;
+    if (direct) {   // an accelerator, not a requirement: never take more than a third of what is free for it
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)slot_bytes * num_layers > (double)free_b / 3.0)
+            direct = false;
+    }
     if (const int o = g_opt.decode_direct.load(); o >= 0) direct = h->R > 1 && o != 0;     // A/B switch, read at alloc
     int rc = MP_OK;
     for (int i = 0; i < num_layers && rc == MP_OK; ++i) {
         void* b = nullptr; void* t = nullptr; void* sl = nullptr;
         rc = alloc_zero(&b, groups * L * h->NB * (size_t)(h->R + 1) * 4);
         if (rc == MP_OK) rc = alloc_zero(&t, groups * L * (size_t)h->M * 4);
-        if (rc == MP_OK && direct) rc = alloc_zero(&sl, groups * L * h->NB * (size_t)h->R * 128);
         h->bounds.push_back((int32_t*)b);
         h->table.push_back((int32_t*)t);
-        if (direct) h->slots.push_back((int32_t*)sl);
+        if (rc == MP_OK && direct) {
+            if (alloc_zero(&sl, slot_bytes) == MP_OK) {
+                h->slots.push_back((int32_t*)sl);
+            } else {                              // out of memory for the slots: run without them (sub-bounds path)
+                (void)hipGetLastError();
+                for (auto p : h->slots) if (p) (void)hipFree(p);
+                h->slots.clear();
+                direct = false;
+            }
+        }
     }
     if (rc == MP_OK) rc = alloc_zero((void**)&h->part_cnt, BH * 8 * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->last_query, BH * L * 4);
