@@ -54,8 +54,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_sparse_kernel(
     float2* __restrict__ head_mz,        // [BH] (max logit, Z) for get_score
     float* __restrict__ score,           // [BH][M] transformed logits z_j (nullable)
     int BH, int G, int64_t M, int maxs, int K, int L, unsigned long long* __restrict__ stamp) {
-    constexpr int LPR = D / 8;           // lanes per row (16 B each)
-    constexpr int RPL = 64 / LPR;        // rows per wave load
+    constexpr int LPR = D / 8;           // lanes per row (16 B each); a wave load fetches 64 / LPR rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane / LPR, c = lane % LPR;
     // 1-D grid, head fastest: block b -> (x = b / BH, h = b % BH).  Blocks land on XCD b % 8, so

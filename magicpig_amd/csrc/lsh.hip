@@ -385,10 +385,10 @@ __global__ __launch_bounds__(1024) void lsh_build_direct_kernel(
 //   A[words] | B[words] | s_start[Lpad] | s_len[Lpad] | s_tail[RT_TAIL_CAP] | s_tmp[32] | s_ntail
 // `words` = words per collision bitmap = ceil(tokens the workgroup owns / 32): all M tokens of the head in
 // the stand-alone retrieve (grid = B*H), one RANGE of M / R tokens in the decode kernel (grid = R * B*H).
-// HASH = true fuses the query SimHash of models/attnserver.py:264-270 into the prologue: the head's
+// HASH = 1 fuses the query SimHash of models/attnserver.py:264-270 into the prologue: the head's
 // query row is normalised (bf16 semantics as simhash.hip), every thread evaluates <= 2 hyperplanes
 // from the chunk-major plane copy Wk[D/8][KLpad][8] (coalesced 16-byte loads, 128 f32 FMAs each,
-// exact-sign guard in f64), the sign bits meet in LDS by ballot and thread l packs table l's code --
+// exact-sign guard in f64 by the whole wave), the sign bits meet in LDS by ballot and are packed into codes --
 // the codes never travel through HBM between two kernels (they are still written for get_mask).
 struct HashArgs {
     const uint16_t* q;       // [BH][D] bf16 queries
