@@ -64,7 +64,9 @@ def parse():
     ap.add_argument("--config", default="cfg1", choices=sorted(CONFIGS))
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2048)
+    ap.add_argument("--cpu-steps", type=int, default=8192,
+                    help="decode steps of ONE sparse layer timed on the host cores per thread placement (medians): "
+                         "~5 s of CPU work at cfg 1, ~20 s at cfg 2")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # tests: control flow on CPU / gloo
     ap.add_argument("--table-build", default="counting", choices=["sort", "counting"])
