@@ -848,6 +848,7 @@ __device__ __forceinline__ void lsh_head_body(
                                                       aa.win_M, 0, 0, rank, 1 << clog, none, nullptr, stamp);
     }
     attn_head_merge<ADD, RT_WAVES>(st, s_merge, m, Z, o0, o1);
+    MP_STAMP(stamp, 40);   // the waves' states have met in LDS (the barrier waits for the wave whose rows came last)
     // from here on WAVE 0 alone holds the workgroup's state: one wave needs no workgroup barrier to order its
     // own stores, ticket and loads, and the other fifteen are done
     if (wave != 0) return;
@@ -890,6 +891,7 @@ __device__ __forceinline__ void lsh_head_body(
             __builtin_amdgcn_raw_buffer_store_b32((uint32_t)total, rc, rank * 4, 0, kSc0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing lane of this wave drained
+        MP_STAMP(stamp, 41);
         if (lane == 0)
             ticket = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ticket = __builtin_amdgcn_readfirstlane(ticket);

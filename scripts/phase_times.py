@@ -52,3 +52,4 @@ print("kernel-to-kernel (WG0 start to WG0 start): simhash->retrieve %.2f, retrie
 print("lib", L.LIB_PATH)
 seg("fused decode kernel [start|hash+probe|table streamed|scan|emit|ids staged|K gathers issued|qk|transform|pv|ticket|end]",
     [16, 17, 19, 20, 21, 33, 34, 35, 36, 37, 38, 39])
+seg("hand-off [pv|states merged in LDS|partial stored + acked|ticket drawn]", [37, 40, 41, 38])
