@@ -412,7 +412,7 @@ struct AttnArgs {
     const float* kn;         // [B*Hkv][M]
     float* part_o;           // [BH][maxs][D]
     float2* part_ml;         // [BH][maxs]
-    int* part_cnt;           // [BH][8] selected tokens of every member (R > 1)
+    int* part_cnt;           // [BH][8] selected tokens of every member (R > 1), bits 0..23; bits 24..27 its XCC_ID
     int* head_cnt;           // [BH] arrival tickets, zero between launches
     uint16_t* out;           // [BH][D] bf16
     float* mve;              // [2][BH]
@@ -422,7 +422,6 @@ struct AttnArgs {
     int* err;                // device flag: bit 4 = a cluster member ran on another XCD than observed
     int BH, maxs, cap, cluster_log2;   // cap: ids of the LDS stage (multiple of AH_SLICE)
     int same_xcd;            // the members of a cluster share one XCD (and its L2): verified by the host
-    uint32_t xcc_expect;     // same_xcd: XCC_ID observed for block residue b % 8, 4 bits each
     // optional static window (models/attnserver.py:281-308): exact attention over the first win_len[h]
     // rows of a second KV store joins the same softmax, which IS flashinfer.merge_state of the two parts
     const uint16_t* win_kv;  // [B*Hkv][win_M][2][D] or nullptr
@@ -864,7 +863,10 @@ __device__ __forceinline__ void lsh_head_body(
     // to bypass the per-CU L1 (sc0, the workgroup scope of a split workgroup) instead of writing through to the
     // memory side (sc1), which takes three ~0.6 us L2 round trips instead of three ~1.8 us ones.  The
     // host enables it only after xcd_round_robin_verified() has seen the placement on this device, and every
-    // member checks its own XCC_ID against that observation (err bit 4 otherwise: mp_attn_check reports it).
+    // launch re-checks that the members of a cluster really ran on ONE XCD: each publishes its XCC_ID next to its
+    // count and the merger compares (err bit 4 otherwise: mp_attn_check reports it).  WHICH XCD a residue lands on
+    // is not fixed -- under graph replay the round robin was observed to start elsewhere than in the probe
+    // launches -- only that blocks b and b + 8k share one matters.
     constexpr int VPL = ADD / 64;
     const int nmem = 1 << clog;
     const int64_t pre = h * aa.maxs;
@@ -872,10 +874,8 @@ __device__ __forceinline__ void lsh_head_body(
     int cr[8];
     int ticket = 0;
     if (aa.same_xcd) {
-        if (lane == 0) {
-            const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
-            if (xcc != ((aa.xcc_expect >> (4 * (blockIdx.x & 7))) & 15u)) atomicOr(aa.err, 4);
-        }
+        // every member publishes the XCD it ran on next to its count; the merger compares them with its own
+        const uint32_t my_xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]
         constexpr int kSc0 = 1;   // aux bit 0 = sc0 on gfx940+
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
             aa.part_o + pre * ADD, 0, (int)(aa.maxs * ADD * 4), 0x00020000);
@@ -888,7 +888,7 @@ __device__ __forceinline__ void lsh_head_body(
         if (lane == 0) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rm, rank * 8, 0, kSc0);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Z), rm, rank * 8 + 4, 0, kSc0);
-            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)total, rc, rank * 4, 0, kSc0);
+            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)total | (my_xcc << 24), rc, rank * 4, 0, kSc0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing lane of this wave drained
         MP_STAMP(stamp, 41);
@@ -912,6 +912,9 @@ __device__ __forceinline__ void lsh_head_body(
                 if (VPL == 2)
                     ob[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (u * ADD + lane * 2 + 1) * 4, 0, kSc0));
                 cr[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rc, u * 4, 0, kSc0);
+                // a member on another XCD (a placement the host did not observe): its partial may be stale in this L2
+                if (lane == 0 && ((uint32_t)cr[u] >> 24) != my_xcc) atomicOr(aa.err, 4);
+                cr[u] &= 0xffffff;
             }
         }
     } else {
@@ -1009,9 +1012,9 @@ __global__ __launch_bounds__(1024) void lsh_compact_segments_kernel(uint32_t* __
                                                                    int range_len, int64_t M) {
     const int64_t h = blockIdx.x;
     uint32_t* row = rows + h * M;
-    int off = part_cnt[h * 8];
+    int off = part_cnt[h * 8] & 0xffffff;   // bits 24+ : the XCD a member reported (same-XCD hand-off)
     for (int r = 1; r < R; ++r) {
-        const int cnt = part_cnt[h * 8 + r];
+        const int cnt = part_cnt[h * 8 + r] & 0xffffff;
         const int64_t src = (int64_t)r * range_len;
         if (off != src) {
             for (int base = 0; base < cnt; base += blockDim.x) {
@@ -1168,8 +1171,9 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
 }
 
 // ---- where do blocks land?  The cluster hand-off of lsh_decode_kernel may stay inside one XCD's L2
-// only if block b really runs on XCD b % 8.  That is measured, once per process and device: every
-// block of two probe launches reports its XCC_ID; the decode kernel re-checks every launch.
+// only if blocks b and b + 8k run on one XCD.  That is measured, once per process and device: every
+// block of two probe launches reports its XCC_ID (round robin over 8 distinct XCDs expected); the decode
+// kernel re-checks every launch that the members of a cluster agree on theirs.
 __global__ void xcc_probe_kernel(int* __restrict__ out) {
     if (threadIdx.x == 0) out[blockIdx.x] = (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
 }
@@ -1306,11 +1310,10 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     int clog = 0;
     while ((1 << clog) < R) ++clog;
     if ((1 << clog) != R || R > 8) return hipErrorInvalidValue;
-    uint32_t xmap = 0;
-    const bool sx = same_xcd && clog > 0 && BH % 8 == 0 && xcd_round_robin_map(&xmap);
+    const bool sx = same_xcd && clog > 0 && BH % 8 == 0 && xcd_round_robin_verified();
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
     AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, slots, score, err, BH, maxs,
-                   DECODE_ID_CAP, clog, sx ? 1 : 0, xmap, win_kv, win_len, win_M};
+                   DECODE_ID_CAP, clog, sx ? 1 : 0, win_kv, win_len, win_M};
     const dim3 grid((unsigned)BH << clog);
     const size_t lds = decode_lds_bytes(range_len, L, D);
     if (codes_given) {   // A/B: the codes and ||q|| come from simhash_query_kernel (plain decode only)
