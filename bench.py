@@ -451,6 +451,8 @@ def main():
     torch.cuda.synchronize()
     n_timed = prof_reps * NL
     k_us = e0.elapsed_time(e1) * 1e3 / n_timed
+    # the device-side validations of all the launches above (append overflow, a cluster seen on two XCDs): raises
+    server.attn_server.check()
     # whole-layer algorithmic bytes, SURVEY.md 8(d): per head L bucket probes (8 B), the candidate
     # ids (4 B), the selected ids (4 B), per selected token K row + V row + key norm + id, q and out;
     # plus the hyperplanes once per layer

@@ -168,7 +168,9 @@ int mp_attn_get_kv(mp_attn_t* h, int layer_id, void** key_dev, void** value_dev,
                    int64_t* row_stride_elems);
 int mp_attn_get_key_norm(mp_attn_t* h, int layer_id, void** kn_dev);
 /* get_score, sparse_attention.cc:1235-1241: probabilities of the last sparse/full call,
- * f32 [B, H, M], first nnz entries per head in `ind` order.  Normalised on demand. */
+ * f32 [B, H, M], first nnz entries per head in `ind` order.  Normalised (and, after the one-launch
+ * decode, compacted) on demand, ONCE per call that produced logits: the library tracks that on the host,
+ * so the view is defined after a call the host issued, not after the replay of a captured graph. */
 int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream);
 
 /* Debug: device buffer of >= 64 uint64 receiving 100 MHz wall-clock stamps at the phase

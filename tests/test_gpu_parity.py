@@ -653,6 +653,53 @@ def test_fused_decode_cluster_handoff_is_deterministic(mp, B, H, Hkv):
         assert np.allclose(l1.reshape(-1).cpu().numpy()[live], mve[1].cpu().numpy()[live], atol=2e-3)
 
 
+@pytest.mark.parametrize("B,H,Hkv", [(1, 32, 8), (1, 8, 2)])
+def test_fused_decode_under_graph_replay_keeps_the_cluster_checks_quiet(mp, B, H, Hkv):
+    """A captured decode step replayed back to back: the block -> XCD round robin does not start where it did
+    in the eager probe launches, which a check against the probe's absolute map reported as a misplaced cluster
+    on every replay.  The members still share an XCD: outputs must equal the eager launch bit for bit, the
+    per-launch placement check (mp_attn_check) must stay quiet, and get_score's compaction must still read the
+    per-member counts (their top byte now carries the XCC_ID)."""  # get_score itself is a host-tracked view: eager
+    n, M, D, K, L = 6000, 6144, 128, 8, 75
+    server, _ = _fused_server(mp, B, H, Hkv, n, M, D, K, L, 777)
+    BH = B * H
+    assert server.lsh_retriever.R > 1
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    qs = torch.randn((6, B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16)
+    q_static = qs[0].clone()
+    server.collect_nnz = False
+    eager = []
+    for i in range(6):
+        o, l = server.decode(qs[i], 0)
+        eager.append((o.clone(), l.clone()))
+    server.attn_server.check()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        server.decode(q_static, 0)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(4):                      # four back-to-back launches per replay
+            o_g, l_g = server.decode(q_static, 0)
+    for rep in range(5):
+        for i in range(6):
+            q_static.copy_(qs[i])
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(o_g, eager[i][0]) and torch.equal(l_g, eager[i][1])
+    server.attn_server.check()                  # raises MP_ERR_STATE if a cluster was seen on two XCDs
+    # the compaction of the per-member segments (get_score) reads the same count words, top byte masked
+    server.collect_nnz = True
+    server.decode(qs[0], 0)
+    sc = server.attn_server.get_score().reshape(BH, -1)
+    nnz = server.nnz.cpu().numpy()
+    assert nnz.max() > 0
+    for h in range(BH):
+        assert nnz[h] == 0 or float(sc[h, :nnz[h]].sum()) == pytest.approx(1.0, abs=1e-3)
+
+
 @pytest.mark.parametrize("B,H,Hkv,D,K,L,n,M", [
     (1, 4, 2, 64, 4, 1100, 600, 640),        # more tables than threads in a workgroup, head_dim 64
     (2, 8, 8, 128, 15, 12, 3000, 3001),      # widest codes, odd max_length, no GQA
