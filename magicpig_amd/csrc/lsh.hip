@@ -45,7 +45,10 @@ hipError_t set_stamp_stride(int stride) {
     return hipMemcpyToSymbol(HIP_SYMBOL(d_stamp_stride), &stride, sizeof(int));
 }
 
-constexpr int RT_THREADS = 1024;           // 16 waves: one workgroup per query head
+#ifndef MP_RT_THREADS
+#define MP_RT_THREADS 1024
+#endif
+constexpr int RT_THREADS = MP_RT_THREADS;  // 16 waves: one workgroup per query head (A/B builds: 512, two per CU)
 constexpr int RT_WAVES = RT_THREADS / 64;
 constexpr int RT_GROUP = 12;               // buckets in flight per wave per round (x 2 chunks of 64 ids)
 constexpr int RT_TAIL_CAP = 2048;          // pooled chunk descriptors for ids beyond 128 per bucket
@@ -984,7 +987,7 @@ __device__ __forceinline__ void lsh_head_body(
 
 // LSH::batch_retrieve (optionally with the query hash as its prologue)
 template <int HASH, int CH>
-__global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
+__global__ __launch_bounds__(RT_THREADS, 4) void lsh_retrieve_kernel(
     const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
     int G, int L, int NB, int64_t M, int R, int words, int Lpad, HashArgs ha,
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(RT_THREADS) void lsh_retrieve_kernel(
 
 // the whole sparse layer of models/attnserver.py:264-300: hash -> retrieve -> attention
 template <int CH, int AD, bool WIN, int HASH = 1>
-__global__ __launch_bounds__(RT_THREADS) void lsh_decode_kernel(
+__global__ __launch_bounds__(RT_THREADS, 4) void lsh_decode_kernel(
     const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     int32_t* __restrict__ results, int32_t* __restrict__ nnz,
     int G, int L, int NB, int64_t M, int R, int range_len, int words, int Lpad, HashArgs ha, AttnArgs aa,
