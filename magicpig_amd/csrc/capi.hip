@@ -413,14 +413,16 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
     // holding the piece's length and first 31 ids.  Worth their memory (groups x L x 2^K x R x 128 B per layer:
     // 1.26 GB at cfg 1) where a head is split over several workgroups AND a piece rarely overflows a slot:
     // mean piece length max_length / (2^K R) <= 12.5 ids (P[Poisson(12.5) > 31] = 2e-6).
-    bool direct = h->R > 1 && (double)h->M <= 12.5 * (double)h->NB * h->R;
+    bool direct = h->R > 1 && (double)h->M <= 12.5 * (double)h->NB * h->R &&
+                  (double)L * h->NB * h->R * 32.0 < 2147483648.0;     // 32-bit slot offsets inside a group
     const size_t slot_bytes = groups * L * h->NB * (size_t)h->R * 128;
     if (direct) {   // an accelerator, not a requirement: never take more than a third of what is free for it
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)slot_bytes * num_layers > (double)free_b / 3.0)
             direct = false;
     }
-    if (const int o = g_opt.decode_direct.load(); o >= 0) direct = h->R > 1 && o != 0;     // A/B switch, read at alloc
+    if (const int o = g_opt.decode_direct.load(); o >= 0)                                  // A/B switch, read at alloc
+        direct = h->R > 1 && o != 0 && (double)L * h->NB * h->R * 32.0 < 2147483648.0;
     int rc = MP_OK;
     for (int i = 0; i < num_layers && rc == MP_OK; ++i) {
         void* b = nullptr; void* t = nullptr; void* sl = nullptr;

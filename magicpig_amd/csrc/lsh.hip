@@ -34,6 +34,7 @@ __device__ int d_stamp_stride = 0;    // debug: > 0 = every workgroup records it
 }
 #define MP_STAMP_STRIDE ::mp::d_stamp_stride
 
+#include <type_traits>
 #include "common.h"
 #include "attn_head.h"
 
@@ -624,6 +625,11 @@ __device__ __forceinline__ void lsh_head_body(
         if (sh + ha.K > 32) v |= s_bits[w + 1] << (32 - sh);
         return (int)(v & ((1u << ha.K) - 1u));
     };
+    auto code_fast = [&](int l) {   // code_of without a branch: both words, one funnel shift (s_bits has slack words)
+        if (HASH == 2) return (int)ha.codes_out[h * L + l];
+        const uint32_t bp = (uint32_t)l * (uint32_t)ha.K, w = bp >> 5;
+        return (int)(__funnelshift_r(s_bits[w], s_bits[w + 1], bp & 31u) & ((1u << ha.K) - 1u));
+    };
     const int32_t* slots = (AD > 0) ? aa.slots : nullptr;
     if (AD > 0 && HASH != 0 && slots != nullptr) {
         // ---- DIRECT pieces: the piece (table l, bucket code, range rank) has a 128-byte slot holding its length
@@ -631,19 +637,36 @@ __device__ __forceinline__ void lsh_head_body(
         // ids).  Half a wave reads a slot; a wave keeps DG loads = 2 DG pieces in flight.  Pieces longer than 31
         // ids (rare by construction: the slots exist only where the mean piece is <= 12.5 ids) finish through
         // the sub-bounds and the chunk pool below.
-        constexpr int DG = 6;
         const int half = lane >> 5, sl = lane & 31;
         const int32_t* sg = slots + ((int64_t)g * L * NB * R + rank) * 32;
+        // DG = 6 covers 192 tables in one round (cfg 1: L = 150); with more tables (cfg 4: L = 300) a second
+        // round would be a second dependent round trip, so the wide form keeps 10 loads = 320 pieces in flight
+        auto direct_pass = [&](auto dg_tag) {
+        constexpr int DG = decltype(dg_tag)::value;
         for (int l0 = 0; l0 < L; l0 += RT_WAVES * 2 * DG) {
             int32_t v[DG];
             int cd[DG];
+            uint32_t at[DG];
+            // three straight-line rounds -- codes (two LDS words + one funnel shift each), slot offsets (shifts only:
+            // NB = 2^K, R = 2^clog, 32-word slots; the host keeps a group's slots under 2^31 words), loads -- and the
+            // stores of the codes after them.  As one loop body per piece (a branch around the second LDS word, 64-bit
+            // multiplies, a branch around the store) the compiler emitted six dependent LDS round trips in front of
+            // the loads: 1.5 us between "sign bits in LDS" and "loads issued" (scripts/phase_times.py), now 0.3.
 #pragma unroll
             for (int b = 0; b < DG; ++b) {
                 const int l = l0 + (b * RT_WAVES + wave) * 2 + half;
                 const int lc = l < L ? l : L - 1;                       // loads stay unconditional
-                cd[b] = code_of(lc);
-                v[b] = sg[((int64_t)lc * NB + cd[b]) * R * 32 + sl];
-                if (HASH == 1 && lead && sl == 0 && l < L) ha.codes_out[h * L + l] = cd[b];
+                cd[b] = code_fast(lc);
+                at[b] = (((((uint32_t)lc << ha.K) + (uint32_t)cd[b]) << clog) << 5) + (uint32_t)sl;
+            }
+#pragma unroll
+            for (int b = 0; b < DG; ++b) v[b] = sg[at[b]];
+            if (HASH == 1 && lead && sl == 0) {
+#pragma unroll
+                for (int b = 0; b < DG; ++b) {
+                    const int l = l0 + (b * RT_WAVES + wave) * 2 + half;
+                    if (l < L) ha.codes_out[h * L + l] = cd[b];
+                }
             }
 #pragma unroll
             for (int b = 0; b < DG; ++b) {
@@ -660,6 +683,9 @@ __device__ __forceinline__ void lsh_head_body(
                 }
             }
         }
+        };
+        if (L > RT_WAVES * 2 * 6) direct_pass(std::integral_constant<int, 10>{});
+        else direct_pass(std::integral_constant<int, 6>{});
         __syncthreads();
         MP_STAMP(stamp, 17);
         if (s_tmp[30] > 0) {                                            // uniform
