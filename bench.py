@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--shard", default="batch", choices=["batch", "head"],
                     help="batch: every rank serves its own B requests (weak scaling); head: the kv heads of the "
                          "whole model are partitioned over the ranks like the reference's TP variant (strong scaling)")
+    ap.add_argument("--lib", default=None,
+                    help="A/B: path of an alternative build of libmagicpig_hip.so (the product reads no environment)")
     ap.add_argument("--cluster", type=int, default=0,
                     help="A/B: workgroups per query head of the decode kernel (1, 2, 4, 8; default: by B*H and CUs)")
     ap.add_argument("--no-direct-slots", action="store_true", help="A/B: sub-bounds + ids instead of direct piece slots")
@@ -306,8 +308,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    import magicpig_amd as mp
     import magicpig_amd._lib as L
+    if args.lib:
+        L.LIB_PATH = os.path.abspath(args.lib)
+    import magicpig_amd as mp
     from magicpig_amd import sharding
 
     cfg = CONFIGS[args.config]
