@@ -192,8 +192,8 @@ int mp_debug_xcd_round_robin(void);
  *                        [b * n + slot] of the stamp buffer (which must hold grid * n entries); 0 = workgroup 0 only
  *   "decode_mfma_hash"   0/1   mp_decode_sparse_layer with the query SimHash as the MFMA kernel's own launch in
  *                        front of the decode kernel instead of the hash fused into it (measured slower: profiles/)
- *   "decode_direct"      -1 = auto, 0 = never, 1 = always (where R > 1): keep 128-byte direct slots (length + first
- *                        31 ids) for every (table, bucket, token range) piece; read by mp_lsh_alloc
+ *   "decode_direct"      -1 = auto, 0 = never, 1 = always (where R > 1): keep 128-byte direct slots (length, position + first
+ *                        30 ids) for every (table, bucket, token range) piece; read by mp_lsh_alloc
  *   "attn_head_kernel"   -1 = auto, 0 = split-KV kernel with the in-launch ticket merge, 1 = one workgroup per head
  *   "attn_gx"            0 = auto, n = split-KV workgroups per head
  *   "attn_dense_grouped" 1 = mp_attn_full reads K/V once per kv group (default), 0 = once per query head */

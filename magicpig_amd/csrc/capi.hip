@@ -410,7 +410,7 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
     h->R = decode_cluster_size((int)BH, h->M);
     h->range_len = lsh_range_len(h->M, h->R);
     // direct piece slots (lsh.hip: lsh_slots_kernel): one 128-byte record per (table, bucket, token range)
-    // holding the piece's length and first 31 ids.  Worth their memory (groups x L x 2^K x R x 128 B per layer:
+    // holding the piece's length, position and first 30 ids.  Worth their memory (groups x L x 2^K x R x 128 B per layer:
     // 1.26 GB at cfg 1) where a head is split over several workgroups AND a piece rarely overflows a slot:
     // mean piece length max_length / (2^K R) <= 12.5 ids (P[Poisson(12.5) > 31] = 2e-6).
     bool direct = h->R > 1 && (double)h->M <= 12.5 * (double)h->NB * h->R &&

@@ -54,6 +54,8 @@ constexpr int RT_WAVES = RT_THREADS / 64;
 constexpr int RT_GROUP = 12;               // buckets in flight per wave per round (x 2 chunks of 64 ids)
 constexpr int RT_TAIL_CAP = 2048;          // pooled chunk descriptors for ids beyond 128 per bucket
 constexpr int RT_TAIL_UNROLL = 8;
+constexpr int DIRECT_IDS = 30;             // ids held by a 128-byte direct slot (behind the piece's length and position)
+constexpr int DIRECT_MORE = 96;            // ids of a longer piece its half-wave fetches itself before the chunk pool
 
 // ---------------------------------------------------------------- LSH::fill
 // grid = Hkv*L rows of one request; one workgroup per (kv head, table) row.  RS = R + 1 entries per
@@ -128,9 +130,10 @@ __global__ __launch_bounds__(256) void lsh_subbounds_kernel(
     }
 }
 
-// direct piece slots [rows][NB][R][32] (R > 1): word 0 = length of the piece (bucket, range) in the table row,
-// words 1 .. 31 = its first ids.  The decode kernel reads a piece with ONE 128-byte access straight from the
-// query's code, without the sub-bounds round trip in front of it.  Half a wave writes a slot.
+// direct piece slots [rows][NB][R][32] (R > 1): word 0 = length of the piece (bucket, range), word 1 = its position
+// in the table row, words 2 .. 31 = its first 30 ids.  The decode kernel reads a piece with ONE 128-byte access
+// straight from the query's code, without the sub-bounds round trip in front of it; the position lets it fetch the
+// rest of a longer piece with the next access.  Half a wave writes a slot.
 __global__ __launch_bounds__(256) void lsh_slots_kernel(const int32_t* __restrict__ table,
                                                         const int32_t* __restrict__ bounds,
                                                         int32_t* __restrict__ slots, int NB, int R, int64_t M) {
@@ -155,7 +158,8 @@ __global__ __launch_bounds__(256) void lsh_slots_kernel(const int32_t* __restric
         for (int u = 0; u < U; ++u) {
             v[u] = 0;
             if (sl == 0) v[u] = hi[u] - lo[u];
-            else if (sl - 1 < hi[u] - lo[u]) v[u] = t[lo[u] + sl - 1];
+            else if (sl == 1) v[u] = lo[u];
+            else if (sl - 2 < hi[u] - lo[u]) v[u] = t[lo[u] + sl - 2];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -632,11 +636,12 @@ __device__ __forceinline__ void lsh_head_body(
     };
     const int32_t* slots = (AD > 0) ? aa.slots : nullptr;
     if (AD > 0 && HASH != 0 && slots != nullptr) {
-        // ---- DIRECT pieces: the piece (table l, bucket code, range rank) has a 128-byte slot holding its length
-        // and its first 31 ids, so ONE dependent round trip (hash -> slot) replaces two (hash -> sub-bounds ->
-        // ids).  Half a wave reads a slot; a wave keeps DG loads = 2 DG pieces in flight.  Pieces longer than 31
-        // ids (rare by construction: the slots exist only where the mean piece is <= 12.5 ids) finish through
-        // the sub-bounds and the chunk pool below.
+        // ---- DIRECT pieces: the piece (table l, bucket code, range rank) has a 128-byte slot holding its length,
+        // position and first 30 ids, so ONE dependent round trip (hash -> slot) replaces two (hash -> sub-bounds ->
+        // ids).  Half a wave reads a slot; a wave keeps DG loads = 2 DG pieces in flight.  A piece longer than 30
+        // ids is finished by its half-wave with one more access (below); the slots exist only where the mean piece
+        // is <= 12.5 ids.  (256-byte slots holding 63 ids need no second access and measured slower: 23.8 against
+        // 22.9 us per layer at cfg 1, 28.6 against 27.3 at cfg 4 -- twice the bytes of random 128-byte reads.)
         const int half = lane >> 5, sl = lane & 31;
         const int32_t* sg = slots + ((int64_t)g * L * NB * R + rank) * 32;
         // DG = 6 covers 192 tables in one round (cfg 1: L = 150); with more tables (cfg 4: L = 300) a second
@@ -672,12 +677,38 @@ __device__ __forceinline__ void lsh_head_body(
             for (int b = 0; b < DG; ++b) {
                 const int l = l0 + (b * RT_WAVES + wave) * 2 + half;
                 const int c0 = __builtin_amdgcn_readlane(v[b], 0), c1 = __builtin_amdgcn_readlane(v[b], 32);
+                const int p0 = __builtin_amdgcn_readlane(v[b], 1), p1 = __builtin_amdgcn_readlane(v[b], 33);
                 const int pl = half ? c1 : c0;                          // length of the piece
+                const int pp = half ? p1 : p0;                          // its position in the table row
+                int rest = 0;
                 if (l < L) {
-                    if (sl >= 1 && sl <= pl) apply(v[b]);
-                    if (sl == 0 && pl > 31) {                           // the rest goes through the sub-bounds
-                        s_start[l] = cd[b];
-                        s_len[l] = pl - 31;
+                    if (sl >= 2 && sl - 2 < pl) apply(v[b]);
+                    rest = pl - DIRECT_IDS;
+                    if (pp < 0 || (int64_t)pp + pl > M) rest = 0;       // never outside the row
+                }
+                // A piece longer than the slot.  Not rare: SimHash buckets are far from equally likely (ten random
+                // planes in 128 dimensions: bucket sizes at cfg 1 run from 32 (p1) to 209 (p99) around a mean of 96)
+                // and a query lands in the heavy ones more often -- 1.2 % of the probed pieces, at least one in 82 %
+                // of the workgroups (scripts/piece_lengths.py).  The half-wave fetches up to 96 more ids right
+                // here, ONE more dependent access and no barrier (through the sub-bounds and the chunk pool it was
+                // two accesses and two barriers); what is longer still goes to the pool.
+                if (__ballot(rest > 0)) {                               // wave-uniform
+                    const int lc = l < L ? l : L - 1;
+                    const int32_t* row = tab + (int64_t)lc * M;
+                    const int r1 = rest < DIRECT_MORE ? rest : DIRECT_MORE;
+                    const int at0 = pp + DIRECT_IDS + sl;
+                    const int32_t e0 = row[sl < r1 ? at0 : 0];
+                    int32_t e1 = -1, e2 = -1;
+                    if (__ballot(r1 > 32)) {
+                        e1 = row[sl + 32 < r1 ? at0 + 32 : 0];
+                        e2 = row[sl + 64 < r1 ? at0 + 64 : 0];
+                    }
+                    apply(sl < r1 ? e0 : -1);
+                    apply(sl + 32 < r1 ? e1 : -1);
+                    apply(sl + 64 < r1 ? e2 : -1);
+                    if (sl == 0 && rest > DIRECT_MORE) {                // skewed data: the chunk pool takes the rest
+                        s_start[l] = pp + DIRECT_IDS + DIRECT_MORE;
+                        s_len[l] = rest - DIRECT_MORE;
                         atomicAdd(&s_tmp[30], 1);
                     }
                 }
@@ -688,16 +719,10 @@ __device__ __forceinline__ void lsh_head_body(
         else direct_pass(std::integral_constant<int, 6>{});
         __syncthreads();
         MP_STAMP(stamp, 17);
-        if (s_tmp[30] > 0) {                                            // uniform
+        if (s_tmp[30] > 0) {                                            // uniform; pieces longer than 30 + 96 ids
             for (int l = tid; l < L; l += RT_THREADS) {
-                int len = s_len[l];
+                const int len = s_len[l];                               // start and length were checked above
                 if (len > 0) {
-                    const int32_t* rec = bnd + ((int64_t)l * NB + s_start[l]) * RS;
-                    const int lo = rec[e_lo], hi = rec[e_hi];
-                    if (lo < 0 || hi - lo - 31 < len) len = hi - lo - 31;    // never past the piece
-                    if (len < 0 || (int64_t)hi > M) len = 0;
-                    s_start[l] = lo + 31;
-                    s_len[l] = len;
                     const int nch = (len + 63) >> 6;
                     const int base = atomicAdd(s_ntail, nch);
                     for (int c = 0; c < nch && base + c < RT_TAIL_CAP; ++c)
