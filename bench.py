@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--cluster", type=int, default=0,
                     help="A/B: workgroups per query head of the decode kernel (1, 2, 4, 8; default: by B*H and CUs)")
     ap.add_argument("--no-direct-slots", action="store_true", help="A/B: sub-bounds + ids instead of direct piece slots")
+    ap.add_argument("--split-hash", type=int, default=-1, choices=[-1, 0, 1],
+                    help="A/B: hyperplanes split over the workgroups of a head's cluster (0 never, 1 always; default: auto)")
     ap.add_argument("--direct-slots", type=int, default=-1, choices=[-1, 0, 1],
                     help="A/B: direct piece slots: 0 never, 1 always (where R > 1); default: auto")
     ap.add_argument("--mfma-hash", action="store_true",
@@ -323,6 +325,8 @@ def main():
         L.set_option("decode_mfma_hash", 1)
     if args.cluster:
         L.set_option("decode_cluster", args.cluster)
+    if args.split_hash >= 0:
+        L.set_option("decode_split_hash", args.split_hash)
     if args.no_direct_slots:
         L.set_option("decode_direct", 0)
     elif args.direct_slots >= 0:

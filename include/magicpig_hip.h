@@ -192,6 +192,10 @@ int mp_debug_xcd_round_robin(void);
  *                        [b * n + slot] of the stamp buffer (which must hold grid * n entries); 0 = workgroup 0 only
  *   "decode_mfma_hash"   0/1   mp_decode_sparse_layer with the query SimHash as the MFMA kernel's own launch in
  *                        front of the decode kernel instead of the hash fused into it (measured slower: profiles/)
+ *   "decode_split_hash"  -1 = auto, 0 = never, 1 = always (clusters whose workgroups share an XCD): the hyperplanes
+ *                        are split over the workgroups of a head's cluster and the sign bits exchanged through the
+ *                        XCD's L2, with a bounded wait and hashing alone as the fallback; 2 = split but nobody
+ *                        publishes (test: every workgroup takes the fallback)
  *   "decode_direct"      -1 = auto, 0 = never, 1 = always (where R > 1): keep 128-byte direct slots (length, position + first
  *                        30 ids) for every (table, bucket, token range) piece; read by mp_lsh_alloc
  *   "attn_head_kernel"   -1 = auto, 0 = split-KV kernel with the in-launch ticket merge, 1 = one workgroup per head

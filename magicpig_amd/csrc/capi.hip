@@ -28,7 +28,7 @@ hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, co
                              int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
                              float*, float2*, int*, int*, uint16_t*, float*, float2*, const int32_t*, float*, int*,
                              int, int, bool, const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t,
-                             bool, hipStream_t);
+                             bool, unsigned long long*, unsigned int*, int, int, hipStream_t);
 hipError_t set_stamp_stride(int);
 hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
@@ -82,6 +82,7 @@ struct DebugOptions {
     std::atomic<int> decode_cluster{0};      // 0 = auto, else workgroups per head (clamped to [1, min(8, slices)])
     std::atomic<int> decode_agent_scope{0};  // 1: cluster hand-off through memory even when the XCD placement was observed
     std::atomic<int> decode_mfma_hash{0};    // 1: query SimHash by the MFMA kernel in a launch of its own, then the decode
+    std::atomic<int> decode_split_hash{-1};  // -1 = auto, 0 = never, 1 = always (clusters on one XCD), 2 = split but nobody publishes (test)
     std::atomic<int> decode_direct{-1};      // -1 = auto, 0 = never, 1 = always (when R > 1) keep direct piece slots
     std::atomic<int> attn_head_kernel{-1};   // -1 = auto, 0 = split-KV kernel, 1 = one workgroup per head
     std::atomic<int> attn_gx{0};             // 0 = auto, else split-KV workgroups per head
@@ -95,6 +96,7 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "decode_cluster")) return &g_opt.decode_cluster;
     if (!strcmp(name, "decode_agent_scope")) return &g_opt.decode_agent_scope;
     if (!strcmp(name, "decode_direct")) return &g_opt.decode_direct;
+    if (!strcmp(name, "decode_split_hash")) return &g_opt.decode_split_hash;
     if (!strcmp(name, "decode_mfma_hash")) return &g_opt.decode_mfma_hash;
     if (!strcmp(name, "attn_head_kernel")) return &g_opt.attn_head_kernel;
     if (!strcmp(name, "attn_gx")) return &g_opt.attn_gx;
@@ -204,6 +206,9 @@ struct mp_lsh {
     std::vector<int32_t*> table;   // per layer [B*Hkv][L][M]
     std::vector<int32_t*> slots;   // per layer [B*Hkv][L][NB][R][32] direct piece slots, or empty (R = 1 / long pieces)
     int* part_cnt = nullptr;       // [BH][8] per-member selected counts of the last decode launch
+    unsigned long long* xw = nullptr;   // [BH][xwords] split hash: (launch sequence << 32 | 32 sign bits) (R > 1)
+    unsigned int* xseq = nullptr;  // [BH] split hash: sequence number of the next launch
+    int xwords = 0;
     Stage small, big;              // host-buffer mode: (nnz | offsets) and the packed result rows
     int32_t* last_query = nullptr; // [BH][L] staging copy of host-side query codes
     const int32_t* lastq = nullptr;// device codes of the last retrieve (for get_mask): last_query,
@@ -369,10 +374,10 @@ static void lsh_free(mp_lsh_t* h) {
     h->bounds.clear();
     h->table.clear();
     h->slots.clear();
-    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->part_cnt};
+    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->part_cnt, h->xw, h->xseq};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->last_query = nullptr; h->err = nullptr; h->codes = nullptr; h->results = nullptr;
-    h->nnz = nullptr; h->qnorm = nullptr; h->part_cnt = nullptr;
+    h->nnz = nullptr; h->qnorm = nullptr; h->part_cnt = nullptr; h->xw = nullptr; h->xseq = nullptr;
     h->small.release();
     h->big.release();
     h->allocated = false;
@@ -442,6 +447,13 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
         }
     }
     if (rc == MP_OK) rc = alloc_zero((void**)&h->part_cnt, BH * 8 * 4);
+    h->xwords = 2 * ((K * L + 63) / 64);
+    if (rc == MP_OK && h->R > 1) rc = alloc_zero((void**)&h->xw, BH * (size_t)h->xwords * 8);
+    if (rc == MP_OK && h->R > 1) {
+        rc = alloc_zero((void**)&h->xseq, BH * 4);
+        // words start at sequence 0, launches at 1: nothing stale can pass for a word of the first launch
+        if (rc == MP_OK && hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->xseq), 1, BH) != hipSuccess) rc = MP_ERR_HIP;
+    }
     if (rc == MP_OK) rc = alloc_zero((void**)&h->last_query, BH * L * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->err, 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->codes, BH * L * 4);
@@ -1077,6 +1089,10 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         // the selected ids stay in LDS.
         // A/B (north_star names MFMA for the query projection): the hash as simhash_query_kernel's own launch
         const bool mfma_hash = win == nullptr && g_opt.decode_mfma_hash.load() != 0;
+        // the planes split over the members of a cluster, sign bits exchanged through the XCD's L2 (lsh.hip); the
+        // launcher keeps it to clusters that share an XCD.  -1 = auto: on
+        int xmode = g_opt.decode_split_hash.load();
+        if (xmode < 0) xmode = 1;
         if (mfma_hash)
             MP_HIP_CHECK(launch_simhash_query(q, s->Wt, s->wnorm, BH, s->D, s->K, s->L, lsh->codes, lsh->qnorm,
                                               nullptr, st));
@@ -1087,7 +1103,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
                                        lsh->slots.empty() ? nullptr : lsh->slots[layer_id], attn->score, attn->err, attn_slices_per_head(attn->M), lsh->R,
                                        attn->xcd_rr && g_opt.decode_agent_scope.load() == 0,
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
-                                       lsh->L, lsh->NB, lsh->M, mfma_hash, st));
+                                       lsh->L, lsh->NB, lsh->M, mfma_hash, lsh->xw, lsh->xseq, lsh->xwords, xmode, st));
         attn->lastz = lsh->nnz;
         attn->score_state = 1;
         attn->seg_cnt = lsh->R > 1 ? lsh->part_cnt : nullptr;

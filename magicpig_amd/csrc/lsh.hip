@@ -430,6 +430,9 @@ struct AttnArgs {
     int* err;                // device flag: bit 4 = a cluster member ran on another XCD than observed
     int BH, maxs, cap, cluster_log2;   // cap: ids of the LDS stage (multiple of AH_SLICE)
     int same_xcd;            // the members of a cluster share one XCD (and its L2): verified by the host
+    unsigned long long* xw;  // split hash: [BH][xwords] (launch sequence << 32 | 32 sign bits) exchanged by a cluster
+    unsigned int* xseq;      // split hash: [BH] sequence number of the current launch (the merger advances it)
+    int xwords, xmode;       // words per head; xmode 2 = nobody publishes (test: every member takes the fallback)
     // optional static window (models/attnserver.py:281-308): exact attention over the first win_len[h]
     // rows of a second KV store joins the same softmax, which IS flashinfer.merge_state of the two parts
     const uint16_t* win_kv;  // [B*Hkv][win_M][2][D] or nullptr
@@ -437,7 +440,8 @@ struct AttnArgs {
     int64_t win_M;
 };
 
-// HASH: 0 = the codes are given (`query`), 1 = fused SimHash prologue, 2 = (decode only) codes + ||q|| were written
+// HASH: 0 = the codes are given (`query`), 1 = fused SimHash prologue, 3 = the same with the planes split over the
+// members of the head's cluster (decode only, clusters on one XCD), 2 = (decode only) codes + ||q|| were written
 // to ha.codes_out / ha.qnorm_out by simhash_query_kernel (the MFMA kernel) in a launch of its own: the A/B
 // variant of the decode entry behind the decode_mfma_hash option.
 template <int HASH, int CH, int AD, bool WIN>    // CH = min(16, D / 8): plane chunks kept in registers (HASH only);
@@ -487,6 +491,7 @@ __device__ __forceinline__ void lsh_head_body(
     if (tid == 0) {
         *s_ntail = 0;
         s_tmp[30] = 0;                                            // pieces that overflow their direct slot
+        s_tmp[29] = 1;                                            // split hash: every word of the head arrived
     }
     // collision bitmaps and piece lengths start at zero: done here, under the query row's round trip
     for (int i = tid; i < 2 * words; i += RT_THREADS) s_u32[i] = 0u;
@@ -500,7 +505,7 @@ __device__ __forceinline__ void lsh_head_body(
             if (lane == 0) s_rn[1] = ha.qnorm_out[h];
         }
     }
-    if (HASH == 1) {
+    if (HASH == 1 || HASH == 3) {
         const int D = ha.D, KL = ha.K * L;
         const int chunks = D >> 3;                              // 16-byte plane chunks per hyperplane
         const u32x4* Wk4 = reinterpret_cast<const u32x4*>(ha.Wk);
@@ -522,12 +527,25 @@ __device__ __forceinline__ void lsh_head_body(
         //    plane loads of this prologue are UNCONDITIONAL on clamped indices (columns >= KL of Wk are
         //    zero): with loads under divergent branches the compiler cannot count what is outstanding
         //    and waits vmcnt(0) before every use, which serialised the second pass's prefetch.
+        // -- SPLIT hash (decode, clusters that share an XCD): every member of the head's cluster evaluates 1/R of the
+        //    planes -- units of 64, one wave each: unit u belongs to member u % R, wave u / R -- and the sign bits are
+        //    exchanged through the XCD's L2.  Every CU pulls its planes through a ~50 bytes/clock path
+        //    (scripts/probes/plane_pull.hip): 384 KB at cfg 1, 845 KB at cfg 4 when a member hashes alone.
+        const int U = (KL + 63) >> 6;                            // units of 64 planes
+        const bool split = HASH == 3 && AD > 0 && aa.xw != nullptr && clog > 0 && U <= (RT_WAVES << clog);   // uniform
+        const int unit = rank + (wave << clog);
+        uint32_t seq = 0;
+        if (split) {   // this launch's sequence number: written by the previous launch's merger (kernel boundary)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(aa.xseq + h, 0, 4, 0x00020000);
+            seq = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 1);
+        }
         u32x4 w[CH];
-        {
-            const int cc = tid < ha.KLpad ? tid : ha.KLpad - 1;
+        auto load_planes = [&](int col) {
+            const int cc = col < ha.KLpad ? col : ha.KLpad - 1;
 #pragma unroll
             for (int i = 0; i < CH; ++i) w[i] = Wk4[cc + (int64_t)i * ha.KLpad];
-        }
+        };
+        load_planes(split ? (unit << 6) + lane : tid);
         // -- normalise the query row
         if (wave == 0) {
             const uint16_t e[4] = {(uint16_t)(e01 & 0xffffu), (uint16_t)(e01 >> 16),
@@ -564,6 +582,75 @@ __device__ __forceinline__ void lsh_head_body(
         //    pass's chunks are fetched into the registers this pass has just consumed
         const float rn = *s_rn;
         const u32x4* q4 = reinterpret_cast<const u32x4*>(s_q);
+        // exact sign of the columns inside the guard band, one column at a time by the WHOLE wave: lane j
+        // takes elements j*per .. of the dot product (exact f64 products of bf16 pairs), a DPP wave sum adds
+        // them (exact and order-free).  One parallel round of loads: ~0.6 us.  The same loop run by the owning
+        // thread alone (16 dependent 16-byte loads) took ~2.5 us, and with eight members per head almost every
+        // cluster had such a member somewhere -- it was the tail of the whole launch.
+        auto exact_signs = [&](bool near, int col0, bool& bit) {            // col0: column of this wave's lane 0
+            for (unsigned long long fm = __ballot(near); fm; fm &= fm - 1) {   // wave-uniform
+                const int src = __ffsll((long long)fm) - 1;
+                const int cs = col0 + src;
+                const int d0 = lane * per;
+                const uint16_t* wp = ha.Wk + ((int64_t)(d0 >> 3) * ha.KLpad + cs) * 8 + (d0 & 7);
+                const uint16_t* qp = reinterpret_cast<const uint16_t*>(s_q) + d0;
+                double part = 0.0;
+                for (int i = 0; i < per; ++i)
+                    part += (double)bf16_bits_to_f32(qp[i]) * (double)bf16_bits_to_f32(wp[i]);
+                const double ex = wave_sum(part);
+                if (lane == src) bit = ex > 0.0;
+            }
+        };
+        auto finish_column = [&](int c, float& acc, bool& bit, bool& near) {
+            if (c < KL) {
+                for (int kc = CH; kc < chunks; ++kc)                // head_dim 256: remaining chunks
+                    dot8_bf16_chain(acc, q4[kc], Wk4[c + (int64_t)kc * ha.KLpad]);
+                dot_settle(acc);
+                bit = acc > 0.f;
+                near = fabsf(acc) <= (1.0f / 65536.0f) * rn * ha.wnorm[c];   // 2^-16 guard band (simhash.hip SH_EPS)
+            }
+        };
+        bool have_bits = false;
+        if (split) {
+            // ---- this wave's unit (if it has one), published as two 64-bit words (sequence << 32 | 32 sign bits):
+            // a word proves by itself that it belongs to THIS launch, so there is no counter, no acknowledgement and
+            // no ticket -- a store, then returning L2 atomics that poll the head's 2 U words until every one carries
+            // the sequence number.  A workgroup may only wait for peers that are running: the wait is bounded, and a
+            // member that gives up hashes all planes itself (always correct, never blocked).
+            bool bit = false, near = false;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) dot8_bf16_chain(acc, q4[i], w[i]);
+            if (unit < U) finish_column((unit << 6) + lane, acc, bit, near);
+            exact_signs(unit < U && near, unit << 6, bit);
+            const unsigned long long bm = __ballot(bit);
+            MP_STAMP(stamp, 23);                                     // own unit evaluated
+            unsigned long long* xh = aa.xw + h * aa.xwords;
+            if (unit < U && aa.xmode != 2 && lane == 0) {
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xh, 0, aa.xwords * 8, 0x00020000);
+                const u32x4 pk = {(uint32_t)bm, seq, (uint32_t)(bm >> 32), seq};
+                __builtin_amdgcn_raw_buffer_store_b128(pk, rx, unit * 16, 0, 1);          // sc0: to the XCD's L2
+            }
+            if (tid < 2 * U) {
+                unsigned long long v = 0;
+                bool ok = false;
+                for (int it = 0; it < 96 && !ok; ++it) {             // ~0.13 us per poll
+                    // polled with AGENT-scope loads (sc1): they bypass this CU's L1 and are served by the XCD's L2,
+                    // where the peers' stores land 0.45 us after they were issued, however many workgroups poll the
+                    // same lines (scripts/probes/l2_poll.hip).  A workgroup-scope load (sc0) is served by the L1 from
+                    // the first poll's line for ever, and so is an atomic "or 0", which the compiler turns into one.
+                    v = __hip_atomic_load(xh + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (uint32_t)(v >> 32) == seq;
+                }
+                s_bits[tid] = (uint32_t)v;
+                if (!ok) s_tmp[29] = 0;                              // set to 1 with the other LDS state at the top
+            }
+            __syncthreads();
+            MP_STAMP(stamp, 24);                                     // every word of the head is there (or timed out)
+            have_bits = s_tmp[29] != 0;                              // uniform
+            if (!have_bits) load_planes(tid);                        // on its own after all: pass 0's chunks
+        }
+        if (!have_bits)
         for (int c0 = 0; c0 < KL; c0 += RT_THREADS) {
             const int c = c0 + tid, cn = c + RT_THREADS;
             const int cnc = cn < ha.KLpad ? cn : ha.KLpad - 1;
@@ -579,30 +666,8 @@ __device__ __forceinline__ void lsh_head_body(
 #pragma unroll
                 for (int i = 0; i < CH; ++i) dot8_bf16_chain(acc, q4[i], w[i]);
             }
-            if (c < KL) {
-                for (int kc = CH; kc < chunks; ++kc)                // head_dim 256: remaining chunks
-                    dot8_bf16_chain(acc, q4[kc], Wk4[c + (int64_t)kc * ha.KLpad]);
-                dot_settle(acc);
-                bit = acc > 0.f;
-                near = fabsf(acc) <= (1.0f / 65536.0f) * rn * ha.wnorm[c];   // 2^-16 guard band (simhash.hip SH_EPS)
-            }
-            // exact sign of the columns inside the guard band, one column at a time by the WHOLE wave: lane j
-            // takes elements j*per .. of the dot product (exact f64 products of bf16 pairs), a DPP wave sum adds
-            // them (exact and order-free).  One parallel round of loads: ~0.6 us.  The same loop run by the owning
-            // thread alone (16 dependent 16-byte loads) took ~2.5 us, and with eight members per head almost every
-            // cluster had such a member somewhere -- it was the tail of the whole launch.
-            for (unsigned long long fm = __ballot(near); fm; fm &= fm - 1) {   // wave-uniform
-                const int src = __ffsll((long long)fm) - 1;
-                const int cs = c0 + (wave << 6) + src;
-                const int d0 = lane * per;
-                const uint16_t* wp = ha.Wk + ((int64_t)(d0 >> 3) * ha.KLpad + cs) * 8 + (d0 & 7);
-                const uint16_t* qp = reinterpret_cast<const uint16_t*>(s_q) + d0;
-                double part = 0.0;
-                for (int i = 0; i < per; ++i)
-                    part += (double)bf16_bits_to_f32(qp[i]) * (double)bf16_bits_to_f32(wp[i]);
-                const double ex = wave_sum(part);
-                if (lane == src) bit = ex > 0.0;
-            }
+            finish_column(c, acc, bit, near);
+            exact_signs(near, c0 + (wave << 6), bit);
             const unsigned long long bm = __ballot(bit);
             if (lane == 0) {
                 s_bits[(c0 >> 5) + wave * 2] = (uint32_t)bm;
@@ -666,7 +731,7 @@ __device__ __forceinline__ void lsh_head_body(
             }
 #pragma unroll
             for (int b = 0; b < DG; ++b) v[b] = sg[at[b]];
-            if (HASH == 1 && lead && sl == 0) {
+            if ((HASH == 1 || HASH == 3) && lead && sl == 0) {
 #pragma unroll
                 for (int b = 0; b < DG; ++b) {
                     const int l = l0 + (b * RT_WAVES + wave) * 2 + half;
@@ -741,7 +806,7 @@ __device__ __forceinline__ void lsh_head_body(
             int code;
             if (HASH != 0) {
                 code = code_of(l);
-                if (HASH == 1 && lead) ha.codes_out[h * L + l] = code;
+                if ((HASH == 1 || HASH == 3) && lead) ha.codes_out[h * L + l] = code;
             } else {
                 code = query[h * L + l];
             }
@@ -951,7 +1016,11 @@ __device__ __forceinline__ void lsh_head_body(
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         MP_STAMP(stamp, 38);
         if (ticket != nmem - 1) return;
-        if (lane == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) {
+            __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // split hash: every member is past the exchange -- the next launch gets a new sequence number
+            if (aa.xseq != nullptr) __hip_atomic_fetch_add(aa.xseq + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             mr[u] = -INFINITY;
@@ -1293,7 +1362,11 @@ static hipError_t retrieve_attr_set() {
                          reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, false>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, false>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, true>),
-                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, true>)};
+                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, true>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, false, 3>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, false, 3>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, true, 3>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, true, 3>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -1355,7 +1428,8 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                              int* head_cnt, uint16_t* out, float* mve, float2* head_mz, const int32_t* slots,
                              float* score, int* err, int maxs, int R, bool same_xcd, const uint16_t* win_kv,
                              const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
-                             bool codes_given, hipStream_t st) {
+                             bool codes_given, unsigned long long* xw, unsigned int* xseq, int xwords, int xmode,
+                             hipStream_t st) {
     const int range_len = lsh_range_len(M, R);
     const int words = range_len / 32;
     const int Lpad = (L + 63) & ~63;
@@ -1366,8 +1440,12 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     if ((1 << clog) != R || R > 8) return hipErrorInvalidValue;
     const bool sx = same_xcd && clog > 0 && BH % 8 == 0 && xcd_round_robin_verified();
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
+    // planes split over the cluster + exchange of the sign bits through the XCD's L2: only where the members of a
+    // cluster share an XCD (sx) and every unit of 64 planes finds a wave (K*L <= 1024 R)
+    const bool split_hash = xmode != 0 && sx && xw != nullptr && xseq != nullptr && !codes_given &&
+                            ((K * L + 63) / 64) <= (RT_WAVES << clog) && 2 * ((K * L + 63) / 64) <= xwords;
     AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, slots, score, err, BH, maxs,
-                   DECODE_ID_CAP, clog, sx ? 1 : 0, win_kv, win_len, win_M};
+                   DECODE_ID_CAP, clog, sx ? 1 : 0, split_hash ? xw : nullptr, split_hash ? xseq : nullptr, xwords, xmode, win_kv, win_len, win_M};
     const dim3 grid((unsigned)BH << clog);
     const size_t lds = decode_lds_bytes(range_len, L, D);
     if (codes_given) {   // A/B: the codes and ||q|| come from simhash_query_kernel (plain decode only)
@@ -1380,11 +1458,15 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                                results, nnz, G, L, NB, M, R, range_len, words, Lpad, ha, aa, g_stamp);
         return hipGetLastError();
     }
-#define MP_DECODE_CASE(DD, CHH, WW)                                                                         \
-    if (D == DD && (win_kv != nullptr) == WW) {                                                             \
-        hipLaunchKernelGGL((lsh_decode_kernel<CHH, DD, WW>), grid, dim3(RT_THREADS), lds, st, bounds, table, \
-                           results, nnz, G, L, NB, M, R, range_len, words, Lpad, ha, aa, g_stamp);          \
-        return hipGetLastError();                                                                           \
+#define MP_DECODE_CASE(DD, CHH, WW)                                                                            \
+    if (D == DD && (win_kv != nullptr) == WW) {                                                                \
+        if (split_hash)                                                                                        \
+            hipLaunchKernelGGL((lsh_decode_kernel<CHH, DD, WW, 3>), grid, dim3(RT_THREADS), lds, st, bounds,   \
+                               table, results, nnz, G, L, NB, M, R, range_len, words, Lpad, ha, aa, g_stamp);  \
+        else                                                                                                   \
+            hipLaunchKernelGGL((lsh_decode_kernel<CHH, DD, WW>), grid, dim3(RT_THREADS), lds, st, bounds,      \
+                               table, results, nnz, G, L, NB, M, R, range_len, words, Lpad, ha, aa, g_stamp);  \
+        return hipGetLastError();                                                                              \
     }
     MP_DECODE_CASE(128, 16, false)
     MP_DECODE_CASE(128, 16, true)

@@ -775,6 +775,39 @@ def test_fused_decode_direct_slots_and_overflow(mp, K, L, n, M, direct):
             assert np.allclose(probs1[h, :z].cpu().numpy(), probs2[h, :z].cpu().numpy(), rtol=2e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize("B,H,Hkv,D,K,L", [(1, 32, 8, 128, 10, 150), (1, 8, 1, 128, 11, 300), (1, 16, 4, 64, 9, 40),
+                                           (2, 8, 2, 128, 7, 26)])
+def test_decode_with_planes_split_over_the_cluster(mp, B, H, Hkv, D, K, L):
+    """decode_split_hash: every member of a head's cluster evaluates 1/R of the hyperplanes and the sign bits are
+    exchanged through the XCD's L2 (64-bit words tagged with the launch's sequence number).  Modes 1 (split), 2
+    (split, but nobody publishes: every member times out and hashes alone) and 0 (off) must give bit-identical
+    codes, nnz, outputs and LSE, launch after launch (the sequence number advances)."""
+    import magicpig_amd._lib as L_
+
+    n, M = 6000, 6144
+    server, _ = _fused_server(mp, B, H, Hkv, n, M, D, K, L, 600 + K)
+    assert server.lsh_retriever.R > 1
+    BH = B * H
+    gen = torch.Generator(device="cuda").manual_seed(K + L)
+    qs = torch.randn((5, B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16)
+    ref = []
+    try:
+        for mode in (0, 1, 2, 1):
+            L_.set_option("decode_split_hash", mode)
+            for i in range(5):
+                out, lse = server.decode(qs[i], 0)
+                got = (out.clone(), lse.clone(), server.nnz.clone())
+                if mode == 0:
+                    ref.append(got)
+                else:
+                    assert torch.equal(got[2], ref[i][2]), (mode, i)
+                    assert torch.equal(got[0], ref[i][0]) and torch.equal(got[1], ref[i][1]), (mode, i)
+        server.attn_server.check()
+    finally:
+        L_.set_option("decode_split_hash", -1)
+    assert int(torch.stack([r[2] for r in ref]).sum()) > 0
+
+
 @pytest.mark.parametrize("B,H,Hkv,D", [(1, 32, 8, 128), (8, 32, 8, 128), (2, 6, 3, 64)])
 def test_decode_with_mfma_hash_launch_equals_fused_hash(mp, B, H, Hkv, D):
     """The decode entry with the query SimHash computed by the MFMA kernel in a launch of its own
