@@ -428,7 +428,7 @@ struct AttnArgs {
     const int32_t* slots;    // [B*Hkv][L][NB][R][32] direct piece slots (R > 1, short pieces) or nullptr
     float* score;            // [BH][M] (nullable); member r's logits start at column r * range_len
     int* err;                // device flag: bit 4 = a cluster member ran on another XCD than observed
-    int BH, maxs, cap, cluster_log2;   // cap: ids of the LDS stage (multiple of AH_SLICE)
+    int BH, BHp, maxs, cap, cluster_log2;   // BHp: heads per rank in the grid (BH padded to 8 when R > 1); cap: ids of the LDS stage (multiple of AH_SLICE)
     int same_xcd;            // the members of a cluster share one XCD (and its L2): verified by the host
     unsigned long long* xw;  // split hash: [BH][xwords] (launch sequence << 32 | 32 sign bits) exchanged by a cluster
     unsigned int* xseq;      // split hash: [BH] sequence number of the current launch (the merger advances it)
@@ -473,8 +473,12 @@ __device__ __forceinline__ void lsh_head_body(
     uint32_t* s_qraw = reinterpret_cast<uint32_t*>(s_tk + 4);   // AD: the raw query row (bf16 pairs), 16-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t h = (AD > 0) ? (int64_t)(blockIdx.x % aa.BH) : (int64_t)blockIdx.x;
-    const int rank = (AD > 0) ? (int)(blockIdx.x / aa.BH) : 0;
+    // decode: the grid is R x BHp blocks, BHp = B*H rounded up to a multiple of 8 when R > 1, so that the members of
+    // a cluster (blocks h, h + BHp, ...) share the residue b % 8 -- one XCD -- whatever B*H is; the padding blocks leave
+    const int BHp = (AD > 0) ? aa.BHp : 1;
+    const int64_t h = (AD > 0) ? (int64_t)(blockIdx.x % BHp) : (int64_t)blockIdx.x;
+    const int rank = (AD > 0) ? (int)(blockIdx.x / BHp) : 0;
+    if (AD > 0 && h >= aa.BH) return;
     const int clog = (AD > 0) ? aa.cluster_log2 : 0;
     const bool lead = rank == 0;                              // the member that writes codes / ||q||
     const int64_t g = h / G;
@@ -1438,15 +1442,16 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     int clog = 0;
     while ((1 << clog) < R) ++clog;
     if ((1 << clog) != R || R > 8) return hipErrorInvalidValue;
-    const bool sx = same_xcd && clog > 0 && BH % 8 == 0 && xcd_round_robin_verified();
+    const int BHp = clog > 0 ? (BH + 7) & ~7 : BH;
+    const bool sx = same_xcd && clog > 0 && xcd_round_robin_verified();
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
     // planes split over the cluster + exchange of the sign bits through the XCD's L2: only where the members of a
     // cluster share an XCD (sx) and every unit of 64 planes finds a wave (K*L <= 1024 R)
     const bool split_hash = xmode != 0 && sx && xw != nullptr && xseq != nullptr && !codes_given &&
                             ((K * L + 63) / 64) <= (RT_WAVES << clog) && 2 * ((K * L + 63) / 64) <= xwords;
-    AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, slots, score, err, BH, maxs,
+    AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, slots, score, err, BH, BHp, maxs,
                    DECODE_ID_CAP, clog, sx ? 1 : 0, split_hash ? xw : nullptr, split_hash ? xseq : nullptr, xwords, xmode, win_kv, win_len, win_M};
-    const dim3 grid((unsigned)BH << clog);
+    const dim3 grid((unsigned)BHp << clog);
     const size_t lds = decode_lds_bytes(range_len, L, D);
     if (codes_given) {   // A/B: the codes and ||q|| come from simhash_query_kernel (plain decode only)
         if (win_kv != nullptr) return hipErrorInvalidValue;

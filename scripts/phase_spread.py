@@ -25,7 +25,8 @@ for li in range(NLAYER):
         vc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
         server.fill(li, b, kc, vc, P); server.build_table(li, b, P)
 R = server.lsh_retriever.R
-grid = B * H * R
+BHp = (B * H + 7) // 8 * 8 if R > 1 else B * H     # the launch pads the heads per rank to a multiple of 8
+grid = BHp * R
 STRIDE = 64
 stamp = torch.zeros(grid * STRIDE, dtype=torch.int64, device=dev)
 qs = torch.randn((reps, NLAYER, B, H, 1, D), device=dev).to(torch.bfloat16)
@@ -56,5 +57,5 @@ BH = B * H
 for i, nm in enumerate(names):
     x = a[:, :, i]
     st = [np.nanmedian(f(x, axis=1)) for f in (np.nanmin, np.nanmedian, lambda v, axis: np.nanpercentile(v, 90, axis=axis), np.nanmax)]
-    r0 = np.nanmedian(x[:, :BH]); ro = np.nanmedian(x[:, BH:]) if R > 1 else float("nan")
+    r0 = np.nanmedian(x[:, :BHp]); ro = np.nanmedian(x[:, BHp:]) if R > 1 else float("nan")
     print(f"{nm:>16} {st[0]:7.2f} {st[1]:7.2f} {st[2]:7.2f} {st[3]:7.2f}   {r0:7.2f} / {ro:7.2f}")

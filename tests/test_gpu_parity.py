@@ -624,7 +624,7 @@ def _fused_server(mp, B, H, Hkv, n, M, D, K, L, seed):
 @pytest.mark.parametrize("B,H,Hkv", [(1, 32, 8), (1, 8, 2), (2, 6, 3)])
 def test_fused_decode_cluster_handoff_is_deterministic(mp, B, H, Hkv):
     """The one-launch decode entry spreads a head over a cluster of workgroups whose states meet
-    through L2 (same-XCD hand-off when B*H is a multiple of 8, write-through otherwise): 40 launches
+    through L2 (the grid pads B*H to a multiple of 8 so that the members share an XCD): 40 launches
     on changing queries, each repeated, must be bit-identical run to run and agree with the
     two-kernel path (same ids, same math, different summation order)."""
     n, M, D, K, L = 6000, 6144, 128, 8, 75
@@ -703,7 +703,7 @@ def test_fused_decode_under_graph_replay_keeps_the_cluster_checks_quiet(mp, B, H
 @pytest.mark.parametrize("B,H,Hkv,D,K,L,n,M", [
     (1, 4, 2, 64, 4, 1100, 600, 640),        # more tables than threads in a workgroup, head_dim 64
     (2, 8, 8, 128, 15, 12, 3000, 3001),      # widest codes, odd max_length, no GQA
-    (3, 6, 2, 64, 9, 33, 2000, 2048),        # B*H not a multiple of 8: agent-scope hand-off, head_dim 64
+    (3, 6, 2, 64, 9, 33, 2000, 2048),        # B*H not a multiple of 8: padded grid, head_dim 64
     (1, 1, 1, 128, 6, 50, 70, 64 * 3),       # one head, a list shorter than the cluster
 ])
 def test_fused_decode_unusual_shapes_equal_two_kernel_path(mp, B, H, Hkv, D, K, L, n, M):
