@@ -1039,11 +1039,18 @@ __device__ __forceinline__ void lsh_head_body(
                 if (VPL == 2)
                     ob[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (u * ADD + lane * 2 + 1) * 4, 0, kSc0));
                 cr[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rc, u * 4, 0, kSc0);
-                // a member on another XCD (a placement the host did not observe): its partial may be stale in this L2
-                if (lane == 0 && ((uint32_t)cr[u] >> 24) != my_xcc) atomicOr(aa.err, 4);
-                cr[u] &= 0xffffff;
             }
         }
+        // (checked AFTER all loads are in flight: a use inside the loop made every member's loads wait for the
+        // previous member's -- eight dependent L2 round trips, ~1 us of the merger's 2)
+        bool misplaced = false;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            // a member on another XCD (a placement the host did not observe): its partial may be stale in this L2
+            if (u < nmem) misplaced = misplaced || ((uint32_t)cr[u] >> 24) != my_xcc;
+            cr[u] &= 0xffffff;
+        }
+        if (lane == 0 && misplaced) atomicOr(aa.err, 4);
     } else {
         __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + lane * VPL),
                            __float_as_uint(o0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
