@@ -290,11 +290,14 @@ __device__ __forceinline__ void attn_head_fold(
 // o[lane * VPL ..] of sum_j exp(z_j - m) V[j] -- and the other waves are done (they have nothing left to do in
 // the kernels that use this: a hand-off by ONE wave needs no further workgroup barrier).  m = -inf, Z = 0 when
 // the workgroup had no slice.
-template <int D, int NW>
+// FULL: the workgroup has exactly NW waves -- the reads below are then straight-line code; with a run-time wave
+// count every read sits behind a branch, and the compiler puts an s_waitcnt vmcnt(0) in front of each, i.e. wave 0
+// first waits for the acknowledgement of the score stores of its last step (~0.5 us on the path to the hand-off).
+template <int D, int NW, bool FULL = false>
 __device__ __forceinline__ void attn_head_merge(const AhState& st, float* s_merge, float& m_out,
                                                 float& Z_out, float& o0_out, float& o1_out) {
     constexpr int VPL = D / 64;          // 2 (D = 128) or 1 (D = 64)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = FULL ? NW : (int)(blockDim.x >> 6);
     float* mine = s_merge + wave * (D + 2);
     mine[st.d0] = st.o0;
     if (D / 8 == 16) mine[st.d0 + 1] = st.o1;
@@ -313,7 +316,7 @@ __device__ __forceinline__ void attn_head_merge(const AhState& st, float* s_merg
         float mw[NW], lw[NW], oa[NW], ob[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const bool live = w < nw;
+            const bool live = FULL || w < nw;
             mw[w] = live ? s_merge[w * (D + 2) + D] : -INFINITY;
             lw[w] = live ? s_merge[w * (D + 2) + D + 1] : 0.f;
             if (VPL == 2) {

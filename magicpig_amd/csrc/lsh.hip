@@ -969,7 +969,7 @@ __device__ __forceinline__ void lsh_head_body(
         attn_head_fold<ADD, RT_WAVES, true, AH_SLICE>(st, aa.win_kv + g * aa.win_M * 2 * ADD, nullptr, qv, 1.f, wlen,
                                                       aa.win_M, 0, 0, rank, 1 << clog, none, nullptr, stamp);
     }
-    attn_head_merge<ADD, RT_WAVES>(st, s_merge, m, Z, o0, o1);
+    attn_head_merge<ADD, RT_WAVES, true>(st, s_merge, m, Z, o0, o1);
     MP_STAMP(stamp, 40);   // the waves' states have met in LDS (the barrier waits for the wave whose rows came last)
     // from here on WAVE 0 alone holds the workgroup's state: one wave needs no workgroup barrier to order its
     // own stores, ticket and loads, and the other fifteen are done
