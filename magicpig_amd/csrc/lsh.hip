@@ -835,27 +835,51 @@ __device__ __forceinline__ void lsh_head_body(
     MP_STAMP(stamp, 17);
     MP_STAMP(stamp, 18);
 
-    // stream the probed pieces: wave w owns tables w, w+16, ...; per round it keeps RT_GROUP
-    // pieces x 2 chunks of 64 ids (<= 128 ids per piece) in flight, then applies them
-    for (int l0 = wave; l0 < L; l0 += RT_WAVES * RT_GROUP) {
+    // stream the probed pieces: wave w owns tables w, w+16, ...; per round it keeps RT_GROUP pieces x 64 ids in
+    // flight (the second 64 ids of a piece only where that piece is longer), then applies them.  Straight-line
+    // rounds: all (start, length) pairs out of LDS, then all loads -- unconditional: a lane past its piece re-reads
+    // the piece's first id (same cache line as its neighbours: no extra request) and applies nothing -- then all
+    // applies.  As one loop body per piece with the loads under lane-divergent branches the compiler put an
+    // s_waitcnt vmcnt(0) between the pieces: two, not twelve, were in flight.
+    {
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    for (int l0 = wave_s; l0 < L; l0 += RT_WAVES * RT_GROUP) {
         int32_t id0[RT_GROUP], id1[RT_GROUP];
+        int ln[RT_GROUP], sa[RT_GROUP];
 #pragma unroll
         for (int b = 0; b < RT_GROUP; ++b) {
             const int l = l0 + b * RT_WAVES;
-            id0[b] = -1;
-            id1[b] = -1;
-            if (l < L) {
-                const int len = s_len[l];
-                const int32_t* row = tab + (int64_t)l * M + s_start[l];
-                if (lane < len) id0[b] = row[lane];
-                if (lane + 64 < len) id1[b] = row[lane + 64];
-            }
+            const int lc = l < L ? l : L - 1;
+            ln[b] = s_len[lc];
+            sa[b] = s_start[lc];
         }
 #pragma unroll
         for (int b = 0; b < RT_GROUP; ++b) {
-            apply(id0[b]);
-            apply(id1[b]);
+            const int l = l0 + b * RT_WAVES;
+            const int lc = l < L ? l : L - 1;
+            ln[b] = l < L ? __builtin_amdgcn_readfirstlane(ln[b]) : 0;       // wave-uniform: one table per wave
+            sa[b] = __builtin_amdgcn_readfirstlane(sa[b]);
+            const int32_t* row = tab + (int64_t)lc * M + sa[b];
+            id0[b] = row[lane < ln[b] ? lane : 0];
         }
+        // applied in issue order: the first piece's ids are counted while the last piece's are still on their way
+#pragma unroll
+        for (int b = 0; b < RT_GROUP; ++b) apply(lane < ln[b] ? id0[b] : -1);
+        bool longer = false;
+#pragma unroll
+        for (int b = 0; b < RT_GROUP; ++b) longer = longer || ln[b] > 64;
+        if (longer) {                                                        // wave-uniform
+#pragma unroll
+            for (int b = 0; b < RT_GROUP; ++b) {
+                const int l = l0 + b * RT_WAVES;
+                const int lc = l < L ? l : L - 1;
+                const int32_t* row = tab + (int64_t)lc * M + sa[b];
+                id1[b] = row[lane + 64 < ln[b] ? lane + 64 : 0];
+            }
+#pragma unroll
+            for (int b = 0; b < RT_GROUP; ++b) apply(lane + 64 < ln[b] ? id1[b] : -1);
+        }
+    }
     }
     }
     // ids beyond the first 128 of a piece (skewed data): pooled 64-id chunks, waves take them
