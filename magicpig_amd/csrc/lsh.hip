@@ -550,6 +550,10 @@ __device__ __forceinline__ void lsh_head_body(
             for (int i = 0; i < CH; ++i) w[i] = Wk4[cc + (int64_t)i * ha.KLpad];
         };
         load_planes(split ? (unit << 6) + lane : tid);
+        // the column norm of the first column this thread decides: fetched here, under the query row's round trip (as a
+        // load behind the dot chain its L2 latency sat between the dots and the sign)
+        const int col_first = split ? (unit << 6) + lane : tid;
+        const float wn_first = ha.wnorm[col_first < ha.KLpad ? col_first : ha.KLpad - 1];
         // -- normalise the query row
         if (wave == 0) {
             const uint16_t e[4] = {(uint16_t)(e01 & 0xffffu), (uint16_t)(e01 >> 16),
@@ -611,7 +615,8 @@ __device__ __forceinline__ void lsh_head_body(
                     dot8_bf16_chain(acc, q4[kc], Wk4[c + (int64_t)kc * ha.KLpad]);
                 dot_settle(acc);
                 bit = acc > 0.f;
-                near = fabsf(acc) <= (1.0f / 65536.0f) * rn * ha.wnorm[c];   // 2^-16 guard band (simhash.hip SH_EPS)
+                const float wn = (c == col_first) ? wn_first : ha.wnorm[c];
+                near = fabsf(acc) <= (1.0f / 65536.0f) * rn * wn;    // 2^-16 guard band (simhash.hip SH_EPS)
             }
         };
         bool have_bits = false;
@@ -1125,7 +1130,6 @@ __device__ __forceinline__ void lsh_head_body(
         mm = fmaxf(mm, mr[u]);
         csum += cr[u];
     }
-    if (lane == 0) nnz[h] = csum;
     float ZZ = 0.f, q0 = 0.f, q1 = 0.f;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1137,6 +1141,7 @@ __device__ __forceinline__ void lsh_head_body(
         }
     }
     attn_head_finalize<ADD>(mm, ZZ, q0, q1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);   // ZZ = 0: no member had a token
+    if (lane == 0) nnz[h] = csum;
     MP_STAMP(stamp, 39);
 }
 
