@@ -491,6 +491,21 @@ __device__ __forceinline__ void lsh_head_body(
     const int64_t trem = M - t0;
     const uint32_t tlen = (AD > 0) ? (uint32_t)(trem <= 0 ? 0 : (trem < range_len ? trem : range_len)) : (uint32_t)M;
 
+    // -- the query row FIRST (its round trip heads the dependent chain: q -> norm -> LDS -> dots): wave 0, D/64
+    //    elements per lane (D = 64, 128 or 256).  Requested before anything else touches the kernel arguments: they
+    //    arrive in half a dozen dependent scalar loads, and behind them the row was requested ~1 us into the kernel.
+    uint32_t e01 = 0u, e23 = 0u;                                 // elements 0,1 | 2,3 of this lane (bf16 pairs)
+    if ((HASH == 1 || HASH == 3) && wave == 0) {                 // ONE load per lane, no loop: nothing to wait for here
+        const int per0 = ha.D >> 6;
+        const uint16_t* src = ha.q + h * ha.D + lane * per0;
+        if (per0 == 2) e01 = *reinterpret_cast<const uint32_t*>(src);
+        else if (per0 == 1) e01 = *src;
+        else {
+            const uint2 t = *reinterpret_cast<const uint2*>(src);
+            e01 = t.x;
+            e23 = t.y;
+        }
+    }
     MP_STAMP(stamp, 16);
     if (tid == 0) {
         *s_ntail = 0;
@@ -513,20 +528,7 @@ __device__ __forceinline__ void lsh_head_body(
         const int D = ha.D, KL = ha.K * L;
         const int chunks = D >> 3;                              // 16-byte plane chunks per hyperplane
         const u32x4* Wk4 = reinterpret_cast<const u32x4*>(ha.Wk);
-        // -- the query row first (its round trip heads the dependent chain: q -> norm -> LDS -> dots):
-        //    wave 0, D/64 elements per lane (D = 64, 128 or 256)
-        const int per = D >> 6;
-        uint32_t e01 = 0u, e23 = 0u;                             // elements 0,1 | 2,3 of this lane (bf16 pairs)
-        if (wave == 0) {                                         // ONE load per lane, no loop: nothing to wait for here
-            const uint16_t* src = ha.q + h * D + lane * per;
-            if (per == 2) e01 = *reinterpret_cast<const uint32_t*>(src);
-            else if (per == 1) e01 = *src;
-            else {
-                const uint2 t = *reinterpret_cast<const uint2*>(src);
-                e01 = t.x;
-                e23 = t.y;
-            }
-        }
+        const int per = D >> 6;                                  // (the query row was requested at the top of the kernel)
         // -- the first pass's hyperplane chunks do not depend on q: put them in flight next.  All
         //    plane loads of this prologue are UNCONDITIONAL on clamped indices (columns >= KL of Wk are
         //    zero): with loads under divergent branches the compiler cannot count what is outstanding
