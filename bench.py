@@ -55,6 +55,44 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
+# --data: what the synthetic keys look like.  randn = isotropic Gaussian keys, Gaussian queries: the
+# most uniform buckets SimHash can see, 1.56 % selected at cfg 1.  clustered / skewed = keys as a KV cache holds them
+# after RoPE -- per-dimension offset (removed by the centring), anisotropic spectrum s_d ~ (1 + d)^-alpha, a mixture
+# of cluster centres with unequal populations, a low-rank component shared by all tokens -- with heavy-hitter queries
+# 0.5 q + 3 k_j (tests/synth.py: clustered_raw_bits is the same generator in numpy; scripts/tune_clustered.py tuned
+# `clustered` to the README's ~2 % sampling rate at K10 L150, /root/reference/README.md:43; `skewed` is a stress
+# case: ~8 % selected, 3.7 % of the probed (table, bucket, range) pieces longer than 126 ids).
+DATA = {
+    "randn": None,
+    "clustered": dict(alpha=0.2, a=0.5, b=0.2, clusters=64, rank=4),
+    "skewed": dict(alpha=0.5, a=1.0, b=0.5, clusters=64, rank=4),
+}
+
+
+def synth_kv(data, P, Hkv, D, dev, gen):
+    """One request's token-major KV cache, bf16 [P, Hkv, D] x 2, drawn on the device."""
+    vc = None
+    if DATA[data] is None:
+        kc = torch.randn((P, Hkv, D), device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+        vc = torch.randn((P, Hkv, D), device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+        return kc, vc
+    p = DATA[data]
+    f32 = dict(device=dev, dtype=torch.float32, generator=gen)
+    sd = (1.0 + torch.arange(D, device=dev, dtype=torch.float32)) ** (-p["alpha"])
+    sd = sd / sd.square().mean().sqrt()
+    raw = torch.randn((P, Hkv, D), **f32) * sd
+    C = torch.randn((Hkv, p["clusters"], D), **f32) * sd
+    cid = torch.minimum(torch.randint(0, p["clusters"], (P, Hkv), device=dev, generator=gen),
+                        torch.randint(0, p["clusters"], (P, Hkv), device=dev, generator=gen))
+    raw += p["a"] * C[torch.arange(Hkv, device=dev)[None, :], cid]
+    U = torch.randn((Hkv, p["rank"], D), **f32) * sd
+    w = torch.randn((P, Hkv, p["rank"]), **f32)
+    raw += p["b"] * torch.einsum("phr,hrd->phd", w, U)
+    raw *= 1.0 / (1.0 + p["a"] ** 2 + p["rank"] * p["b"] ** 2) ** 0.5
+    raw += 0.75 * torch.randn((1, Hkv, D), **f32)
+    vc = torch.randn((P, Hkv, D), **f32).to(torch.bfloat16)
+    return raw.to(torch.bfloat16), vc
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -62,6 +100,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--config", default="cfg1", choices=sorted(CONFIGS))
+    ap.add_argument("--data", default="randn", choices=sorted(DATA),
+                    help="synthetic key distribution: randn (isotropic), clustered (anisotropic clusters + low-rank "
+                         "component, ~2 %% selected at cfg 1), skewed (stress)")
+    ap.add_argument("--queries", default="auto", choices=["auto", "randn", "heavy"],
+                    help="randn queries or heavy hitters 0.5 q + 3 k_j (SURVEY.md 8(d)); auto: randn with --data randn, "
+                         "heavy otherwise")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8192,
@@ -306,10 +350,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
-        import torch.distributed as dist
+    if world > 1 or "WORLD_SIZE" in os.environ:     # launched under torch.distributed.run (also with ONE rank: the
+        import torch.distributed as dist             # RCCL path -- broadcast, barrier, f64 MAX, all_gather -- runs as with N)
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     import magicpig_amd._lib as L
@@ -357,8 +403,7 @@ def main():
     for li in range(NL):
         for b in range(B):
             gen = torch.Generator(device=dev).manual_seed(1000 * (rank + 1) + 37 * li + b)
-            kc = torch.randn((P, Hkv, D), device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
-            vc = torch.randn((P, Hkv, D), device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+            kc, vc = synth_kv(args.data, P, Hkv, D, dev, gen)
             server.fill(li, b, kc, vc, P)
             server.build_table(li, b, P)
             del kc, vc
@@ -367,7 +412,17 @@ def main():
 
     NQ = 16
     gen = torch.Generator(device=dev).manual_seed(2000 + rank)
-    qs = torch.randn((NQ, NL, B, H, 1, D), device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+    qs = torch.randn((NQ, NL, B, H, 1, D), device=dev, dtype=torch.float32, generator=gen)
+    heavy = args.queries == "heavy" or (args.queries == "auto" and args.data != "randn")
+    if heavy:   # every query is pulled toward one (centred) key of its kv group: q <- 0.5 q + 3 k_j
+        G = H // Hkv
+        bi = torch.arange(B, device=dev)[None, :, None].expand(NQ, B, H)
+        gi = (torch.arange(H, device=dev) // G)[None, None, :].expand(NQ, B, H)
+        for li in range(NL):
+            kc = server.attn_server.get_key_cache(li)                              # [B, Hkv, M, D] centred keys
+            j = torch.randint(0, n, (NQ, B, H), device=dev, generator=gen)
+            qs[:, li, :, :, 0] = 0.5 * qs[:, li, :, :, 0] + 3.0 * kc[bi, gi, j].float()
+    qs = qs.to(torch.bfloat16)
     q_static = qs[0].clone()
 
     def step():
@@ -381,7 +436,7 @@ def main():
             torch.cuda.synchronize()
 
     # stats pass (untimed): nnz and candidate counts actually observed on step 0
-    nnz_obs, cand_obs = [], []
+    nnz_obs, cand_obs, piece_obs = [], [], []
     for li in range(NL):
         server.decode(q_static[li], li)
         nnz_obs.append(server.nnz.clone())
@@ -391,10 +446,17 @@ def main():
             g = torch.arange(BH, device=dev) // (H // Hkv)
             be = bounds[g[:, None], torch.arange(Lt, device=dev)[None, :], codes.long()]   # [BH, L, R + 1]
             cand_obs.append((be[..., -1] - be[..., 0]).sum(-1))
+            piece_obs.append((be[..., 1:] - be[..., :-1]).flatten())   # (table, bucket, token range) pieces probed
     torch.cuda.synchronize()
     nnz_all = torch.stack(nnz_obs).float()
     nnz_mean = float(nnz_all.mean())
     cand_mean = float(torch.stack(cand_obs).float().mean())
+    pieces = torch.cat(piece_obs).float()
+    piece_stats = {"ranges_per_head": int(server.lsh_retriever.R), "mean": float(pieces.mean()),
+                   "p50": float(pieces.quantile(0.5)) if pieces.numel() < (1 << 24) else float(pieces[:1 << 24].quantile(0.5)),
+                   "p99": float(pieces.quantile(0.99)) if pieces.numel() < (1 << 24) else float(pieces[:1 << 24].quantile(0.99)),
+                   "max": float(pieces.max()), "share_gt_30": float((pieces > 30).float().mean()),
+                   "share_gt_126": float((pieces > 126).float().mean())}
 
     server.collect_nnz = False      # no statistics copies inside the timed region
     graph = None
@@ -492,17 +554,22 @@ def main():
                   f" P={P} K{K}L{Lt}",
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "strong" if shard is not None else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "strong" if shard is not None else "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic" if args.data == "randn" else f"synthetic ({args.data} keys, heavy-hitter queries)" if heavy
+                else f"synthetic ({args.data} keys)",
         "config": {"workload": f"{args.config}: {cfg['model']} B={B} P={P} K={K} L={Lt}, "
                                f"{NL} sparse layers/step, H={H} Hkv={Hkv} D={D}, KV+tables resident in HBM",
                    "batch_per_gpu": B, "global_batch": B if shard is not None else B * world,
                    "parallelism": (f"tp{world} (kv heads sharded: {Hkv} of {cfg.get('Hkv_full', Hkv)} kv heads, "
                                    f"{H} of {cfg.get('H_full', H)} query heads per GPU)") if shard is not None
                                   else f"dp{world} (requests sharded)",
-                   "launch": "eager" if graph is None else "hipGraph"},
+                   "launch": "eager" if graph is None else "hipGraph",
+                   "process_group": None if dist is None else f"{dist.get_backend()} x{dist.get_world_size()}"},
         "sparse_attn_us_per_layer": us_per_layer,
         "observed": {"nnz_per_head": nnz_mean, "candidates_per_head": cand_mean,
-                     "selected_fraction": nnz_mean / n, "setup_s": t_setup},
+                     "selected_fraction": nnz_mean / n, "nnz_max_head": float(nnz_all.max()),
+                     "probed_pieces": piece_stats, "key_distribution": args.data,
+                     "queries": "heavy" if heavy else "randn", "setup_s": t_setup},
         "roofline": {"bound": "hbm",
                      "kernel": "lsh_decode_kernel" if fused else "lsh_retrieve_kernel + attn_sparse_kernel",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

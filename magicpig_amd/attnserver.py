@@ -153,6 +153,12 @@ class LSHSparseAttnServer:
             raise L.MagicPigError(6, f"static window full: request(s) {full} would hold more than {self.length} rows")
         self._window_rows = rows
 
+    def replay(self, graph: "torch.cuda.CUDAGraph") -> None:
+        """Replay a hipGraph that captured one decode step (plan() + the layers' decode_full* calls) with the
+        host-side bookkeeping plan() would have done: raises instead of replaying once the window is full."""
+        self.account_steps(1)
+        graph.replay()
+
     def plan(self) -> None:
         """models/attnserver.py:196-198: one more token in every request's window this step.  The static
         window holds sink + local + generation_buffer rows (:25): a step past that raises here -- the
@@ -162,7 +168,9 @@ class LSHSparseAttnServer:
             raise L.MagicPigError(6, f"static window full: request(s) {full} already hold {self.length} rows "
                                      "(num_sink_tokens + num_local_tokens + generation_buffer); "
                                      "raise generation_buffer")
-        self._window_rows = [r + 1 for r in self._window_rows]
+        # under stream capture nothing executes on the device: the host mirror advances per REPLAY (replay())
+        if not torch.cuda.is_current_stream_capturing():
+            self._window_rows = [r + 1 for r in self._window_rows]
         self.kv_last_page_len += 1
         self.window_nnz.copy_(self.kv_last_page_len.repeat_interleave(self.num_attention_heads))
 

@@ -915,6 +915,24 @@ hipError_t launch_attn_append(const uint16_t* k, const uint16_t* v, const int32_
     return hipGetLastError();
 }
 
+// mp_attn_check: the arrival tickets of the in-launch merges (head_cnt) are zero between launches -- the merger of a
+// head resets its counter.  A counter that is not zero means tickets were LOST: the cluster hand-off of
+// lsh_decode_kernel takes them at workgroup scope in its XCD's L2, so members of a cluster that ran on different
+// XCDs each draw ticket 0 from their own L2, nobody merges, nothing is written (and the XCC_ID comparison of the
+// merger, err bit 4, never runs).  Sets err bit 8 and zeroes the counters so that later launches start clean.
+__global__ void attn_ticket_check_kernel(int* __restrict__ head_cnt, int BH, int* __restrict__ err) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < BH && head_cnt[h] != 0) {
+        head_cnt[h] = 0;
+        atomicOr(err, 8);
+    }
+}
+
+hipError_t launch_attn_ticket_check(int* head_cnt, int BH, int* err, hipStream_t st) {
+    hipLaunchKernelGGL(attn_ticket_check_kernel, dim3((BH + 255) / 256), dim3(256), 0, st, head_cnt, BH, err);
+    return hipGetLastError();
+}
+
 hipError_t launch_merge_state(const uint16_t* va, const float* sa, const uint16_t* vb,
                               const float* sb, int R, int D, uint16_t* v, float* s, hipStream_t st) {
     hipLaunchKernelGGL(merge_state_kernel, dim3(R), dim3(128), 0, st, va, sa, vb, sb, R, D, v, s);

@@ -33,7 +33,7 @@ hipError_t set_stamp_stride(int);
 hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
                            int32_t*, int*, hipStream_t);
-hipError_t launch_lsh_unsort(const int16_t*, const int32_t*, int, int64_t, int16_t*, hipStream_t);
+hipError_t launch_lsh_unsort(const int16_t*, const int32_t*, int, int64_t, int16_t*, int*, hipStream_t);
 hipError_t launch_lsh_subbounds(const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int, int32_t*, int32_t*, int*,
                             hipStream_t);
@@ -65,6 +65,7 @@ hipError_t launch_merge_state(const uint16_t*, const float*, const uint16_t*, co
                               int, uint16_t*, float*, hipStream_t);
 hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, int, const uint16_t*, int, int, int, int64_t,
                               uint16_t*, float*, int*, hipStream_t);
+hipError_t launch_attn_ticket_check(int*, int, int*, hipStream_t);
 
 extern unsigned long long* g_stamp;
 
@@ -174,6 +175,8 @@ struct Stage {
     }
 };
 
+constexpr int FILL_BLOCKS = 1024;   // row blocks of mp_attn_fill_offload's column sums
+
 static int alloc_zero(void** p, size_t bytes) {
     MP_HIP_CHECK(hipMalloc(p, bytes ? bytes : 1));
     MP_HIP_CHECK(hipMemset(*p, 0, bytes));
@@ -205,7 +208,6 @@ struct mp_lsh {
     std::vector<int32_t*> bounds;  // per layer [B*Hkv][L][NB][R+1]
     std::vector<int32_t*> table;   // per layer [B*Hkv][L][M]
     std::vector<int32_t*> slots;   // per layer [B*Hkv][L][NB][R][32] direct piece slots, or empty (R = 1 / long pieces)
-    int* part_cnt = nullptr;       // [BH][8] per-member selected counts of the last decode launch
     unsigned long long* xw = nullptr;   // [BH][xwords] split hash: (launch sequence << 32 | 32 sign bits) (R > 1)
     unsigned int* xseq = nullptr;  // [BH] split hash: sequence number of the next launch
     int xwords = 0;
@@ -234,6 +236,8 @@ struct mp_attn {
     float2* part_ml = nullptr;     // [max_slices]
     float2* head_mz = nullptr;     // [BH] (max logit, Z) of the last call
     int* head_cnt = nullptr;       // [BH] arrival tickets of the in-launch merge (zero between calls)
+    int* part_cnt = nullptr;       // [BH][8] selected tokens of every cluster member in the last one-launch decode (owned
+                                   // here, not by the lsh handle: get_score compacts the score rows with it later)
     int* err = nullptr;            // device-side validation flag (append past max_length)
     double* colsum = nullptr;      // [FILL_BLOCKS][Hkv*D] scratch of mp_attn_fill_offload
     Stage small, big;              // host-buffer mode: (q | qn | nnz | offsets | out | mve) and the packed index rows
@@ -374,10 +378,10 @@ static void lsh_free(mp_lsh_t* h) {
     h->bounds.clear();
     h->table.clear();
     h->slots.clear();
-    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->part_cnt, h->xw, h->xseq};
+    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->xw, h->xseq};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->last_query = nullptr; h->err = nullptr; h->codes = nullptr; h->results = nullptr;
-    h->nnz = nullptr; h->qnorm = nullptr; h->part_cnt = nullptr; h->xw = nullptr; h->xseq = nullptr;
+    h->nnz = nullptr; h->qnorm = nullptr; h->xw = nullptr; h->xseq = nullptr;
     h->small.release();
     h->big.release();
     h->allocated = false;
@@ -446,7 +450,6 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
             }
         }
     }
-    if (rc == MP_OK) rc = alloc_zero((void**)&h->part_cnt, BH * 8 * 4);
     h->xwords = 2 * ((K * L + 63) / 64);
     if (rc == MP_OK && h->R > 1) rc = alloc_zero((void**)&h->xw, BH * (size_t)h->xwords * 8);
     if (rc == MP_OK && h->R > 1) {
@@ -532,10 +535,12 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
         DevBuf tok;
         MP_HIP_CHECK(tok.alloc((size_t)rows * n * 2));
         MP_HIP_CHECK(hipMemsetAsync(tok.p, 0xff, (size_t)rows * n * 2, st));      // code -1: a token no id named
-        MP_HIP_CHECK(launch_lsh_unsort((const int16_t*)c, (const int32_t*)i, rows, n, tok.as<int16_t>(), st));
+        MP_HIP_CHECK(launch_lsh_unsort((const int16_t*)c, (const int32_t*)i, rows, n, tok.as<int16_t>(), h->err, st));
         MP_HIP_CHECK(launch_lsh_build(tok.as<int16_t>(), rows, n, h->NB, h->M, h->R, b, t, h->err, st));
-        rc = lsh_read_err(h, st, "mp_lsh_fill");       // a token missing from the id list shows up as code -1
-        if (rc) return rc;
+        // an id outside [0, n) is flagged by the unsort, a token missing from the id list shows up as code -1
+        if (lsh_read_err(h, st, "mp_lsh_fill") != MP_OK)
+            return fail(MP_ERR_DATA, "mp_lsh_fill: a bucket's ids do not ascend (unstable sort) and the ids of a row are "
+                                     "not a permutation of [0, n): the rows cannot be re-sorted on device");
     }
     MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, st));
     if (!h->slots.empty())
@@ -686,10 +691,10 @@ static void attn_free(mp_attn_t* h) {
     for (auto p : h->kn) if (p) (void)hipFree(p);
     h->kv.clear();
     h->kn.clear();
-    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt, h->err, h->colsum};
+    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt, h->err, h->colsum, h->part_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->score = nullptr; h->part_o = nullptr; h->part_ml = nullptr; h->head_mz = nullptr;
-    h->last_nnz = nullptr; h->head_cnt = nullptr; h->err = nullptr; h->colsum = nullptr;
+    h->last_nnz = nullptr; h->head_cnt = nullptr; h->err = nullptr; h->colsum = nullptr; h->part_cnt = nullptr;
     if (h->ind_rows) (void)hipFree(h->ind_rows);
     h->ind_rows = nullptr;
     h->small.release();
@@ -737,6 +742,10 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
     if (rc == MP_OK) rc = alloc_zero((void**)&h->last_nnz, BH * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->head_cnt, BH * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->err, 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->part_cnt, BH * 8 * 4);
+    // scratch of mp_attn_fill_offload (8 MB at Llama shapes): here, not lazily -- a first call under stream capture
+    // could not allocate
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->colsum, (size_t)FILL_BLOCKS * h->Hkv * h->D * sizeof(double));
     if (rc != MP_OK) { attn_free(h); return rc; }
     // grid.x of the attention kernel: B*H * GX workgroups of 4 waves should fill the chip exactly
     // once (4 resident workgroups per CU at 120 VGPRs): no second dispatch round with a ragged tail.
@@ -784,7 +793,6 @@ int mp_attn_fill(mp_attn_t* h, int layer_id, int request_id, const uint16_t* k, 
 }
 
 // models/attnserver.py:126-175 (sparse-layer branch of fill) for one request, device buffers only
-constexpr int FILL_BLOCKS = 1024;
 
 int mp_attn_fill_offload(mp_attn_t* h, mp_simhash_t* s, int layer_id, int request_id, const uint16_t* key_cache,
                          const uint16_t* value_cache, int64_t seq_len, int num_sink, int num_local,
@@ -805,8 +813,6 @@ int mp_attn_fill_offload(mp_attn_t* h, mp_simhash_t* s, int layer_id, int reques
                    "mp_attn_fill_offload: hasher disagrees on head_dim / device");
     }
     hipStream_t st = (hipStream_t)stream;
-    if (h->colsum == nullptr)
-        MP_HIP_CHECK(hipMalloc((void**)&h->colsum, (size_t)FILL_BLOCKS * h->Hkv * h->D * sizeof(double)));
     int nblk = (int)((n + 63) / 64);
     if (nblk > FILL_BLOCKS) nblk = FILL_BLOCKS;
     uint16_t* kv = h->kv[layer_id] + (size_t)request_id * h->Hkv * h->M * 2 * h->D;
@@ -847,10 +853,17 @@ int mp_attn_check(mp_attn_t* h, mp_stream_t stream) {
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_check: not allocated");
     hipStream_t st = (hipStream_t)stream;
     int flag = 0;
+    // arrival tickets must be zero between launches: a counter left standing means a cluster's tickets were lost
+    // (its members ran on different XCDs and drew from different L2s) -- bit 8; the counters are reset
+    MP_HIP_CHECK(launch_attn_ticket_check(h->head_cnt, h->B * h->H, h->err, st));
     MP_HIP_CHECK(hipMemcpyAsync(&flag, h->err, 4, hipMemcpyDeviceToHost, st));
     MP_HIP_CHECK(hipStreamSynchronize(st));
     if (flag) {
         MP_HIP_CHECK(hipMemsetAsync(h->err, 0, 4, st));
+        if (flag & 8)
+            return fail(MP_ERR_STATE, "mp_attn_check: arrival tickets of an in-launch merge were lost (the workgroups of "
+                                      "a decode cluster ran on different XCDs: stream with a CU mask / partition "
+                                      "change): outputs of those heads were not written; set the decode_agent_scope option");
         if (flag & 4)
             return fail(MP_ERR_STATE, "mp_attn_check: a decode cluster ran on another XCD than the placement "
                                       "observed at alloc (stream with a CU mask / partition change): its hand-off "
@@ -1099,14 +1112,14 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         MP_HIP_CHECK(launch_lsh_decode(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk, s->wnorm, s->D,
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
-                                       lsh->part_cnt, attn->head_cnt, output, max_value_expsum, attn->head_mz,
+                                       attn->part_cnt, attn->head_cnt, output, max_value_expsum, attn->head_mz,
                                        lsh->slots.empty() ? nullptr : lsh->slots[layer_id], attn->score, attn->err, attn_slices_per_head(attn->M), lsh->R,
                                        attn->xcd_rr && g_opt.decode_agent_scope.load() == 0,
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
                                        lsh->L, lsh->NB, lsh->M, mfma_hash, lsh->xw, lsh->xseq, lsh->xwords, xmode, st));
         attn->lastz = lsh->nnz;
         attn->score_state = 1;
-        attn->seg_cnt = lsh->R > 1 ? lsh->part_cnt : nullptr;
+        attn->seg_cnt = lsh->R > 1 ? attn->part_cnt : nullptr;
         attn->seg_R = lsh->R;
     } else {
         // two launches: (hash + retrieve), then attention (models/attnserver.py:264-299, :300)

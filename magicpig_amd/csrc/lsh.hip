@@ -98,14 +98,19 @@ __global__ __launch_bounds__(256) void lsh_fill_kernel(
 
 // codes of a reference-sorted row back in token order (the fallback of mp_lsh_fill when a bucket's ids are
 // not ascending -- torch.sort without stable=True, models/attnserver.py:187): tok[row][ids[k]] = codes[k];
-// the row is then rebuilt by lsh_build_kernel, which emits ascending ids.
+// the row is then rebuilt by lsh_build_kernel, which emits ascending ids.  This path needs the ids of a row to be a
+// permutation of [0, n) (what a sort returns): an id outside sets err bit 1, a token no id named keeps code -1 and is
+// reported by the rebuild.
 __global__ void lsh_unsort_kernel(const int16_t* __restrict__ codes, const int32_t* __restrict__ ids,
-                                  int64_t n, int16_t* __restrict__ tok) {
+                                  int64_t n, int16_t* __restrict__ tok, int* __restrict__ err) {
     const int64_t row = blockIdx.y;
+    bool bad = false;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const int32_t id = ids[row * n + k];
         if (id >= 0 && id < n) tok[row * n + id] = codes[row * n + k];
+        else bad = true;
     }
+    if (bad) atomicOr(err, 1);
 }
 
 // entries 1 .. R-1 of every bucket: first position of the bucket whose token id is >= r * range_len
@@ -742,6 +747,7 @@ __device__ __forceinline__ void lsh_head_body(
             }
 #pragma unroll
             for (int b = 0; b < DG; ++b) v[b] = sg[at[b]];
+            MP_STAMP(stamp, 42);                                     // slot loads issued
             if ((HASH == 1 || HASH == 3) && lead && sl == 0) {
 #pragma unroll
                 for (int b = 0; b < DG; ++b) {
@@ -756,6 +762,8 @@ __device__ __forceinline__ void lsh_head_body(
                 const int p0 = __builtin_amdgcn_readlane(v[b], 1), p1 = __builtin_amdgcn_readlane(v[b], 33);
                 const int pl = half ? c1 : c0;                          // length of the piece
                 const int pp = half ? p1 : p0;                          // its position in the table row
+                if (b == 0) MP_STAMP(stamp, 43);                        // the first slot has arrived
+                if (b == DG - 1) MP_STAMP(stamp, 44);                   // the last one has
                 int rest = 0;
                 if (l < L) {
                     if (sl >= 2 && sl - 2 < pl) apply(v[b]);
@@ -793,6 +801,7 @@ __device__ __forceinline__ void lsh_head_body(
         };
         if (L > RT_WAVES * 2 * 6) direct_pass(std::integral_constant<int, 10>{});
         else direct_pass(std::integral_constant<int, 6>{});
+        MP_STAMP(stamp, 45);                                            // this wave's pieces counted
         __syncthreads();
         MP_STAMP(stamp, 17);
         if (s_tmp[30] > 0) {                                            // uniform; pieces longer than 30 + 96 ids
@@ -1018,7 +1027,10 @@ __device__ __forceinline__ void lsh_head_body(
     // memory side (sc1), which takes three ~0.6 us L2 round trips instead of three ~1.8 us ones.  The
     // host enables it only after xcd_round_robin_verified() has seen the placement on this device, and every
     // launch re-checks that the members of a cluster really ran on ONE XCD: each publishes its XCC_ID next to its
-    // count and the merger compares (err bit 4 otherwise: mp_attn_check reports it).  WHICH XCD a residue lands on
+    // count and the merger compares (err bit 4 otherwise: mp_attn_check reports it).  That comparison needs a merger:
+    // members spread over several XCDs draw their tickets from different L2s, nobody draws the last one, nothing is
+    // merged -- the counters left standing are what mp_attn_check looks for (attn_ticket_check_kernel, err bit 8) and
+    // resets.  WHICH XCD a residue lands on
     // is not fixed -- under graph replay the round robin was observed to start elsewhere than in the probe
     // launches -- only that blocks b and b + 8k share one matters.
     constexpr int VPL = ADD / 64;
@@ -1276,11 +1288,11 @@ hipError_t launch_lsh_fill(const int16_t* codes, const int32_t* ids, int rows, i
 }
 
 hipError_t launch_lsh_unsort(const int16_t* codes, const int32_t* ids, int rows, int64_t n, int16_t* tok,
-                             hipStream_t st) {
+                             int* err, hipStream_t st) {
     int gx = (int)((n + 255) / 256);
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(lsh_unsort_kernel, dim3(gx, rows), dim3(256), 0, st, codes, ids, n, tok);
+    hipLaunchKernelGGL(lsh_unsort_kernel, dim3(gx, rows), dim3(256), 0, st, codes, ids, n, tok, err);
     return hipGetLastError();
 }
 

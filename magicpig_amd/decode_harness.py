@@ -227,14 +227,13 @@ def run_decode_benchmark(decoder: SyntheticLlamaDecoder, prompt_len: int, warmup
         s_ids.copy_(ids[:, done:done + 1]); s_pos.copy_(pos[:, done:done + 1])
         with torch.cuda.graph(graph):
             decoder.inference(s_ids, s_pos)
-        # (a capture records the step without executing it: lengths advance only on replay)
-        decoder.attention_server.account_steps(-1)
+        # (a capture records the step without executing it: plan() leaves its host mirror alone under capture, the
+        # lengths advance per replay -- LSHSparseAttnServer.replay)
 
     def one(i):
         if graph is not None:
             s_ids.copy_(ids[:, i:i + 1]); s_pos.copy_(pos[:, i:i + 1])
-            decoder.attention_server.account_steps(1)     # the replayed plan() advances the device counter
-            graph.replay()
+            decoder.attention_server.replay(graph)        # the replayed plan() advances the device counter
         else:
             decoder.inference(ids[:, i:i + 1], pos[:, i:i + 1])
 

@@ -80,7 +80,7 @@ def sync_hash_func(hash_func: torch.Tensor, src: int = 0) -> torch.Tensor:
     """Every rank must hash with the same hyperplanes: broadcast rank `src`'s tensor
     (evaluations/RULER/pred/attnserver_dist.py:279).  bf16 travels as raw bytes (gloo has no bf16)."""
     dist = _dist()
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None:         # (a one-rank process group still runs the collective: tests/test_gpu_rccl.py)
         return hash_func
     buf = hash_func.contiguous().view(torch.uint8)
     dist.broadcast(buf, src)
@@ -93,7 +93,7 @@ def gather_outputs(local: torch.Tensor, shard: Shard, batch_size: int, num_atten
     dist = _dist()
     D = local.shape[-1]
     local = local.reshape(shard.local_batch, shard.local_heads, D)
-    if dist is None or shard.world_size == 1:
+    if dist is None:
         return local
     full = torch.zeros((batch_size, num_attention_heads, D), dtype=local.dtype, device=local.device)
     # ragged batch blocks: gather through a padded buffer of the largest block
@@ -120,7 +120,7 @@ def gather_outputs(local: torch.Tensor, shard: Shard, batch_size: int, num_atten
 def max_over_ranks(seconds: float, device=None) -> float:
     """The bench's step time is the slowest rank's."""
     dist = _dist()
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None:
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

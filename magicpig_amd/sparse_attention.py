@@ -56,7 +56,12 @@ class SparseAttentionServer:
         L.expect(value_cache[:seq_len], torch.bfloat16, (seq_len, self.Hkv, self.D), "value_cache")
         if not (key_cache.is_cuda and value_cache.is_cuda):
             raise ValueError("fill_offload takes CUDA tensors")
+        if key_cache.device.index != self._device or value_cache.device.index != self._device:
+            raise ValueError(f"fill_offload: caches on {key_cache.device} / {value_cache.device}, the store lives on "
+                             f"cuda:{self._device}")
         n = seq_len - num_sink - num_local
+        if n <= 0:
+            raise ValueError(f"fill_offload: nothing to offload (seq_len {seq_len} <= sink {num_sink} + local {num_local})")
         avg = torch.empty((self.Hkv, 1, self.D), dtype=torch.bfloat16, device=key_cache.device)
         codes = None
         if hasher is not None:

@@ -1,6 +1,6 @@
 """Phase stamps of EVERY workgroup of the decode kernel at a BASELINE config shape: per phase boundary the
 median / max over the workgroups of (stamp - earliest kernel start), i.e. where the critical path runs.
-usage: python scripts/phase_spread.py [cfg1|cfg2|cfg3|cfg4] [reps]"""
+usage: python scripts/phase_spread.py [cfg0|cfg1|cfg2|cfg3|cfg4] [reps] [randn|clustered|skewed]"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,10 +9,11 @@ import magicpig_amd._lib as L
 if os.environ.get("MP_LIB"):
     L.LIB_PATH = os.path.abspath(os.environ["MP_LIB"])
 import magicpig_amd as mp
-from bench import CONFIGS
+from bench import CONFIGS, synth_kv
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg1"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+data = sys.argv[3] if len(sys.argv) > 3 else "randn"
 cfg = CONFIGS[name]
 B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
 dev = torch.device("cuda:0")
@@ -21,24 +22,33 @@ server = mp.LSHSparseAttnServer(NLAYER, H, Hkv, D, K=K, L=Lt, batch_size=B, max_
 for li in range(NLAYER):
     for b in range(B):
         gen = torch.Generator(device=dev).manual_seed(100 * li + b)
-        kc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
-        vc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
+        kc, vc = synth_kv(data, P, Hkv, D, dev, gen)
         server.fill(li, b, kc, vc, P); server.build_table(li, b, P)
 R = server.lsh_retriever.R
 BHp = (B * H + 7) // 8 * 8 if R > 1 else B * H     # the launch pads the heads per rank to a multiple of 8
 grid = BHp * R
 STRIDE = 64
 stamp = torch.zeros(grid * STRIDE, dtype=torch.int64, device=dev)
-qs = torch.randn((reps, NLAYER, B, H, 1, D), device=dev).to(torch.bfloat16)
+qs = torch.randn((reps, NLAYER, B, H, 1, D), device=dev)
+if data != "randn":     # heavy hitters (bench.py --queries heavy)
+    G = H // Hkv
+    bi = torch.arange(B, device=dev)[None, :, None].expand(reps, B, H)
+    gi = (torch.arange(H, device=dev) // G)[None, None, :].expand(reps, B, H)
+    for li in range(NLAYER):
+        kcen = server.attn_server.get_key_cache(li)
+        j = torch.randint(0, P - 68, (reps, B, H), device=dev)
+        qs[:, li, :, :, 0] = 0.5 * qs[:, li, :, :, 0] + 3.0 * kcen[bi, gi, j].float()
+qs = qs.to(torch.bfloat16)
 server.collect_nnz = False
 for r in range(3):
     for li in range(NLAYER): server.decode(qs[r % reps, li], li)
 torch.cuda.synchronize()
 L.set_option("stamp_stride", STRIDE)
 L.check(L.lib().mp_debug_set_stamp_buffer(L.ptr(stamp)))
-slots = [16, 22, 27, 17, 19, 20, 21, 33, 34, 35, 36, 37, 38, 39]
-names = ["start", "normalised", "hashed", "pieces in", "stream done", "scanned", "emitted", "ids staged", "gathers issued",
-         "qk", "transform", "pv", "ticket", "end (merger)"]
+slots = [16, 28, 22, 23, 27, 42, 43, 44, 45, 17, 19, 20, 21, 33, 34, 35, 36, 37, 40, 41, 38, 39]
+names = ["start", "q row in", "normalised", "own unit", "hashed", "slots issued", "first slot in", "last slot in",
+         "wave counted", "pieces in", "stream done", "scanned", "emitted", "ids staged", "gathers issued",
+         "qk", "transform", "pv", "states met", "stores acked", "ticket", "end (merger)"]
 acc = []
 for r in range(reps):
     for li in range(NLAYER):
@@ -51,7 +61,7 @@ for r in range(reps):
 L.check(L.lib().mp_debug_set_stamp_buffer(None))
 L.set_option("stamp_stride", 0)
 a = np.array(acc)                    # [runs, grid, phases]
-print(f"{name}: grid {grid} workgroups (R = {R}); us after the first workgroup's start, median over runs of the per-launch")
+print(f"{name} ({data}): grid {grid} workgroups (R = {R}); us after the first workgroup's start, median over runs of the per-launch")
 print(f"{'phase':>16} {'min':>7} {'median':>7} {'p90':>7} {'max':>7}   rank-0 median / other ranks median")
 BH = B * H
 for i, nm in enumerate(names):

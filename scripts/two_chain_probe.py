@@ -1,7 +1,9 @@
 """A/B: a batch decoded as `chains` independent half-batch launch chains on separate streams (one hipGraph), with an
 optional start skew of the second chain, against one chain.  Meant for an A/B library whose decode workgroups are
 512 threads (two co-resident per CU): MP_LIB=magicpig_amd/lib/libmagicpig_hip_nt512.so.
-usage: python scripts/two_chain_probe.py [cfg2] [chains] [skew_us] [layers] [B]"""
+usage: python scripts/two_chain_probe.py [cfg2] [chains] [skew_us] [layers] [B] [cluster]
+cluster: workgroups per head of every chain (decode_cluster option; 1 = one 1024-thread workgroup per head, so that two
+half-batch chains of 128 heads run on disjoint halves of the CUs)"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,6 +22,8 @@ cfg = CONFIGS[name]
 B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
 if len(sys.argv) > 5:
     B = int(sys.argv[5])                     # batch override (e.g. one half-batch chain alone)
+if len(sys.argv) > 6:
+    L.set_option("decode_cluster", int(sys.argv[6]))
 assert B % chains == 0
 Bc = B // chains
 dev = torch.device("cuda:0")

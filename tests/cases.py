@@ -16,16 +16,34 @@ def load_golden(name: str) -> dict:
         return {k: z[k] for k in z.files}
 
 
-def case_inputs(seed, B, H, Hkv, n, D, K, L):
-    """Identical to make_golden.case_inputs (kept in sync by test_oracle_golden)."""
+DATA_KINDS = ("randn", "clustered", "skewed")     # fixture key `data` holds the index; absent = randn
+
+
+def golden_data(g: dict) -> str:
+    return DATA_KINDS[int(g["data"])] if "data" in g else "randn"
+
+
+def case_keys(seed, Hkv, n, D, data="randn"):
+    """Centred keys + norms of one request: isotropic (synth.centred_keys) or the clustered / skewed workload
+    of SURVEY.md 8(d) (synth.clustered_keys with the CLUSTERED / SKEWED parameters)."""
+    if data == "randn":
+        return synth.centred_keys(seed, Hkv, n, D)
+    return synth.clustered_keys(seed, Hkv, n, D, **(synth.CLUSTERED if data == "clustered" else synth.SKEWED))
+
+
+def case_inputs(seed, B, H, Hkv, n, D, K, L, data="randn"):
+    """Synthetic single-layer inputs shared by tests/golden/make_golden.py and the tests (same seeds, tests/synth.py
+    generator): keys, norms, values, hyperplanes, heavy-hitter queries."""
     keys, kns, vals = [], [], []
     for b in range(B):
-        k, kn = synth.centred_keys(seed + 10 * b, Hkv, n, D)
+        k, kn = case_keys(seed + 10 * b, Hkv, n, D, data)
         keys.append(k)
         kns.append(kn)
         vals.append(synth.normal_bf16_bits(seed + 10 * b + 1, (Hkv, n, D)))
     W = synth.normal_bf16_bits(seed + 7, (D, K * L))
     q = synth.normal_f32(seed + 3, (B * H, D))
+    # heavy hitters: pull each query toward one key of its kv group (SURVEY.md 8d) so a few
+    # tokens have cos ~ 0.9 and the importance weights span several orders of magnitude
     G = H // Hkv
     tgt = synth.randint(seed + 4, 0, n, (B * H,))
     for h in range(B * H):

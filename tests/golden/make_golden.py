@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import synth  # noqa: E402
-from cases import (FILL_CENTRE, FULL_DENSE_CASES, WINDOW_MERGE, fill_centre_inputs,  # noqa: E402
-                   full_dense_inputs, full_dense_seed, window_merge_inputs)
+from cases import (DATA_KINDS, FILL_CENTRE, FULL_DENSE_CASES, WINDOW_MERGE, case_inputs,  # noqa: E402
+                   fill_centre_inputs, full_dense_inputs, full_dense_seed, window_merge_inputs)
 from oracle.build_ref import load_ref, ref_uses_bf16_family  # noqa: E402
 
 
@@ -62,27 +62,6 @@ def torch_khash(offload_key: torch.Tensor, hash_func: torch.Tensor, K: int, L: i
 
 # ----------------------------------------------------------------- case builders
 
-def case_inputs(seed, B, H, Hkv, n, D, K, L):
-    """Synthetic single-layer inputs shared by the generator and the tests."""
-    keys, kns, vals = [], [], []
-    for b in range(B):
-        k, kn = synth.centred_keys(seed + 10 * b, Hkv, n, D)
-        keys.append(k)
-        kns.append(kn)
-        vals.append(synth.normal_bf16_bits(seed + 10 * b + 1, (Hkv, n, D)))
-    W = synth.normal_bf16_bits(seed + 7, (D, K * L))
-    q = synth.normal_f32(seed + 3, (B * H, D))
-    # heavy hitters: pull each query toward one key of its kv group (SURVEY.md 8d) so a few
-    # tokens have cos ~ 0.9 and the importance weights span several orders of magnitude
-    G = H // Hkv
-    tgt = synth.randint(seed + 4, 0, n, (B * H,))
-    for h in range(B * H):
-        b, g = h // H, (h % H) // G
-        q[h] = 0.5 * q[h] + 3.0 * synth.bf16_bits_to_f32(keys[b][g, tgt[h]])
-    qb = synth.f32_to_bf16_bits(q)
-    return np.stack(keys), np.stack(kns), np.stack(vals), W, qb
-
-
 def exact_sign_ties(kcodes: torch.Tensor, keys: np.ndarray, W: np.ndarray, K: int, L: int):
     """Where does torch's bf16 GEMM (f32 accumulation in the library's own order, attnserver.py:159-162)
     disagree with the sign of the EXACT dot product?  Only where the exact value is zero or within f32
@@ -110,8 +89,8 @@ def exact_sign_ties(kcodes: torch.Tensor, keys: np.ndarray, W: np.ndarray, K: in
     return patched, np.array(ties, np.int64).reshape(-1, 6), np.array(dots, np.float64)
 
 
-def run_pipeline(name, seed, B, H, Hkv, n, M, D, K, L, ref_lsh, ref_attn, out):
-    keys, kns, vals, W, qb = case_inputs(seed, B, H, Hkv, n, D, K, L)
+def run_pipeline(name, seed, B, H, Hkv, n, M, D, K, L, ref_lsh, ref_attn, out, data="randn"):
+    keys, kns, vals, W, qb = case_inputs(seed, B, H, Hkv, n, D, K, L, data)
     Wt = synth.to_torch_bf16(W)
     # --- SimHash (torch restatement)
     qcodes = torch_qhash(synth.to_torch_bf16(qb), Wt, K, L).contiguous()
@@ -156,6 +135,8 @@ def run_pipeline(name, seed, B, H, Hkv, n, M, D, K, L, ref_lsh, ref_attn, out):
         mve=mve.numpy().copy(),
         probs=np.concatenate([probs[h, :nz[h]].numpy() for h in range(B * H)]),
     )
+    if data != "randn":
+        out[name]["data"] = np.array(DATA_KINDS.index(data), np.int64)
     print(f"{name}: nnz mean {nz.mean():.1f} min {nz.min()} max {nz.max()}; "
           f"{len(ties)} of {kcodes.numel() * K} key sign bits are summation-order ties")
 
@@ -407,35 +388,94 @@ def run_fill_centre(name, out):
     print(f"{name}: {len(avg_ties)} of {t_avg.size} means and {len(kn_ties)} of {t_kn.size} norms are summation-order ties")
 
 
+def run_cfg1_skew_sha(name, seed, ref_lsh, ref_attn, out):
+    """BASELINE cfg 1 at full size on the CLUSTERED workload (anisotropic clustered keys, heavy-hitter
+    queries, ~2 % selected): B = 1, H = 32, Hkv = 8, n = 97 932, M = 98 304, K10 L150.  Key codes by the torch
+    restatement of models/attnserver.py:159-168 (ties listed and defined by the exact sign, as run_pipeline), tables
+    + retrieve + sparse attention by the compiled reference.  Stored: SHA-256 of the key codes and of (nnz, sorted
+    selected ids), nnz, and the reference's outputs (8 KB) -- the big case is pinned without a big file."""
+    B, H, Hkv, n, M, D, K, L = 1, 32, 8, 97932, 98304, 128, 10, 150
+    keys, kns, vals, W, qb = case_inputs(seed, B, H, Hkv, n, D, K, L, "clustered")
+    Wt = synth.to_torch_bf16(W)
+    qcodes = torch_qhash(synth.to_torch_bf16(qb), Wt, K, L).contiguous()
+    kcodes = torch.stack([torch_khash(synth.to_torch_bf16(keys[b]), Wt, K, L) for b in range(B)])
+    kcodes, ties, tie_dots = exact_sign_ties(kcodes, keys, W, K, L)
+    assert len(ties) <= 1e-7 * kcodes.numel() * K + 1 and (len(ties) == 0 or np.abs(tie_dots).max() < 1e-5)
+    lsh = ref_lsh.LSH()
+    lsh.alloc(K, L, 1, H, Hkv, B, M)
+    sc, si = kcodes[0].sort(stable=True)
+    lsh.fill(0, 0, sc.contiguous(), si.int().contiguous())
+    results = torch.zeros((B * H, M), dtype=torch.int32)
+    nnz = torch.zeros((B * H,), dtype=torch.int32)
+    lsh.batch_retrieve(0, qcodes, results, nnz)
+    srv = ref_attn.SparseAttentionServer()
+    srv.alloc(1, H, Hkv, D, B, M)
+    srv.fill(0, 0, synth.to_torch_bf16(keys[0]), synth.to_torch_bf16(vals[0]), torch.from_numpy(kns[0]))
+    q_t = synth.to_torch_bf16(qb)
+    qn = q_t.float().norm(p=2, dim=-1)
+    output = torch.zeros((B * H, D), dtype=torch.bfloat16)
+    mve = torch.zeros((2, B * H), dtype=torch.float32)
+    srv.attention_wrapper(0, K, L, output, mve, q_t, qn, results, nnz)
+    nz = nnz.numpy()
+    hsh = hashlib.sha256()
+    hsh.update(nz.tobytes())
+    for h in range(B * H):
+        hsh.update(np.sort(results[h, :nz[h]].numpy()).tobytes())
+    out[name] = dict(meta=np.array([seed, B, H, Hkv, n, M, D, K, L], np.int64),
+                     data=np.array(DATA_KINDS.index("clustered"), np.int64), qcodes=qcodes.numpy().astype(np.int32),
+                     kcodes_sha=np.frombuffer(hashlib.sha256(kcodes.numpy().tobytes()).digest(), np.uint8),
+                     kcodes_ties=ties, kcodes_tie_dots=tie_dots, nnz=nz.copy(),
+                     sha256=np.frombuffer(hsh.digest(), np.uint8),
+                     out_bits=output.view(torch.int16).numpy().view(np.uint16).copy(), mve=mve.numpy().copy())
+    print(f"{name}: nnz mean {nz.mean():.1f} ({nz.mean() / n * 100:.2f} %) min {nz.min()} max {nz.max()}; {len(ties)} ties")
+
+
 def main():
     only = set(sys.argv[1:])            # fixture names to (re)generate; none = all
     ref_lsh, ref_attn = load_ref()
     assert ref_uses_bf16_family(), "fixtures are generated with the __AVX512BF16__ build"
-    cases: dict = {}
-    run_qhash_only("qhash_r1_k10_l150", 11, 1, 128, 10, 150, cases)
-    run_qhash_only("qhash_r32_k10_l150", 12, 32, 128, 10, 150, cases)
-    run_qhash_only("qhash_r64_k11_l300", 13, 64, 128, 11, 300, cases)
-    run_qhash_only("qhash_r40_k8_l50", 14, 40, 128, 8, 50, cases)
-    run_qhash_only("qhash_r256_k10_l170", 15, 256, 128, 10, 170, cases)
-    run_lsh_edge("lsh_edge", 21, ref_lsh, cases)
-    run_attn_edge("attn_edge", 31, ref_attn, cases)
-    run_pipeline("lsh_small", 41, 2, 4, 2, 256, 300, 128, 4, 8, ref_lsh, ref_attn, cases)
-    run_pipeline("cfg0", 42, 1, 1, 1, 4096, 4288, 128, 10, 150, ref_lsh, ref_attn, cases)
-    run_pipeline("gqa_32h", 43, 1, 32, 8, 4096, 4288, 128, 10, 150, ref_lsh, ref_attn, cases)
-    run_pipeline("b2_k8_l60", 44, 2, 8, 2, 1500, 1600, 128, 8, 60, ref_lsh, ref_attn, cases)
-    # BASELINE cfg 2 / cfg 3 head counts at a small sequence: B = 8, H = 32, Hkv = 8 -> 256 query heads
-    # (the one-workgroup-per-head / cluster = 1 regime of the decode entry), L = 170 and L = 150
-    run_pipeline("cfg2_small", 45, 8, 32, 8, 2048, 2112, 128, 10, 170, ref_lsh, ref_attn, cases)
-    run_pipeline("cfg3_small", 46, 8, 32, 8, 2048, 2112, 128, 10, 150, ref_lsh, ref_attn, cases)
-    run_cfg1_retrieve_sha("cfg1_retrieve_sha", 51, ref_lsh, cases)
-    run_full_dense("full_dense", 55, ref_attn, cases)
-    run_window_merge("window_merge", cases)
-    run_fill_centre("fill_centre", cases)
+    P = lambda *a, **kw: (lambda name, out: run_pipeline(name, *a, ref_lsh, ref_attn, out, **kw))   # noqa: E731
+    Q = lambda *a: (lambda name, out: run_qhash_only(name, *a, out))                                  # noqa: E731
+    registry = {
+        "qhash_r1_k10_l150": Q(11, 1, 128, 10, 150),
+        "qhash_r32_k10_l150": Q(12, 32, 128, 10, 150),
+        "qhash_r64_k11_l300": Q(13, 64, 128, 11, 300),
+        "qhash_r40_k8_l50": Q(14, 40, 128, 8, 50),
+        "qhash_r256_k10_l170": Q(15, 256, 128, 10, 170),
+        "lsh_edge": lambda name, out: run_lsh_edge(name, 21, ref_lsh, out),
+        "attn_edge": lambda name, out: run_attn_edge(name, 31, ref_attn, out),
+        "lsh_small": P(41, 2, 4, 2, 256, 300, 128, 4, 8),
+        "cfg0": P(42, 1, 1, 1, 4096, 4288, 128, 10, 150),
+        "gqa_32h": P(43, 1, 32, 8, 4096, 4288, 128, 10, 150),
+        "b2_k8_l60": P(44, 2, 8, 2, 1500, 1600, 128, 8, 60),
+        # BASELINE cfg 2 / cfg 3 head counts at a small sequence: B = 8, H = 32, Hkv = 8 -> 256 query heads
+        # (the one-workgroup-per-head / cluster = 1 regime of the decode entry), L = 170 and L = 150
+        "cfg2_small": P(45, 8, 32, 8, 2048, 2112, 128, 10, 170),
+        "cfg3_small": P(46, 8, 32, 8, 2048, 2112, 128, 10, 150),
+        # round 3 -- BASELINE cfg 4's per-GPU geometry and hyper-parameters (70B, TP = 8: 1 kv head, 8 query heads,
+        # K = 11, L = 300 -> G = 8, NB = 2048), a G = 8 case with several kv heads and requests
+        # (library/sparse_attention/test.py:6-14 has G = 8 in its grid), and the non-isotropic workloads of
+        # SURVEY.md 8(d): `skewed` at K = 6 (64 buckets: pieces of hundreds of ids -- slot overflow, second access and
+        # chunk pool of the decode kernel) and `clustered` at K10 L150
+        "cfg4_small": P(47, 1, 8, 1, 4096, 4160, 128, 11, 300),
+        "g8_hkv2": P(48, 2, 16, 2, 1500, 1600, 128, 8, 60),
+        "skew_small": P(49, 1, 8, 2, 4096, 4160, 128, 6, 64, data="skewed"),
+        "clustered_k10": P(50, 1, 32, 8, 8192, 8256, 128, 10, 150, data="clustered"),
+        "cfg1_retrieve_sha": lambda name, out: run_cfg1_retrieve_sha(name, 51, ref_lsh, out),
+        "cfg1_skew_sha": lambda name, out: run_cfg1_skew_sha(name, 52, ref_lsh, ref_attn, out),
+        "full_dense": lambda name, out: run_full_dense(name, 55, ref_attn, out),
+        "window_merge": lambda name, out: run_window_merge(name, out),
+        "fill_centre": lambda name, out: run_fill_centre(name, out),
+    }
+    unknown = only - set(registry)
+    assert not unknown, f"unknown fixtures: {sorted(unknown)}"
     wrote = 0
-    for name, d in cases.items():
+    for name, fn in registry.items():
         if only and name not in only:
             continue
-        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        cases: dict = {}
+        fn(name, cases)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **cases[name])
         wrote += 1
     print("wrote", wrote, "fixtures to", HERE)
 

@@ -79,3 +79,51 @@ def centred_keys(seed: int, Hkv: int, n: int, D: int):
     kn = np.sqrt((kf * kf).sum(-1)).astype(np.float32)
     kn = bf16_bits_to_f32(f32_to_bf16_bits(kn))  # `.norm()` of a bf16 tensor is bf16, then .float()
     return k, kn
+
+
+# ---- the `clustered` workload (bench.py --data clustered): keys as a model's KV cache holds them
+# after RoPE -- a per-dimension offset (removed by the centring), an anisotropic spectrum (per-dimension scale
+# s_d ~ (1 + d)^-alpha; SimHash with Gaussian planes is rotation invariant, so a diagonal spectrum is general), a
+# mixture of `clusters` centres with unequal populations, and a low-rank component shared by all tokens.  Element-wise
+# float64 arithmetic in a fixed order only (no matmul): identical bits on every machine.
+CLUSTERED = dict(alpha=0.2, a=0.5, b=0.2, clusters=64, rank=4)    # cfg 1 with heavy-hitter queries selects ~2.1 % (README.md:43: ~2 %)
+SKEWED = dict(alpha=0.5, a=1.0, b=0.5, clusters=64, rank=4)       # stress: ~8 % selected, 3.7 % of the probed pieces > 126 ids
+
+
+def clustered_raw_bits(seed: int, Hkv: int, n: int, D: int, alpha=None, a=None, b=None, clusters=None, rank=None):
+    p = dict(CLUSTERED)
+    for k, v in (("alpha", alpha), ("a", a), ("b", b), ("clusters", clusters), ("rank", rank)):
+        if v is not None:
+            p[k] = v
+    s = (1.0 + np.arange(D, dtype=np.float64)) ** (-p["alpha"])
+    s = s / np.sqrt((s * s).mean())
+    z = normal_f32(seed, (Hkv, n, D)).astype(np.float64)
+    C = normal_f32(seed + 101, (Hkv, p["clusters"], D)).astype(np.float64)
+    u1 = randint(seed + 102, 0, p["clusters"], (Hkv, n))
+    u2 = randint(seed + 106, 0, p["clusters"], (Hkv, n))
+    cid = np.minimum(u1, u2)                                   # populations fall linearly from cluster 0 to the last
+    U = normal_f32(seed + 103, (Hkv, p["rank"], D)).astype(np.float64)
+    w = normal_f32(seed + 104, (Hkv, n, p["rank"])).astype(np.float64)
+    off = normal_f32(seed + 105, (Hkv, 1, D)).astype(np.float64) * 0.75
+    raw = s * z
+    raw = raw + p["a"] * (s * np.take_along_axis(C, cid[:, :, None], axis=1))
+    for j in range(p["rank"]):
+        raw = raw + p["b"] * (w[:, :, j:j + 1] * (s * U[:, j:j + 1, :]))
+    # unit mean square per element like the isotropic workload (SimHash does not see the scale; the logits do)
+    raw = raw * (1.0 / np.sqrt(1.0 + p["a"] ** 2 + p["rank"] * p["b"] ** 2)) + off
+    return f32_to_bf16_bits(raw.astype(np.float32))
+
+
+def centre_bits(raw_bits: np.ndarray):
+    """models/attnserver.py:139-146 on bf16 keys [Hkv, n, D], with exact (f64) sums: (centred key bits, kn f32)."""
+    raw = bf16_bits_to_f32(raw_bits).astype(np.float64)
+    avg = bf16_bits_to_f32(f32_to_bf16_bits(raw.mean(axis=1, keepdims=True).astype(np.float32)))
+    k = f32_to_bf16_bits((raw.astype(np.float32) - avg).astype(np.float32))
+    kf = bf16_bits_to_f32(k).astype(np.float64)
+    kn = np.sqrt((kf * kf).sum(-1)).astype(np.float32)
+    return k, bf16_bits_to_f32(f32_to_bf16_bits(kn))
+
+
+def clustered_keys(seed: int, Hkv: int, n: int, D: int, **kw):
+    """Centred clustered keys: (key bits uint16 [Hkv, n, D], kn f32 [Hkv, n])."""
+    return centre_bits(clustered_raw_bits(seed, Hkv, n, D, **kw))

@@ -322,6 +322,153 @@ def test_cfg2_full_size_fused_decode_properties(mp):
     assert np.allclose(got, ref, rtol=2 ** -6, atol=4e-3)
 
 
+# ------------------------------------------------------------------ BASELINE cfg 1 at full size, non-isotropic keys
+
+def test_cfg1_clustered_full_size_vs_reference(mp):
+    """BASELINE cfg 1 (B = 1, H = 32, Hkv = 8, n = 97 932, M = 98 304, K10 L150) on the CLUSTERED workload of
+    SURVEY.md 8(d) (anisotropic clustered keys, heavy-hitter queries: 2.2 % selected, 5 % of the probed pieces
+    overflow their direct slot) against tests/golden/cfg1_skew_sha.npz, which the compiled reference produced at
+    this size: key codes by SHA-256 (device key SimHash), query codes, nnz and the selected sets by SHA-256 --
+    through the device counting-sort build and the three-call path -- and the one-launch decode entry (clusters of
+    8 workgroups, direct slots, second access, split hash): nnz bit for bit, outputs at the reference's tolerance
+    and within 1 bf16 ulp of the three-call path's."""
+    import hashlib
+
+    g = cases.load_golden("cfg1_skew_sha")
+    seed, B, H, Hkv, n, M, D, K, L = (int(x) for x in g["meta"])
+    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L, cases.golden_data(g))
+    BH = B * H
+    server = mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, num_sink_tokens=0, num_local_tokens=0,
+                                    max_length=M, dense_layers=(), hash_func=bf16_t(W, "cuda"))
+    server.hash_code_buffer = server.hasher.keys(bf16_t(keys[0], "cuda"))
+    kcodes = server.hash_code_buffer.cpu().numpy()
+    assert np.array_equal(np.frombuffer(hashlib.sha256(kcodes[None].tobytes()).digest(), np.uint8), g["kcodes_sha"])
+    server.build_table(0, 0, n)
+    server.attn_server.fill(0, 0, bf16_t(keys[0], "cuda"), bf16_t(vals[0], "cuda"), torch.from_numpy(kns[0]).cuda())
+    q = bf16_t(qb, "cuda")
+    # three-call path: codes, selected sets, attention
+    codes, qn = server.hasher.query(q)
+    assert np.array_equal(codes.cpu().numpy(), g["qcodes"])
+    res = torch.zeros((BH, M), dtype=torch.int32, device="cuda")
+    nz = torch.zeros((BH,), dtype=torch.int32, device="cuda")
+    server.lsh_retriever.batch_retrieve(0, codes, res, nz)
+    nzh = nz.cpu().numpy()
+    assert np.array_equal(nzh, g["nnz"])
+    resh = res.cpu().numpy()
+    hsh = hashlib.sha256()
+    hsh.update(nzh.tobytes())
+    for h in range(BH):
+        hsh.update(resh[h, :nzh[h]].tobytes())                      # ascending already
+    assert np.array_equal(np.frombuffer(hsh.digest(), np.uint8), g["sha256"])
+    o3 = torch.zeros((BH, D), dtype=torch.bfloat16, device="cuda")
+    mve3 = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
+    server.attn_server.attention_wrapper(0, K, L, o3, mve3, q, qn, res, nz)
+    ref_out = synth.bf16_bits_to_f32(g["out_bits"])
+    assert np.allclose(o3.float().cpu().numpy(), ref_out, rtol=1e-2, atol=1e-2)          # test_sparse.py:92
+    assert np.allclose(mve3[1].cpu().numpy(), g["mve"][1], atol=0.03)
+    # the one-launch decode entry
+    out, lse = server.decode(q.view(B, H, 1, D), 0)
+    torch.cuda.synchronize()
+    server.attn_server.check()
+    assert np.array_equal(server.nnz.cpu().numpy(), g["nnz"])
+    got = out.float().cpu().numpy().reshape(BH, D)
+    assert np.allclose(got, ref_out, rtol=1e-2, atol=1e-2)
+    assert np.allclose(got, o3.float().cpu().numpy(), rtol=2 ** -7, atol=2e-4)          # <= 1 bf16 ulp (summation order)
+    assert np.allclose(lse.cpu().numpy().reshape(-1), mve3[1].cpu().numpy(), atol=1e-3)
+    # the probed pieces really leave the direct slots on this workload (what the fixture is for)
+    R = server.lsh_retriever.R
+    if R > 1:
+        bounds, _ = server.lsh_retriever.get_tables(0)
+        gidx = torch.arange(BH, device="cuda") // (H // Hkv)
+        be = bounds[gidx[:, None], torch.arange(L, device="cuda")[None, :], codes.long()]      # [BH, L, R + 1]
+        pieces = (be[..., 1:] - be[..., :-1]).flatten()
+        assert float((pieces > 30).float().mean()) > 0.02
+
+
+# ------------------------------------------------------------------ BASELINE cfg 4 (per-GPU share) at full size
+
+def test_cfg4_full_size_fused_decode_properties(mp):
+    """BASELINE cfg 4's per-GPU share (Llama-3.1-70B, TP = 8: H = 8, Hkv = 1, P = 131 072 -> n = 131 004,
+    M = 131 264, K = 11, L = 300: NB = 2048, U = 52 units of the split hash over 8 members, the wide direct pass),
+    one layer, through size-independent properties: (1) the one-launch entry equals hash -> batch_retrieve ->
+    attention_wrapper on the same stores (codes and nnz bit for bit, outputs up to summation order); (2) the selected
+    sets are exactly {tokens colliding in >= 2 tables}, recounted densely from the stored key codes; (3) V -> 2 V
+    doubles the output exactly and leaves the LSE unchanged; (4) the hyperplanes split over the cluster, split with
+    nobody publishing (every member falls back) and not split give bit-identical results; (5) so do the decode
+    without direct slots and the two-launch form."""
+    import magicpig_amd._lib as L_
+
+    B, H, Hkv, D, K, L, P = 1, 8, 1, 128, 11, 300, 131072
+    n, M = P - 68, 131264
+    BH, G = B * H, H // Hkv
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(23)
+    W = torch.randn((D, K * L), device=dev, generator=gen).to(torch.bfloat16)
+    kc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
+    vc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
+    q = torch.randn((B, H, 1, D), device=dev, generator=gen)
+    mk = lambda: mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, max_length=M, dense_layers=(),  # noqa: E731
+                                        hash_func=W, generation_buffer=8)
+    server = mk()
+    server.fill(0, 0, kc, vc, P)
+    kcodes = server.hash_code_buffer.clone()                                     # int16 [Hkv, L, n]
+    server.build_table(0, 0, P)
+    # heavy hitters on half of the heads (a realistic mix of peaked and flat heads)
+    kcen = server.attn_server.get_key_cache(0)
+    j = torch.randint(0, n, (H,), device=dev, generator=gen)
+    q[0, ::2, 0] = 0.5 * q[0, ::2, 0] + 3.0 * kcen[0, 0, j[::2]].float()
+    q = q.to(torch.bfloat16)
+    assert server.lsh_retriever.R == 8
+    out, lse = server.decode(q, 0)
+    out, lse, nz1 = out.clone().reshape(BH, D), lse.clone().reshape(-1), server.nnz.clone()
+    server.attn_server.check()
+    codes, qn = server.hasher.query(q.reshape(BH, D))
+    res = torch.zeros((BH, M), dtype=torch.int32, device=dev)
+    nz = torch.zeros((BH,), dtype=torch.int32, device=dev)
+    server.lsh_retriever.batch_retrieve(0, codes, res, nz)
+    assert torch.equal(nz, nz1) and int(nz.min()) > 100
+    for h in range(BH):                                                          # (2)
+        cnt = (kcodes[h // G] == codes[h].to(torch.int16)[:, None]).sum(0)
+        assert torch.equal(torch.nonzero(cnt >= 2).flatten().int(), res[h, :int(nz[h])])
+    o_ref = torch.zeros((BH, D), dtype=torch.bfloat16, device=dev)               # (1)
+    mve = torch.zeros((2, BH), dtype=torch.float32, device=dev)
+    server.attn_server.attention_wrapper(0, K, L, o_ref, mve, q.reshape(BH, D), qn, res, nz)
+    assert np.allclose(out.float().cpu().numpy(), o_ref.float().cpu().numpy(), rtol=2 ** -6, atol=2e-3)
+    assert np.allclose(lse.cpu().numpy(), mve[1].cpu().numpy(), atol=2e-3)
+    kvv = server.attn_server.get_value_cache(0)                                  # (3)
+    kvv.mul_(2)
+    out2, lse2 = server.decode(q, 0)
+    assert torch.equal(out2.reshape(BH, D).float(), out.float() * 2)
+    assert torch.equal(lse2.reshape(-1), lse)
+    kvv.mul_(0.5)
+    for mode in (2, 0, 1):                                                       # (4)
+        L_.set_option("decode_split_hash", mode)
+        try:
+            o_m, lse_m = server.decode(q, 0)
+            assert torch.equal(o_m.reshape(BH, D), out) and torch.equal(lse_m.reshape(-1), lse), mode
+            assert torch.equal(server.nnz, nz1)
+        finally:
+            L_.set_option("decode_split_hash", -1)
+    server.attn_server.check()
+    for opt, val in (("decode_direct", 0), ("decode_two_launch", 1)):            # (5)
+        L_.set_option(opt, val)
+        try:
+            other = mk() if opt == "decode_direct" else server
+            if other is not server:
+                other.fill(0, 0, kc, vc, P)
+                other.build_table(0, 0, P)
+            o_m, lse_m = other.decode(q, 0)
+            assert torch.equal(other.nnz, nz1), opt
+            assert np.allclose(o_m.float().cpu().numpy().reshape(BH, D), out.float().cpu().numpy(), rtol=2 ** -6,
+                               atol=2e-3), opt
+            assert np.allclose(lse_m.cpu().numpy().reshape(-1), lse.cpu().numpy(), atol=2e-3), opt
+            if opt == "decode_direct":
+                assert torch.equal(o_m.reshape(BH, D), out)                      # same kernel, same order: bit-identical
+            del other
+        finally:
+            L_.set_option(opt, 0 if opt == "decode_two_launch" else -1)
+
+
 # ------------------------------------------------------------------ f-1: prefill fill on device vs the torch fixture
 
 def test_fill_offload_vs_torch_fixture(mp):

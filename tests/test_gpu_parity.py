@@ -21,7 +21,9 @@ pytestmark = pytest.mark.gpu
 QHASH = ["qhash_r1_k10_l150", "qhash_r32_k10_l150", "qhash_r64_k11_l300", "qhash_r40_k8_l50",
          "qhash_r256_k10_l170"]
 PIPE = ["lsh_small", "cfg0", "gqa_32h", "b2_k8_l60",
-        "cfg2_small", "cfg3_small"]   # BASELINE cfg 2 / cfg 3 head counts: B = 8 x H = 32 = 256 query heads, L = 170 / 150
+        "cfg2_small", "cfg3_small",   # BASELINE cfg 2 / cfg 3 head counts: B = 8 x H = 32 = 256 query heads, L = 170 / 150
+        "cfg4_small", "g8_hkv2",      # cfg 4's per-GPU geometry (H = 8, Hkv = 1, K11 L300) and G = 8 with Hkv > 1
+        "skew_small", "clustered_k10"]   # the non-isotropic workloads of SURVEY.md 8(d) (tests/synth.py)
 
 
 @pytest.fixture(scope="module")
@@ -154,7 +156,7 @@ def test_key_simhash_bit_exact(mp):
 
 def _gpu_pipeline(mp, g, where, fused=False, table_build="fill"):
     seed, B, H, Hkv, n, M, D, K, L = (int(x) for x in g["meta"])
-    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L)
+    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L, cases.golden_data(g))
     dev = "cuda"
     sh = mp.SimHash(bf16_t(W, dev), K, L)
     lsh = mp.LSH()
@@ -571,7 +573,8 @@ def test_merge_state_vs_oracle(mp):
 
 # ------------------------------------------------------------------ fused decode step (the hot path as benchmarked)
 
-@pytest.mark.parametrize("name", ["gqa_32h", "b2_k8_l60", "cfg2_small", "cfg3_small"])
+@pytest.mark.parametrize("name", ["gqa_32h", "b2_k8_l60", "cfg2_small", "cfg3_small", "cfg4_small", "g8_hkv2",
+                                  "skew_small", "clustered_k10"])
 @pytest.mark.parametrize("table_build", ["sort", "counting"])
 def test_fused_decode_layer(mp, name, table_build):
     """The one-launch decode entry against the reference's vectors and the oracle.  gqa_32h / b2_k8_l60
@@ -579,7 +582,7 @@ def test_fused_decode_layer(mp, name, table_build):
     workgroup per head, no cluster -- the regime of BASELINE cfg 2 and cfg 3."""
     g = cases.load_golden(name)
     seed, B, H, Hkv, n, M, D, K, L = (int(x) for x in g["meta"])
-    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L)
+    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L, cases.golden_data(g))
     server = mp.LSHSparseAttnServer(3, H, Hkv, D, K=K, L=L, batch_size=B, num_sink_tokens=0,
                                     num_local_tokens=0, max_length=M, dense_layers=(0,),
                                     hash_func=bf16_t(W, "cuda"), table_build=table_build)

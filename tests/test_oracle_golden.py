@@ -13,7 +13,9 @@ import synth
 QHASH = ["qhash_r1_k10_l150", "qhash_r32_k10_l150", "qhash_r64_k11_l300", "qhash_r40_k8_l50",
          "qhash_r256_k10_l170"]
 PIPE = ["lsh_small", "cfg0", "gqa_32h", "b2_k8_l60",
-        "cfg2_small", "cfg3_small"]   # BASELINE cfg 2 / cfg 3 head counts (B = 8, 256 query heads; L = 170 / 150)
+        "cfg2_small", "cfg3_small",   # BASELINE cfg 2 / cfg 3 head counts (B = 8, 256 query heads; L = 170 / 150)
+        "cfg4_small", "g8_hkv2",      # cfg 4's per-GPU geometry (H = 8, Hkv = 1, K11 L300) and G = 8 with Hkv > 1
+        "skew_small", "clustered_k10"]   # the non-isotropic workloads of SURVEY.md 8(d) (tests/synth.py)
 
 
 @pytest.mark.parametrize("name", QHASH)
@@ -31,7 +33,7 @@ def test_query_simhash_bit_exact(name):
 
 def _run_oracle_pipeline(g, exp_mode):
     seed, B, H, Hkv, n, M, D, K, L = (int(x) for x in g["meta"])
-    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L)
+    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L, cases.golden_data(g))
     qcodes, qn = oracle.simhash_query(qb, W, K, L)
     kcodes = np.stack([oracle.simhash_keys(keys[b], W, K, L) for b in range(B)])
     lsh = oracle.LSH()
