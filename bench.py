@@ -108,6 +108,7 @@ def parse():
                          "heavy otherwise")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-mode", action="store_true", help="skip the untimed host-buffer (unchanged caller) leg")
     ap.add_argument("--cpu-steps", type=int, default=8192,
                     help="decode steps of ONE sparse layer timed on the host cores per thread placement (medians): "
                          "~5 s of CPU work at cfg 1, ~20 s at cfg 2")
@@ -255,6 +256,50 @@ def run_cpu_baseline(cfg, server, qs, steps, H, Hkv):
         if line.startswith("CPU_BASELINE_JSON "):
             return json.loads(line[len("CPU_BASELINE_JSON "):])
     raise RuntimeError("cpu baseline worker failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
+
+
+# ---------------------------------------------------------------------------- host-buffer mode leg
+
+def host_mode_leg(server, cfg, qs, H, reps=40):
+    """Per-layer cost of the UNCHANGED caller: the decode lines of models/attnserver.py:264-303 -- q hash on the GPU,
+    codes + query copied to pinned CPU tensors, batch_retrieve and attention_wrapper on CPU tensors (`results` and
+    `nnz` pageable, the rest pinned, exactly as :59-66), output + LSE copied back -- eager, synchronised per layer.
+    Untimed extra leg: `value` is measured with everything resident in HBM."""
+    B, D, M, K, Lt = (cfg[k] for k in ("B", "D", "M", "K", "L"))
+    BH = B * H
+    dev = qs.device
+    pin = lambda *shape, dtype: torch.zeros(shape, dtype=dtype).pin_memory()       # noqa: E731
+    pinned_hashcode, pinned_query = pin(BH, Lt, dtype=torch.int32), pin(BH, D, dtype=torch.bfloat16)
+    results, nnz = torch.zeros((BH, M), dtype=torch.int32), torch.zeros((BH,), dtype=torch.int32)      # :59-60: pageable
+    output, mve = pin(BH, D, dtype=torch.bfloat16), pin(2, BH, dtype=torch.float32)
+    out_cuda = torch.zeros((BH, D), dtype=torch.bfloat16, device=dev)
+    lse_cuda = torch.zeros((BH,), dtype=torch.float32, device=dev)
+    lsh, srv, hasher = server.lsh_retriever, server.attn_server, server.hasher
+
+    def host_layer(q):
+        codes, _ = hasher.query(q.reshape(BH, D))                       # :264-270 on the GPU
+        pinned_hashcode.copy_(codes)                                    # :272
+        pinned_query.copy_(q.reshape(BH, D))                            # :273
+        lsh.batch_retrieve(0, pinned_hashcode, results, nnz)            # :299
+        srv.attention_wrapper(0, K, Lt, output, mve, pinned_query, pinned_query.float().norm(p=2, dim=-1), results, nnz)
+        lse_cuda.copy_(mve[1], non_blocking=True)                       # :302-303
+        out_cuda.copy_(output, non_blocking=True)
+        torch.cuda.synchronize()
+
+    NQ = qs.shape[0]
+    for i in range(4):
+        host_layer(qs[i % NQ, 0])
+    t0 = time.perf_counter()
+    for i in range(reps):
+        host_layer(qs[i % NQ, 0])
+    us = (time.perf_counter() - t0) / reps * 1e6
+    server.collect_nnz = True
+    server.decode(qs[(reps - 1) % NQ, 0], 0)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(server.nnz.cpu(), nnz)) and float((server.output.float().cpu() - output.float()).abs().max()) < 2e-2
+    return {"us_per_layer": us, "matches_device_entry": same, "reps": reps,
+            "what": "models/attnserver.py:264-303 unchanged: GPU q-hash, pinned codes/query/output, pageable results/nnz, "
+                    "batch_retrieve + attention_wrapper on CPU tensors, eager + synchronised per layer"}
 
 
 # ---------------------------------------------------------------------------- end-to-end variant
@@ -579,6 +624,11 @@ def main():
     if gathered is not None:
         out["head_shard_gather"] = gathered
 
+    if rank == 0 and world == 1 and shard is None and not args.no_host_mode:
+        try:
+            out["host_mode"] = host_mode_leg(server, cfg, qs, H)
+        except Exception as e:
+            out["host_mode"] = {"us_per_layer": None, "what": f"failed: {e!r}"[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cb = run_cpu_baseline(cfg, server, qs, args.cpu_steps, H, Hkv)

@@ -784,6 +784,40 @@ __global__ void ragged_copy_kernel(int32_t* __restrict__ rows, int32_t* __restri
     }
 }
 
+// host-buffer mode: a few KB between the handle's pinned block (as the device sees it) and HBM, 16 bytes per lane
+__global__ __launch_bounds__(1024) void relay_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+}
+// host-buffer mode of the attention entry, one launch: blocks (x, h < BH) bring the first nnz[h] entries of the caller's
+// index row h into HBM (coalesced 256-byte wave reads over PCIe: read in 16-byte pieces by the attention kernel's row
+// groups the same ids cost ~20 us at cfg 1), blocks (x, BH) relay the small arguments (q | qn | nnz).
+__global__ __launch_bounds__(256) void host_rows_kernel(const int32_t* __restrict__ ind_host, const int32_t* __restrict__ nnz_host,
+                                                        int32_t* __restrict__ rows, int64_t M, int BH,
+                                                        const uint4* __restrict__ small_src, uint4* __restrict__ small_dst, int n16) {
+    const int h = blockIdx.y;
+    if (h == BH) {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) small_dst[i] = small_src[i];
+        return;
+    }
+    int64_t n = nnz_host[h];
+    n = n < 0 ? 0 : (n > M ? M : n);
+    const int32_t* src = ind_host + (int64_t)h * M;
+    int32_t* dst = rows + (int64_t)h * M;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) dst[j] = src[j];
+}
+hipError_t launch_host_rows(const int32_t* ind_host, const int32_t* nnz_host, int32_t* rows, int64_t M, int BH,
+                            const void* small_src, void* small_dst, size_t small_bytes, int gx, hipStream_t st) {
+    hipLaunchKernelGGL(host_rows_kernel, dim3(gx, BH + 1), dim3(256), 0, st, ind_host, nnz_host, rows, M, BH,
+                       reinterpret_cast<const uint4*>(small_src), reinterpret_cast<uint4*>(small_dst),
+                       (int)((small_bytes + 15) / 16));
+    return hipGetLastError();
+}
+hipError_t launch_relay(const void* src, void* dst, size_t bytes, hipStream_t st) {
+    hipLaunchKernelGGL(relay_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const uint4*>(src),
+                       reinterpret_cast<uint4*>(dst), (int)((bytes + 15) / 16));
+    return hipGetLastError();
+}
+
 hipError_t launch_ragged_offsets(const int32_t* nnz, int BH, int64_t M, int32_t* offs, hipStream_t st) {
     hipLaunchKernelGGL(ragged_offsets_kernel, dim3(1), dim3(1024), 0, st, nnz, BH, M, offs);
     return hipGetLastError();

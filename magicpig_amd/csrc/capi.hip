@@ -66,6 +66,9 @@ hipError_t launch_merge_state(const uint16_t*, const float*, const uint16_t*, co
 hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, int, const uint16_t*, int, int, int, int64_t,
                               uint16_t*, float*, int*, hipStream_t);
 hipError_t launch_attn_ticket_check(int*, int, int*, hipStream_t);
+hipError_t launch_relay(const void*, void*, size_t, hipStream_t);
+hipError_t launch_host_rows(const int32_t*, const int32_t*, int32_t*, int64_t, int, const void*, void*, size_t, int,
+                            hipStream_t);
 
 extern unsigned long long* g_stamp;
 
@@ -88,6 +91,7 @@ struct DebugOptions {
     std::atomic<int> attn_head_kernel{-1};   // -1 = auto, 0 = split-KV kernel, 1 = one workgroup per head
     std::atomic<int> attn_gx{0};             // 0 = auto, else split-KV workgroups per head
     std::atomic<int> attn_dense_grouped{1};  // full_attention: 1 = K/V read once per kv group, 0 = once per query head
+    std::atomic<int> host_zero_copy{1};      // MP_MEM_HOST calls: 1 = kernels read / write the caller's buffers in place, 0 = staged copies
 };
 static DebugOptions g_opt;
 
@@ -102,6 +106,7 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "attn_head_kernel")) return &g_opt.attn_head_kernel;
     if (!strcmp(name, "attn_gx")) return &g_opt.attn_gx;
     if (!strcmp(name, "attn_dense_grouped")) return &g_opt.attn_dense_grouped;
+    if (!strcmp(name, "host_zero_copy")) return &g_opt.host_zero_copy;
     return nullptr;
 }
 
@@ -155,6 +160,7 @@ static int stage_in(const void* src, size_t bytes, int mem, DevBuf& buf, const v
 // demand and kept by the handle (no hipMalloc / hipFree per call).
 struct Stage {
     void* hp = nullptr;   // pinned host
+    void* hd = nullptr;   // the same block as the device sees it (kernels read / write it over PCIe)
     void* dp = nullptr;   // device
     size_t cap = 0;
     int reserve(size_t bytes) {
@@ -162,16 +168,59 @@ struct Stage {
         size_t want = cap ? cap : 4096;
         while (want < bytes) want *= 2;
         release();
-        MP_HIP_CHECK(hipHostMalloc(&hp, want, hipHostMallocDefault));
+        MP_HIP_CHECK(hipHostMalloc(&hp, want, hipHostMallocMapped));
         MP_HIP_CHECK(hipMalloc(&dp, want));
+        if (hipHostGetDevicePointer(&hd, hp, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            hd = nullptr;                      // no alias: callers fall back to copies
+        }
         cap = want;
         return MP_OK;
     }
     void release() {
         if (hp) (void)hipHostFree(hp);
         if (dp) (void)hipFree(dp);
-        hp = dp = nullptr;
+        hp = dp = hd = nullptr;
         cap = 0;
+    }
+};
+
+// Host-buffer mode without copies: the address at which a KERNEL can read / write a caller's host buffer in place.
+// The reference's callers hold pinned tensors (models/attnserver.py:59-66: hipHostMalloc through torch's pin_memory):
+// those are mapped already.  A large pageable buffer (results_lsh_cpu, :60: 12.6 MB at cfg 1) is registered ONCE per
+// (pointer, size) and stays registered until the handle is freed; small pageable buffers are not worth a registration
+// and go through the handle's pinned block.  nullptr = not mappable: the staged path is used.
+struct HostMap {
+    struct Reg { const char* p; size_t bytes; char* dev; };
+    std::vector<Reg> regs;
+    void* resolve(const void* ptr, size_t bytes) {
+        const char* p = reinterpret_cast<const char*>(ptr);
+        for (const Reg& r : regs)
+            if (r.p <= p && p + bytes <= r.p + r.bytes) return r.dev + (p - r.p);
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, ptr) == hipSuccess) {
+            if (a.type == hipMemoryTypeHost && a.devicePointer != nullptr) return a.devicePointer;
+            if (a.type != hipMemoryTypeUnregistered) return nullptr;   // device / managed memory passed as "host"
+        } else {
+            (void)hipGetLastError();                               // pageable memory: "invalid value" on older runtimes
+        }
+        if (bytes < (256u << 10)) return nullptr;
+        if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, const_cast<void*>(ptr), 0) != hipSuccess || d == nullptr) {
+            (void)hipGetLastError();
+            (void)hipHostUnregister(const_cast<void*>(ptr));
+            return nullptr;
+        }
+        regs.push_back({p, bytes, reinterpret_cast<char*>(d)});
+        return d;
+    }
+    void release() {
+        for (const Reg& r : regs) (void)hipHostUnregister(const_cast<char*>(r.p));
+        regs.clear();
     }
 };
 
@@ -211,7 +260,8 @@ struct mp_lsh {
     unsigned long long* xw = nullptr;   // [BH][xwords] split hash: (launch sequence << 32 | 32 sign bits) (R > 1)
     unsigned int* xseq = nullptr;  // [BH] split hash: sequence number of the next launch
     int xwords = 0;
-    Stage small, big;              // host-buffer mode: (nnz | offsets) and the packed result rows
+    Stage small, big;              // host-buffer mode: (codes | nnz | offsets) and the packed result rows
+    HostMap hostmap;               // host-buffer mode: caller buffers the kernels use in place
     int32_t* last_query = nullptr; // [BH][L] staging copy of host-side query codes
     const int32_t* lastq = nullptr;// device codes of the last retrieve (for get_mask): last_query,
                                    // `codes`, or the caller's own device buffer (valid until it changes)
@@ -241,6 +291,7 @@ struct mp_attn {
     int* err = nullptr;            // device-side validation flag (append past max_length)
     double* colsum = nullptr;      // [FILL_BLOCKS][Hkv*D] scratch of mp_attn_fill_offload
     Stage small, big;              // host-buffer mode: (q | qn | nnz | offsets | out | mve) and the packed index rows
+    HostMap hostmap;               // host-buffer mode: caller buffers the kernels use in place
     int32_t* ind_rows = nullptr;   // host-buffer mode: [BH][M] device copy of `ind`
     int32_t* last_nnz = nullptr;   // [BH] staging copy of host-side nnz
     const int32_t* lastz = nullptr;// device nnz of the last call (for get_score): last_nnz or the
@@ -384,6 +435,7 @@ static void lsh_free(mp_lsh_t* h) {
     h->nnz = nullptr; h->qnorm = nullptr; h->xw = nullptr; h->xseq = nullptr;
     h->small.release();
     h->big.release();
+    h->hostmap.release();
     h->allocated = false;
 }
 
@@ -588,10 +640,30 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
                                          nnz, BH, h->G, h->L, h->NB, h->M, h->R, st));
         return MP_OK;
     }
-    // host callers (models/attnserver.py:299 passes pinned CPU tensors): stage through the handle's step buffers;
-    // only the first nnz[h] entries of each row mean anything, and they come back as ONE packed copy
-    int rc = h->small.reserve((size_t)(2 * BH + 1) * 4);
+    // host callers (models/attnserver.py:299 passes CPU tensors).  Zero copy: the kernel reads the codes from the handle's
+    // pinned block and writes the ids straight into the caller's `results` rows (mapped once, HostMap) and the counts
+    // into the pinned block: ONE launch, ONE synchronisation, no copy engine.
+    int rc = h->small.reserve(qb + (size_t)(2 * BH + 1) * 4);
     if (rc) return rc;
+    if (g_opt.host_zero_copy.load() != 0 && h->small.hd != nullptr) {
+        if (void* res_dev = h->hostmap.resolve(results, (size_t)BH * h->M * 4)) {
+            char* hp = reinterpret_cast<char*>(h->small.hp);
+            char* hd = reinterpret_cast<char*>(h->small.hd);
+            const size_t o_codes = (size_t)(2 * BH + 1) * 4;
+            memcpy(hp + o_codes, query, qb);
+            h->lastq = reinterpret_cast<const int32_t*>(hd + o_codes);      // (get_mask reads them again)
+            h->last_layer = layer_id;
+            MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id],
+                                             reinterpret_cast<const int32_t*>(hd + o_codes),
+                                             reinterpret_cast<int32_t*>(res_dev), reinterpret_cast<int32_t*>(hd), BH,
+                                             h->G, h->L, h->NB, h->M, h->R, st));
+            MP_HIP_CHECK(hipStreamSynchronize(st));
+            memcpy(nnz, hp, (size_t)BH * 4);
+            return MP_OK;
+        }
+    }
+    // staged: through the handle's step buffers; only the first nnz[h] entries of each row mean anything, and they
+    // come back as ONE packed copy
     MP_HIP_CHECK(hipMemcpyAsync(h->last_query, query, qb, hipMemcpyHostToDevice, st));
     h->lastq = h->last_query;
     h->last_layer = layer_id;
@@ -699,6 +771,7 @@ static void attn_free(mp_attn_t* h) {
     h->ind_rows = nullptr;
     h->small.release();
     h->big.release();
+    h->hostmap.release();
     h->allocated = false;
 }
 
@@ -934,6 +1007,37 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
     memcpy(hp + o_q, query, qbytes);
     if (!dense) memcpy(hp + o_qn, qn, (size_t)BH * 4);
     memcpy(hp + o_nnz, nnz, (size_t)BH * 4);
+    // Zero copy: ONE launch brings (q | qn | nnz) and the first nnz[h] entries of every index row -- read straight from
+    // the caller's buffer (mapped once, HostMap) -- into HBM with coalesced reads, the attention kernel writes (out | mve)
+    // straight into the pinned block: two launches, ONE synchronisation, no copy engine.
+    if (g_opt.host_zero_copy.load() != 0 && h->small.hd != nullptr) {
+        const void* ind_dev = dense ? nullptr : h->hostmap.resolve(ind, (size_t)BH * h->M * 4);
+        if (dense || ind_dev != nullptr) {
+            char* hd = reinterpret_cast<char*>(h->small.hd);
+            if (dense) {
+                MP_HIP_CHECK(launch_relay(hd, dp, o_offs, st));
+            } else {
+                if (h->ind_rows == nullptr) MP_HIP_CHECK(hipMalloc((void**)&h->ind_rows, (size_t)BH * h->M * 4));
+                int64_t longest = 0;                                     // one PCIe round trip per thread: blocks by the longest row
+                for (int i = 0; i < BH; ++i) longest = nnz[i] > longest ? nnz[i] : longest;
+                longest = longest > h->M ? h->M : longest;
+                int gx = (int)((longest + 255) / 256);
+                gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+                MP_HIP_CHECK(launch_host_rows(reinterpret_cast<const int32_t*>(ind_dev),
+                                              reinterpret_cast<const int32_t*>(hd + o_nnz), h->ind_rows, h->M, BH, hd, dp,
+                                              o_offs, gx, st));
+            }
+            rc = attn_run(h, layer_id, dense, K, L, reinterpret_cast<uint16_t*>(hd + o_out),
+                          reinterpret_cast<float*>(hd + o_mve), dp + o_q, query_dtype,
+                          reinterpret_cast<const float*>(dp + o_qn), dense ? nullptr : h->ind_rows,
+                          reinterpret_cast<const int32_t*>(dp + o_nnz), st);
+            if (rc) return rc;
+            MP_HIP_CHECK(hipStreamSynchronize(st));
+            memcpy(output, hp + o_out, (size_t)BH * h->D * 2);
+            memcpy(mve, hp + o_mve, (size_t)2 * BH * 4);
+            return MP_OK;                                         // (lastz = dp + o_nnz: valid until the next host call)
+        }
+    }
     int32_t* offs = reinterpret_cast<int32_t*>(hp + o_offs);
     size_t total = 0;
     for (int i = 0; i < BH; ++i) {

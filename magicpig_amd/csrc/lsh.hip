@@ -139,10 +139,13 @@ __global__ __launch_bounds__(256) void lsh_subbounds_kernel(
 // in the table row, words 2 .. 31 = its first 30 ids.  The decode kernel reads a piece with ONE 128-byte access
 // straight from the query's code, without the sub-bounds round trip in front of it; the position lets it fetch the
 // rest of a longer piece with the next access.  Half a wave writes a slot.
+// (Measured and rejected, round 3: the layout [group][R][L][NB][32], in which the slots a cluster member reads are one
+// contiguous eighth of its group's 157 MB -- an eighth of the pages to translate: 19.4 / 22.1 / 20.9 us per launch at cfg 1
+// randn / clustered / cfg 4 against 19.4 / 22.1 / 21.0 with this one.  Address translation is not what the phase waits for.)
 __global__ __launch_bounds__(256) void lsh_slots_kernel(const int32_t* __restrict__ table,
                                                         const int32_t* __restrict__ bounds,
                                                         int32_t* __restrict__ slots, int NB, int R, int64_t M) {
-    const int64_t row = blockIdx.y;
+    const int64_t row = blockIdx.y;                      // (kv head, table) row of this request
     const int RS = R + 1;
     const int32_t* t = table + row * M;
     const int32_t* b = bounds + row * NB * RS;
@@ -755,6 +758,18 @@ __device__ __forceinline__ void lsh_head_body(
                     if (l < L) ha.codes_out[h * L + l] = cd[b];
                 }
             }
+            // A piece longer than its slot.  Not rare: SimHash buckets are far from equally likely (ten random planes in
+            // 128 dimensions: bucket sizes at cfg 1 run from 32 (p1) to 209 (p99) around a mean of 96) and a query lands
+            // in the heavy ones more often -- 1.5 % of the probed pieces on isotropic keys, 5.9 % on the clustered
+            // workload (bench.py --data clustered), i.e. two to three per wave somewhere in almost every cluster.  Its
+            // half-wave fetches up to 96 more ids itself (the slot carries the position): ONE more dependent access for
+            // the whole wave -- the follow-up loads of ALL its long pieces are issued while the slots are still being
+            // counted and are waited for together (round 2 waited for each long piece's loads on the spot: a wave
+            // with three long pieces paid three dependent round trips, and the launch waits for its slowest wave).
+            // What is longer still (> 126 ids, skewed data) goes to the chunk pool.
+            int32_t e0[DG], e1[DG], e2[DG];
+            int r1s[DG];
+            uint32_t more = 0u, wide = 0u;                                  // wave-uniform bit masks over b
 #pragma unroll
             for (int b = 0; b < DG; ++b) {
                 const int l = l0 + (b * RT_WAVES + wave) * 2 + half;
@@ -766,34 +781,40 @@ __device__ __forceinline__ void lsh_head_body(
                 if (b == DG - 1) MP_STAMP(stamp, 44);                   // the last one has
                 int rest = 0;
                 if (l < L) {
-                    if (sl >= 2 && sl - 2 < pl) apply(v[b]);
                     rest = pl - DIRECT_IDS;
                     if (pp < 0 || (int64_t)pp + pl > M) rest = 0;       // never outside the row
                 }
-                // A piece longer than the slot.  Not rare: SimHash buckets are far from equally likely (ten random
-                // planes in 128 dimensions: bucket sizes at cfg 1 run from 32 (p1) to 209 (p99) around a mean of 96)
-                // and a query lands in the heavy ones more often -- 1.2 % of the probed pieces, at least one in 82 %
-                // of the workgroups (scripts/piece_lengths.py).  The half-wave fetches up to 96 more ids right
-                // here, ONE more dependent access and no barrier (through the sub-bounds and the chunk pool it was
-                // two accesses and two barriers); what is longer still goes to the pool.
-                if (__ballot(rest > 0)) {                               // wave-uniform
+                const int r1 = rest < DIRECT_MORE ? rest : DIRECT_MORE;
+                r1s[b] = r1;
+                e0[b] = e1[b] = e2[b] = -1;
+                if (__ballot(rest > 0)) {                               // wave-uniform: the follow-up goes out NOW
+                    more |= 1u << b;
                     const int lc = l < L ? l : L - 1;
                     const int32_t* row = tab + (int64_t)lc * M;
-                    const int r1 = rest < DIRECT_MORE ? rest : DIRECT_MORE;
                     const int at0 = pp + DIRECT_IDS + sl;
-                    const int32_t e0 = row[sl < r1 ? at0 : 0];
-                    int32_t e1 = -1, e2 = -1;
+                    e0[b] = row[sl < r1 ? at0 : 0];
                     if (__ballot(r1 > 32)) {
-                        e1 = row[sl + 32 < r1 ? at0 + 32 : 0];
-                        e2 = row[sl + 64 < r1 ? at0 + 64 : 0];
+                        wide |= 1u << b;
+                        e1[b] = row[sl + 32 < r1 ? at0 + 32 : 0];
+                        e2[b] = row[sl + 64 < r1 ? at0 + 64 : 0];
                     }
-                    apply(sl < r1 ? e0 : -1);
-                    apply(sl + 32 < r1 ? e1 : -1);
-                    apply(sl + 64 < r1 ? e2 : -1);
                     if (sl == 0 && rest > DIRECT_MORE) {                // skewed data: the chunk pool takes the rest
                         s_start[l] = pp + DIRECT_IDS + DIRECT_MORE;
                         s_len[l] = rest - DIRECT_MORE;
                         atomicAdd(&s_tmp[30], 1);
+                    }
+                }
+                if (l < L && sl >= 2 && sl - 2 < pl) apply(v[b]);       // the slot's own ids
+            }
+            if (more) {                                                 // wave-uniform; one wait for all follow-ups
+#pragma unroll
+                for (int b = 0; b < DG; ++b) {
+                    if (more & (1u << b)) {
+                        apply(sl < r1s[b] ? e0[b] : -1);
+                        if (wide & (1u << b)) {
+                            apply(sl + 32 < r1s[b] ? e1[b] : -1);
+                            apply(sl + 64 < r1s[b] ? e2[b] : -1);
+                        }
                     }
                 }
             }
@@ -926,7 +947,8 @@ __device__ __forceinline__ void lsh_head_body(
             for (int j = first + tid; j < len; j += RT_THREADS) apply(row[j]);
         }
     }
-    __syncthreads();
+    // (direct pass without pooled chunks: nothing was counted since the barrier behind the pass)
+    if (!(AD > 0 && HASH != 0 && slots != nullptr && ntail == 0)) __syncthreads();
     MP_STAMP(stamp, 19);
 
     // sweep B: contiguous words per thread, block-wide exclusive scan, ascending emission

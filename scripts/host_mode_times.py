@@ -28,20 +28,38 @@ qs = torch.randn((reps + 5, B, H, 1, D), device=dev).to(torch.bfloat16)
 # pinned CPU tensors of the reference (attnserver.py:59-66)
 pin = lambda *shape, dtype: torch.zeros(shape, dtype=dtype).pin_memory()
 pinned_hashcode, pinned_query = pin(BH, Lt, dtype=torch.int32), pin(BH, D, dtype=torch.bfloat16)
-results, nnz = pin(BH, M, dtype=torch.int32), pin(BH, dtype=torch.int32)
+# (results_lsh_cpu and nnz are PAGEABLE in the reference, :59-60; argv[3] = "pinned" pins them for comparison)
+if len(sys.argv) > 3 and sys.argv[3] == "pinned":
+    results, nnz = pin(BH, M, dtype=torch.int32), pin(BH, dtype=torch.int32)
+else:
+    results, nnz = torch.zeros((BH, M), dtype=torch.int32), torch.zeros((BH,), dtype=torch.int32)
 output, mve = pin(BH, D, dtype=torch.bfloat16), pin(2, BH, dtype=torch.float32)
 out_cuda, lse_cuda = torch.zeros((BH, D), dtype=torch.bfloat16, device=dev), torch.zeros((BH,), device=dev)
 lsh, srv, hasher = server.lsh_retriever, server.attn_server, server.hasher
 
+parts = {}
+def lap(name, t):
+    now = time.perf_counter()
+    parts[name] = parts.get(name, 0.0) + (now - t)
+    return now
+
 def host_layer(q):
+    t = time.perf_counter()
     codes, _ = hasher.query(q.reshape(BH, D))                       # :264-270 on the GPU
     pinned_hashcode.copy_(codes)                                    # :272
+    t = lap("q hash + codes -> pinned (blocking D2H)", t)
     pinned_query.copy_(q.reshape(BH, D))                            # :273
+    t = lap("query -> pinned (blocking D2H)", t)
     lsh.batch_retrieve(0, pinned_hashcode, results, nnz)            # :299
-    srv.attention_wrapper(0, K, Lt, output, mve, pinned_query, pinned_query.float().norm(p=2, dim=-1), results, nnz)   # :300
+    t = lap("batch_retrieve (host buffers)", t)
+    qn = pinned_query.float().norm(p=2, dim=-1)
+    t = lap("||q|| on the CPU (torch)", t)
+    srv.attention_wrapper(0, K, Lt, output, mve, pinned_query, qn, results, nnz)   # :300
+    t = lap("attention_wrapper (host buffers)", t)
     lse_cuda.copy_(mve[1], non_blocking=True)                       # :302-303
     out_cuda.copy_(output, non_blocking=True)
     torch.cuda.synchronize()
+    t = lap("out + LSE -> device, synchronize", t)
 
 d_res = torch.zeros((BH, M), dtype=torch.int32, device=dev)
 d_nnz = torch.zeros((BH,), dtype=torch.int32, device=dev)
@@ -63,11 +81,15 @@ for fn, label in ((host_layer, "host buffers (unchanged attnserver.py decode lin
                   (device_one_launch, "device buffers, mp_decode_sparse_layer")):
     for i in range(5):
         fn(qs[i])
+    parts.clear()
     t0 = time.perf_counter()
     for i in range(reps):
         fn(qs[5 + i])
     dt = (time.perf_counter() - t0) / reps * 1e6
     print(f"{label:58s} {dt:9.1f} us per layer (eager, synchronised after every layer)")
+    if fn is host_layer:
+        for k, v in parts.items():
+            print(f"    {k:54s} {v / reps * 1e6:9.1f} us")
 host_layer(qs[0]); a = out_cuda.clone(); device_three_call(qs[0])
 # (the host path takes ||q|| from torch's CPU norm, attnserver.py:300: f32 sums in another order than the kernel's)
 print("max |host - device| output:", float((a.float() - d_out.float()).abs().max()), " nnz equal:", torch.equal(nnz.cuda(), d_nnz))

@@ -258,6 +258,53 @@ def test_pipeline_vs_reference_and_oracle(mp, name, where):
     _check_attention(r, g)
 
 
+@pytest.mark.parametrize("pinned", [True, False])
+@pytest.mark.parametrize("zero_copy", [1, 0])
+def test_host_buffer_modes_agree(mp, zero_copy, pinned):
+    """MP_MEM_HOST calls (the unchanged caller of models/attnserver.py:299-300): kernels working on the caller's
+    buffers in place (pinned tensors as :59-66, or a large pageable `results` registered once) and the staged-copy
+    fallback give what the device-buffer calls give, bit for bit; rows behind nnz stay untouched; a second call with
+    other queries reuses the mapping."""
+    import magicpig_amd._lib as L_
+
+    g = cases.load_golden("gqa_32h")
+    seed, B, H, Hkv, n, M, D, K, L = (int(x) for x in g["meta"])
+    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L)
+    BH = B * H
+    sh = mp.SimHash(bf16_t(W, "cuda"), K, L)
+    lsh, srv = mp.LSH(), mp.SparseAttentionServer()
+    lsh.alloc(K, L, 1, H, Hkv, B, M)
+    srv.alloc(1, H, Hkv, D, B, M)
+    lsh.fastfill(0, 0, sh.keys(bf16_t(keys[0], "cuda")))
+    srv.fill(0, 0, bf16_t(keys[0], "cuda"), bf16_t(vals[0], "cuda"), torch.from_numpy(kns[0]).cuda())
+    mk = (lambda t: t.pin_memory()) if pinned else (lambda t: t)
+    L_.set_option("host_zero_copy", zero_copy)
+    try:
+        for rep in range(2):
+            q = bf16_t(qb if rep == 0 else np.roll(qb, 3, axis=0), "cuda")
+            codes, qn = sh.query(q)
+            d_res = torch.full((BH, M), -7, dtype=torch.int32, device="cuda")
+            d_nnz = torch.zeros((BH,), dtype=torch.int32, device="cuda")
+            lsh.batch_retrieve(0, codes, d_res, d_nnz)
+            m_dev = lsh.get_mask()
+            d_out = torch.zeros((BH, D), dtype=torch.bfloat16, device="cuda")
+            d_mve = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
+            srv.attention_wrapper(0, K, L, d_out, d_mve, q, qn, d_res, d_nnz)
+            d_probs = srv.get_score().reshape(BH, M).clone()
+            h_codes, h_q, h_qn = mk(codes.cpu()), mk(q.cpu()), qn.cpu()
+            h_res = mk(torch.full((BH, M), -7, dtype=torch.int32))
+            h_nnz = torch.zeros((BH,), dtype=torch.int32)
+            lsh.batch_retrieve(0, h_codes, h_res, h_nnz)
+            assert torch.equal(h_nnz, d_nnz.cpu()) and torch.equal(h_res, d_res.cpu())       # incl. the -7 behind nnz
+            assert torch.equal(lsh.get_mask(), m_dev)                  # get_mask re-reads the staged / mapped codes
+            h_out, h_mve = mk(torch.zeros((BH, D), dtype=torch.bfloat16)), mk(torch.zeros((2, BH), dtype=torch.float32))
+            srv.attention_wrapper(0, K, L, h_out, h_mve, h_q, h_qn, h_res, h_nnz)
+            assert torch.equal(h_out, d_out.cpu()) and torch.equal(h_mve, d_mve.cpu())
+            assert torch.equal(srv.get_score().reshape(BH, M), d_probs)
+    finally:
+        L_.set_option("host_zero_copy", 1)
+
+
 @pytest.mark.parametrize("name", ["lsh_small", "gqa_32h"])
 def test_device_table_build_equals_sorted_fill(mp, name):
     g = cases.load_golden(name)
