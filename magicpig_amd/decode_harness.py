@@ -50,9 +50,10 @@ LLAMA_3_1_70B = LlamaShape(hidden_size=8192, num_hidden_layers=80, num_attention
 
 
 def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
-    """models/utils.py:47-56 (`flashinfer.rmsnorm`): x * rsqrt(mean(x^2) + eps) * w, f32 inside."""
+    """models/utils.py:47-56 (`flashinfer.rmsnorm`): x * rsqrt(mean(x^2) + eps) * w, evaluated in f32 and rounded
+    once (pinned by tests/golden/llama_ops.npz)."""
     xf = x.float()
-    return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype) * weight
+    return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * weight.float()).to(x.dtype)
 
 
 def rotate_half(x: torch.Tensor) -> torch.Tensor:
@@ -60,8 +61,17 @@ def rotate_half(x: torch.Tensor) -> torch.Tensor:
     return torch.cat((-x2, x1), dim=-1)
 
 
+def rope_tables(head_dim: int, max_length: int, theta: float, device, dtype=torch.bfloat16):
+    """models/llama.py:114-126 (attention_scaling = 1): cos / sin caches [max_length, head_dim]."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, device=device).float() / head_dim))
+    pos = torch.arange(0, max_length, device=device).float()
+    freqs = torch.outer(pos, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
 def apply_rotary_pos_emb(x, cos, sin, position_ids, unsqueeze_dim=1):
-    """models/utils.py:36-45."""
+    """models/utils.py:36-45 (pinned by tests/golden/llama_ops.npz)."""
     c = cos[position_ids].unsqueeze(unsqueeze_dim)
     s = sin[position_ids].unsqueeze(unsqueeze_dim)
     return (x * c) + (rotate_half(x) * s)
@@ -74,6 +84,7 @@ class SyntheticLlamaDecoder:
                  max_length: int = 8192, generation_buffer: int = 256, dense_layers=(0, 16, 32, 48, 64),
                  device: str = "cuda:0", dtype=torch.bfloat16, seed: int = 0):
         self.shape, self.K, self.L = shape, K, L
+        self.fused_window = True      # sparse layers: decode_full_fused (two launches); False: decode_full (four)
         self.batch_size, self.max_length = batch_size, max_length
         self.device, self.dtype = torch.device(device), dtype
         self.num_layers = shape.num_hidden_layers
@@ -99,11 +110,7 @@ class SyntheticLlamaDecoder:
                 ln1=torch.ones(hs, device=self.device, dtype=dtype),
                 ln2=torch.ones(hs, device=self.device, dtype=dtype)))
         # RoPE tables (models/llama.py:114-126)
-        inv_freq = 1.0 / (shape.rope_theta ** (torch.arange(0, D, 2, device=self.device).float() / D))
-        pos = torch.arange(0, max_length, device=self.device).float()
-        freqs = torch.outer(pos, inv_freq)
-        emb = torch.cat((freqs, freqs), dim=-1)
-        self.cos_cache, self.sin_cache = emb.cos().to(dtype), emb.sin().to(dtype)
+        self.cos_cache, self.sin_cache = rope_tables(D, max_length, shape.rope_theta, self.device, dtype)
         # attention state: sparse layers -> LSH server (indexed by position in sparse_layers);
         # dense layers -> one full-length store (indexed by position in dense_layers)
         self.sparse_index = {l: i for i, l in enumerate(self.sparse_layers)}
@@ -176,8 +183,8 @@ class SyntheticLlamaDecoder:
         if layer in self.dense_index:
             attn = self._dense_attention(q.contiguous(), k, v, layer)
         else:
-            attn = self.attention_server.decode_full_fused(q.contiguous(), k.contiguous(), v.contiguous(),
-                                                     self.sparse_index[layer])
+            decode = self.attention_server.decode_full_fused if self.fused_window else self.attention_server.decode_full
+            attn = decode(q.contiguous(), k.contiguous(), v.contiguous(), self.sparse_index[layer])
         h = residual + F.linear(attn.reshape(B, 1, H * D), W["wo"])
         y = rms_norm(h, W["ln2"], eps)
         y = F.linear(F.silu(F.linear(y, W["gate"])) * F.linear(y, W["up"]), W["down"])

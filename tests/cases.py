@@ -136,3 +136,18 @@ def fill_centre_inputs(c):
     k = synth.f32_to_bf16_bits((synth.normal_f32(c["seed"], (T, Hkv, D)) + mean).astype(np.float32))
     v = synth.normal_bf16_bits(c["seed"] + 1, (T, Hkv, D))
     return k, v
+
+
+# ---- model plumbing around the path (tests/golden/llama_ops.npz, SURVEY f-3): RoPE tables + apply_rotary_pos_emb
+# (models/llama.py:114-126, models/utils.py:29-45) and RMSNorm (models/utils.py:47-56 -> flashinfer.rmsnorm)
+LLAMA_OPS = dict(seed=81, B=2, H=4, Hkv=2, D=128, hidden=512, max_len=4096, theta=500000.0, eps=1e-5,
+                 positions=(0, 1, 777, 4095))
+
+
+def llama_ops_inputs(c):
+    """bf16 bit patterns: hidden states [B, 1, hidden], norm weight [hidden] (around 1), q [B, H, 1, D], k [B, Hkv, 1, D]."""
+    x = synth.normal_bf16_bits(c["seed"], (c["B"], 1, c["hidden"]))
+    w = synth.f32_to_bf16_bits((1.0 + 0.25 * synth.normal_f32(c["seed"] + 1, (c["hidden"],))).astype(np.float32))
+    q = synth.normal_bf16_bits(c["seed"] + 2, (c["B"], c["H"], 1, c["D"]))
+    k = synth.normal_bf16_bits(c["seed"] + 3, (c["B"], c["Hkv"], 1, c["D"]))
+    return x, w, q, k

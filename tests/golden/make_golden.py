@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import synth  # noqa: E402
-from cases import (DATA_KINDS, FILL_CENTRE, FULL_DENSE_CASES, WINDOW_MERGE, case_inputs,  # noqa: E402
-                   fill_centre_inputs, full_dense_inputs, full_dense_seed, window_merge_inputs)
+from cases import (DATA_KINDS, FILL_CENTRE, FULL_DENSE_CASES, LLAMA_OPS, WINDOW_MERGE, case_inputs,  # noqa: E402
+                   fill_centre_inputs, full_dense_inputs, full_dense_seed, llama_ops_inputs, window_merge_inputs)
 from oracle.build_ref import load_ref, ref_uses_bf16_family  # noqa: E402
 
 
@@ -430,6 +430,49 @@ def run_cfg1_skew_sha(name, seed, ref_lsh, ref_attn, out):
     print(f"{name}: nnz mean {nz.mean():.1f} ({nz.mean() / n * 100:.2f} %) min {nz.min()} max {nz.max()}; {len(ties)} ties")
 
 
+def run_llama_ops(name, out):
+    """The model plumbing the decode-step harness (SURVEY f-3) restates around the path, executed with torch on CPU:
+    the RoPE tables exactly as models/llama.py:114-126 builds them (inv_freq = theta^(-2i/D), attention_scaling = 1:
+    the default rotary embedding of the HF config the reference loads), rotate_half / apply_rotary_pos_emb verbatim
+    from models/utils.py:29-45 on bf16 tensors, and RMSNorm as models/utils.py:47-56 calls it -- flashinfer.rmsnorm,
+    a third-party wheel absent from /root/reference (install.sh:4); its published definition is
+    out = x / sqrt(mean(x^2) + eps) * weight evaluated in f32 and rounded once to the input dtype."""
+    c = LLAMA_OPS
+    x, w, q, k = llama_ops_inputs(c)
+    D, max_len = c["D"], c["max_len"]
+    inv_freq = 1.0 / (c["theta"] ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))
+    position_ids = torch.arange(0, max_len).unsqueeze(0)                                   # llama.py:114
+    inv_freq_expanded = inv_freq[None, :, None].float().expand(position_ids.shape[0], -1, 1)
+    position_ids_expanded = position_ids[:, None, :].float()
+    freqs = (inv_freq_expanded.float() @ position_ids_expanded.float()).transpose(1, 2)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    cos_cache = (emb.cos()[0] * 1.0).to(torch.bfloat16)                                   # :119-124
+    sin_cache = (emb.sin()[0] * 1.0).to(torch.bfloat16)
+
+    def rotate_half(t):                                                                    # utils.py:29-33
+        t1 = t[..., : t.shape[-1] // 2]
+        t2 = t[..., t.shape[-1] // 2:]
+        return torch.cat((-t2, t1), dim=-1)
+
+    def apply_rotary_pos_emb(t, cos, sin, position_ids, unsqueeze_dim=1):                  # utils.py:36-45
+        cos = cos[position_ids].unsqueeze(unsqueeze_dim)
+        sin = sin[position_ids].unsqueeze(unsqueeze_dim)
+        return (t * cos) + (rotate_half(t) * sin)
+
+    bits = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()     # noqa: E731
+    d = dict(meta=np.array([c["seed"], c["B"], c["H"], c["Hkv"], D, c["hidden"], max_len], np.int64),
+             cos_rows=bits(cos_cache[list(c["positions"])]), sin_rows=bits(sin_cache[list(c["positions"])]))
+    qt, kt = synth.to_torch_bf16(q), synth.to_torch_bf16(k)
+    for p_ in c["positions"]:
+        pos = torch.full((c["B"], 1), p_, dtype=torch.long)
+        d[f"q_rope_{p_}"] = bits(apply_rotary_pos_emb(qt, cos_cache, sin_cache, pos))
+        d[f"k_rope_{p_}"] = bits(apply_rotary_pos_emb(kt, cos_cache, sin_cache, pos))
+    xf, wf = synth.to_torch_bf16(x).float(), synth.to_torch_bf16(w).float()
+    d["rmsnorm"] = bits((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + c["eps"]) * wf).to(torch.bfloat16))
+    out[name] = d
+    print(f"{name}: positions {c['positions']}")
+
+
 def main():
     only = set(sys.argv[1:])            # fixture names to (re)generate; none = all
     ref_lsh, ref_attn = load_ref()
@@ -466,6 +509,7 @@ def main():
         "full_dense": lambda name, out: run_full_dense(name, 55, ref_attn, out),
         "window_merge": lambda name, out: run_window_merge(name, out),
         "fill_centre": lambda name, out: run_fill_centre(name, out),
+        "llama_ops": lambda name, out: run_llama_ops(name, out),
     }
     unknown = only - set(registry)
     assert not unknown, f"unknown fixtures: {sorted(unknown)}"

@@ -36,16 +36,29 @@ def test_decoder_matches_dense_attention_when_everything_is_sampled():
     for t in range(steps):
         pos = torch.full((B, 1), P + t, device="cuda", dtype=torch.long)
         logits = dec.inference(ids[:, t:t + 1], pos)
-        # ---- reference decoder: same bf16 projections, dense f32 attention
+        # ---- reference decoder: same bf16 projections, dense f32 attention; RMSNorm and RoPE restated HERE (f32
+        #      arithmetic, the rotation written out per pair), not taken from the module under test -- the harness'
+        #      own versions are pinned bit for bit by tests/golden/llama_ops.npz (test_host_logic.py)
+        def ref_norm(x, w):
+            xf = x.float()
+            return (xf / torch.sqrt((xf * xf).mean(-1, keepdim=True) + shape.rms_norm_eps) * w.float()).to(x.dtype)
+
+        def ref_rope(x, p):                     # x [B, heads, 1, D]; pairs (i, i + D/2) rotate by p * theta^(-2i/D)
+            half = D // 2
+            ang = p[:, :, None].float() * (shape.rope_theta ** (-torch.arange(half, device="cuda").float() * 2 / D))
+            cs, sn = ang.cos().to(torch.bfloat16)[:, None], ang.sin().to(torch.bfloat16)[:, None]   # [B, 1, 1, half]
+            a, b_ = x[..., :half], x[..., half:]
+            return torch.cat((a * cs - b_ * sn, b_ * cs + a * sn), dim=-1)
+
         hs = F.embedding(ids[:, t:t + 1], dec.embed_tokens)
         for l in range(3):
             W = dec.layers[l]
-            x = dh.rms_norm(hs, W["ln1"], shape.rms_norm_eps)
+            x = ref_norm(hs, W["ln1"])
             q = F.linear(x, W["wq"]).view(B, 1, H, D).transpose(1, 2)
             k = F.linear(x, W["wk"]).view(B, 1, Hkv, D).transpose(1, 2)
             v = F.linear(x, W["wv"]).view(B, 1, Hkv, D).transpose(1, 2)
-            k = dh.apply_rotary_pos_emb(k, dec.cos_cache, dec.sin_cache, pos)
-            q = dh.apply_rotary_pos_emb(q, dec.cos_cache, dec.sin_cache, pos)
+            k = ref_rope(k, pos)
+            q = ref_rope(q, pos)
             attn = torch.zeros((B, 1, H * D), device="cuda", dtype=torch.bfloat16)
             for b in range(B):
                 ref_k[b][l] = torch.cat([ref_k[b][l], k[b].transpose(0, 1).float()], 0)
@@ -54,9 +67,9 @@ def test_decoder_matches_dense_attention_when_everything_is_sampled():
                     s = (ref_k[b][l][:, h // G] @ q[b, h, 0].float()) / math.sqrt(D)
                     attn[b, 0, h * D:(h + 1) * D] = (torch.softmax(s, 0) @ ref_v[b][l][:, h // G]).to(torch.bfloat16)
             hmid = hs + F.linear(attn, W["wo"])
-            y = dh.rms_norm(hmid, W["ln2"], shape.rms_norm_eps)
+            y = ref_norm(hmid, W["ln2"])
             hs = hmid + F.linear(F.silu(F.linear(y, W["gate"])) * F.linear(y, W["up"]), W["down"])
-        ref_logits = F.linear(dh.rms_norm(hs, dec.norm_weight, shape.rms_norm_eps), dec.lm_head).float()
+        ref_logits = F.linear(ref_norm(hs, dec.norm_weight), dec.lm_head).float()
         err = (logits - ref_logits).abs().max().item()
         scale = ref_logits.abs().max().item()
         assert err < 0.03 * scale + 0.03, (t, err, scale)
@@ -64,6 +77,113 @@ def test_decoder_matches_dense_attention_when_everything_is_sampled():
     assert float(dec.attention_server.nnz.float().mean()) > 0.97 * (P - 68)
     dec.attention_server.window_server.check()
     dec.dense_server.check()
+
+
+def test_decoder_in_the_sampling_regime_against_the_pinned_oracle_parts():
+    """One decode step of the harness with K = 8, L = 48 on 4 096 offloaded tokens (~1.6 % of them sampled, importance
+    weights over several orders of magnitude): every sparse layer's attention, as the harness really called it (query
+    after RoPE, this step's k / v, the stores as the prefill left them), is recomputed from the PINNED oracle parts --
+    oracle SimHash + retrieve + importance-corrected attention over the offloaded tokens, exact attention over the
+    static window, one softmax over their union (tests/test_gpu_configs._oracle_union) -- and must agree within 1 bf16
+    ulp; the selected counts must agree exactly."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import numpy as np
+
+    import synth
+    from magicpig_amd import decode_harness as dh
+    from test_gpu_configs import _oracle_union
+
+    shape = dh.LlamaShape(hidden_size=512, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2,
+                          intermediate_size=1024, vocab_size=1000)
+    B, H, Hkv, D, K, L = 2, 4, 2, 128, 8, 48
+    P, M = 4096 + 68, 4224
+    n = P - 68
+    dec = dh.SyntheticLlamaDecoder(shape, K=K, L=L, batch_size=B, max_length=M, generation_buffer=8,
+                                   dense_layers=(0,), seed=11)
+    for b in range(B):
+        dec.prefill_synthetic(b, P, seed=20 + b)
+    srv = dec.attention_server
+    calls = []
+    inner = srv.decode_full_fused
+
+    def recording(q, k, v, li):
+        out = inner(q, k, v, li)
+        calls.append((li, q.reshape(B * H, D).clone(), out.reshape(B * H, D).clone(), srv.nnz.clone(),
+                      srv.max_value_expsum[1].clone()))
+        return out
+
+    srv.decode_full_fused = recording
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    ids = torch.randint(0, 1000, (B, 1), device="cuda", generator=gen)
+    pos = torch.full((B, 1), P, device="cuda", dtype=torch.long)
+    logits = dec.inference(ids, pos)
+    torch.cuda.synchronize()
+    srv.window_server.check()
+    assert torch.isfinite(logits).all() and len(calls) == 2
+    bits = lambda t: t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)       # noqa: E731
+    W = bits(srv.hash_func)
+    rows = 68 + 1                                                  # sink + local + this step's token
+    c = dict(B=B, H=H, Hkv=Hkv, D=D, K=K, L=L, n=n, M=M)
+    for li, q, out, nnz, lse in calls:
+        kc, vc = srv.attn_server.get_key_cache(li), srv.attn_server.get_value_cache(li)
+        kn = srv.attn_server.get_key_norm(li)
+        keys = [bits(kc[b, :, :n]) for b in range(B)]
+        vals = [bits(vc[b, :, :n]) for b in range(B)]
+        kns = [kn[b, :, :n].cpu().numpy().copy() for b in range(B)]
+        wkc, wvc = srv.window_server.get_key_cache(li), srv.window_server.get_value_cache(li)
+        wk = [bits(wkc[b, :, :rows]) for b in range(B)]
+        wv = [bits(wvc[b, :, :rows]) for b in range(B)]
+        ref, ref_lse = _oracle_union(c, keys, kns, vals, W, bits(q), wk, wv, nnz.cpu().numpy())
+        assert 20 < float(nnz.float().mean()) < 0.05 * n           # the sampling regime, not "everything"
+        assert np.allclose(out.float().cpu().numpy(), ref, rtol=2 ** -7, atol=2e-4), li
+        assert np.allclose(lse.cpu().numpy(), ref_lse, atol=1e-3), li
+
+
+def test_llama_8b_shaped_step_is_finite_and_both_window_forms_agree():
+    """The timed configuration of bench.py --end-to-end, checked: one decode step of the Llama-3.1-8B-shaped decoder
+    (32 layers, hidden 4096, 32 / 8 heads, K10 L150, synthetic weights, 4 096 offloaded tokens) gives finite logits,
+    every sparse layer samples, and on every sparse layer's REAL inputs (query after RoPE, this step's k / v) the two
+    forms of the layer -- decode_full_fused (window folded into the decode launch) and decode_full (append, window
+    attention, hot path, merge_state) -- agree up to the bf16 rounding of the four-launch form's partial outputs.
+    (Layer by layer, not on the final logits: LSH sampling is discontinuous in the query, so a one-ulp difference in
+    one layer's output selects other tokens in the next and the two 30-layer trajectories part ways.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import numpy as np
+
+    from magicpig_amd import decode_harness as dh
+
+    P = 4096 + 68
+    dec = dh.SyntheticLlamaDecoder(dh.LLAMA_3_1_8B, K=10, L=150, batch_size=1, max_length=4224, generation_buffer=8,
+                                   dense_layers=(0, 16), seed=2)
+    dec.prefill_synthetic(0, P, seed=4)
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    ids = torch.randint(0, dec.shape.vocab_size, (1, 1), device="cuda", generator=gen)
+    pos = torch.full((1, 1), P, device="cuda", dtype=torch.long)
+    srv = dec.attention_server
+    calls = []
+    inner = srv.decode_full_fused
+
+    def recording(q, k, v, li):
+        out = inner(q, k, v, li)
+        calls.append((li, q.clone(), k.clone(), v.clone(), out.clone(), srv.nnz.clone()))
+        return out
+
+    srv.decode_full_fused = recording
+    logits = dec.inference(ids, pos)
+    torch.cuda.synchronize()
+    srv.window_server.check()
+    dec.dense_server.check()
+    assert torch.isfinite(logits).all() and logits.shape == (1, 1, dec.shape.vocab_size)
+    assert len(calls) == 30 and min(float(c[5].float().mean()) for c in calls) > 10
+    # the four-launch form on the same inputs: its append rewrites the row the fused step appended (same row, same
+    # values), the window lengths still stand
+    for li, q, k, v, out, nnz in calls:
+        h4 = srv.decode_full(q, k, v, li)
+        assert torch.equal(srv.nnz, nnz), li
+        assert np.allclose(h4.float().cpu().numpy(), out.float().cpu().numpy(), rtol=2 ** -6, atol=4e-3), li
+    srv.window_server.check()
 
 
 def test_decode_benchmark_loop_runs():

@@ -84,3 +84,32 @@ def test_bench_configs_match_baseline_json():
     assert len([i for i in range(c4["layers"]) if i not in c4["dense"]]) == 75
     for c in bench.CONFIGS.values():
         assert c["M"] >= c["P"] - 68
+
+
+def test_harness_rope_and_rmsnorm_match_the_reference_fixture():
+    """SURVEY f-3: the two pieces of model plumbing the decode-step harness restates (magicpig_amd/decode_harness.py:
+    rope_tables / apply_rotary_pos_emb / rms_norm) against tests/golden/llama_ops.npz -- the torch-CPU execution of
+    models/llama.py:114-126 and models/utils.py:29-45 verbatim, and flashinfer.rmsnorm's published definition.  Bit
+    for bit on the CPU (same torch, same arithmetic); the tables may differ from the fixture in the last bf16 bit only
+    where torch.outer and the reference's batched matmul round a product differently (none observed)."""
+    import numpy as np
+    import torch
+
+    import cases
+    import synth
+    from magicpig_amd import decode_harness as dh
+
+    g = cases.load_golden("llama_ops")
+    c = cases.LLAMA_OPS
+    x, w, q, k = cases.llama_ops_inputs(c)
+    bits = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16)       # noqa: E731
+    cos, sin = dh.rope_tables(c["D"], c["max_len"], c["theta"], "cpu")
+    rows = list(c["positions"])
+    assert np.array_equal(bits(cos[rows]), g["cos_rows"]) and np.array_equal(bits(sin[rows]), g["sin_rows"])
+    qt, kt = synth.to_torch_bf16(q), synth.to_torch_bf16(k)
+    for p in c["positions"]:
+        pos = torch.full((c["B"], 1), p, dtype=torch.long)
+        assert np.array_equal(bits(dh.apply_rotary_pos_emb(qt, cos, sin, pos)), g[f"q_rope_{p}"])
+        assert np.array_equal(bits(dh.apply_rotary_pos_emb(kt, cos, sin, pos)), g[f"k_rope_{p}"])
+    got = dh.rms_norm(synth.to_torch_bf16(x), synth.to_torch_bf16(w), c["eps"])
+    assert np.array_equal(bits(got), g["rmsnorm"])
