@@ -12,10 +12,11 @@
  *   - every function returns MP_OK (0) or an MP_ERR_* code; mp_last_error() gives the text
  *     (an ADDITION over the reference, which has no error reporting at all: lsh.cc asserts
  *     are compiled out by -DNDEBUG and wrong shapes corrupt memory);
- *   - `mem` says where caller buffers live: MP_MEM_HOST buffers are staged through HBM
- *     (drop-in for the reference's CPU-tensor callers, models/attnserver.py:59-66);
- *     MP_MEM_DEVICE buffers are used in place (fast path: codes, results and nnz never
- *     leave HBM);
+ *   - `mem` says where caller buffers live: MP_MEM_HOST buffers (the reference's CPU-tensor callers,
+ *     models/attnserver.py:59-66) are used IN PLACE by the kernels where they can be mapped -- pinned
+ *     memory as it is, a large pageable buffer registered once per (pointer, size) and kept mapped
+ *     until the handle is destroyed -- and staged through handle-owned pinned blocks otherwise;
+ *     MP_MEM_DEVICE buffers are used in place (fast path: codes, results and nnz never leave HBM);
  *   - `stream` is a hipStream_t (NULL = default stream); work is enqueued asynchronously for
  *     MP_MEM_DEVICE arguments, synchronously completed for MP_MEM_HOST arguments;
  *   - all state (tables, KV, norms, scratch) lives in HBM of the device that was current at
@@ -76,7 +77,11 @@ int mp_simhash_set_planes(mp_simhash_t* s, int D, int K, int L, const uint16_t* 
 int mp_simhash_query(mp_simhash_t* s, const uint16_t* q, int R, int32_t* codes, float* qnorm,
                      int mem, mp_stream_t stream);
 /* keys: bf16 [Hkv, n, D] (centred keys); codes: int16 [Hkv, L, n] (== hash_code_buffer[:, :, :n],
- * attnserver.py:159-168: no normalisation, transposed, int16). */
+ * attnserver.py:159-168: no normalisation, transposed, int16).
+ * Key and query codes are the sign of the EXACT dot product (f32 accumulation + exact recomputation inside a guard
+ * band).  The reference's bf16 GEMM decides a bit by its summation order where the exact value is zero or within
+ * rounding of it: ~1e-8 of the bits can differ from torch's (the fixtures list them, tests/golden: kcodes_ties), so
+ * hash the keys AND the queries with this library. */
 int mp_simhash_keys(mp_simhash_t* s, const uint16_t* keys, int Hkv, int64_t n, int16_t* codes,
                     int mem, mp_stream_t stream);
 
@@ -200,7 +205,9 @@ int mp_debug_xcd_round_robin(void);
  *                        30 ids) for every (table, bucket, token range) piece; read by mp_lsh_alloc
  *   "attn_head_kernel"   -1 = auto, 0 = split-KV kernel with the in-launch ticket merge, 1 = one workgroup per head
  *   "attn_gx"            0 = auto, n = split-KV workgroups per head
- *   "attn_dense_grouped" 1 = mp_attn_full reads K/V once per kv group (default), 0 = once per query head */
+ *   "attn_dense_grouped" 1 = mp_attn_full reads K/V once per kv group (default), 0 = once per query head
+ *   "host_zero_copy"     1 = MP_MEM_HOST calls let the kernels read / write the caller's buffers in place (default),
+ *                        0 = staged copies through the handle's pinned blocks (the fallback, kept under test) */
 int mp_debug_set_option(const char* name, int value);
 int mp_debug_get_option(const char* name, int* value);
 

@@ -1214,6 +1214,37 @@ def test_token_range_sub_bounds_and_unstable_fill(mp, H, Hkv, B):
                 assert np.all((piece >= r * rl) & (piece < (r + 1) * rl))
 
 
+def test_unstable_fill_needs_a_permutation_and_says_so(mp):
+    """with R > 1 a bucket whose ids do not ascend sends LSH.fill down the re-sort path, which needs the
+    ids of a row to be a permutation of [0, n).  An id in [n, max_length) -- accepted by the sorted path -- is reported
+    there with a message of its own instead of being dropped silently; fill_offload checks its device and lengths
+    before it allocates."""
+    import magicpig_amd._lib as L_
+
+    K, L, H, Hkv, n, M = 6, 5, 8, 2, 3000, 3200
+    codes = torch.from_numpy(synth.randint(77, 0, 1 << K, (Hkv, L, n)).astype(np.int16)).cuda()
+    lsh = mp.LSH()
+    lsh.alloc(K, L, 1, H, Hkv, 1, M)
+    assert lsh.R == 8
+    rnd = torch.from_numpy(synth.randint(10, 0, 1 << 30, (Hkv, L, n))).cuda()
+    order = torch.argsort(codes.long() * (1 << 31) + rnd, dim=-1)              # unstable: ids shuffled inside buckets
+    sc, ids = torch.gather(codes, -1, order).contiguous(), order.int().contiguous()
+    lsh.fill(0, 0, sc, ids)                                                     # fine: re-sorted on device
+    bad = ids.clone()
+    bad[0, 0, 5] = n + 7                                                        # < max_length, but names no token
+    with pytest.raises(L_.MagicPigError) as e:
+        lsh.fill(0, 0, sc, bad)
+    assert e.value.code == 6 and "not a permutation" in str(e.value)
+    lsh.fill(0, 0, sc, ids)                                                     # the handle stays usable
+    srv = mp.SparseAttentionServer()
+    srv.alloc(1, H, Hkv, 128, 1, M)
+    kc = torch.zeros((100, Hkv, 128), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError):
+        srv.fill_offload(0, 0, kc, kc, 60, 4, 64)                               # nothing to offload
+    with pytest.raises(ValueError):
+        srv.fill_offload(0, 0, kc.cpu(), kc.cpu(), 100, 4, 64)                  # not on the store's device
+
+
 def test_table_build_rejects_codes_out_of_range(mp):
     K, Hkv, L, n = 6, 1, 3, 500
     codes = torch.from_numpy(synth.randint(5, 0, 1 << K, (Hkv, L, n)).astype(np.int16)).cuda()
