@@ -588,6 +588,8 @@ def main():
             with open(tpath) as f:
                 tj = json.load(f)
             key = "lsh_decode_bytes_per_launch" if fused else "two_launch_bytes_per_layer"
+            if args.data != "randn":
+                key += "_" + args.data              # PMC passes exist per key distribution (or not at all)
             traffic = (tj.get(key) or {}).get(args.config)
             if traffic is not None:
                 traffic_source = "not measured in this run: rocprofv3 PMC passes of " + str(tj.get("source", "profiles/"))
