@@ -178,7 +178,8 @@ int mp_attn_get_key_norm(mp_attn_t* h, int layer_id, void** kn_dev);
  * so the view is defined after a call the host issued, not after the replay of a captured graph. */
 int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream);
 
-/* Debug: device buffer of >= 64 uint64 receiving 100 MHz wall-clock stamps at the phase
+/* Debug (builds with -DMP_STAMPS=1 only -- scripts/build_variant.py stamps -DMP_STAMPS=1; a no-op in the product build):
+ * device buffer of >= 64 uint64 receiving 100 MHz wall-clock stamps at the phase
  * boundaries of workgroup 0 of the hot kernels (scripts/phase_times.py); NULL switches it off. */
 int mp_debug_set_stamp_buffer(void* dev_u64x64);
 

@@ -21,6 +21,7 @@ hipError_t launch_simhash_query(const uint16_t*, const uint16_t*, const float*, 
 hipError_t launch_simhash_keys(const uint16_t*, const uint16_t*, const float*, int, int64_t, int,
                                int, int, int16_t*, hipStream_t);
 size_t retrieve_lds_bytes(int64_t M, int L);
+size_t lsh_lds_limit();
 int lsh_range_len(int64_t M, int R);
 bool lsh_decode_supported(int64_t M, int L, int D, int R);
 bool xcd_round_robin_verified();
@@ -461,7 +462,7 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
                MP_ERR_INVALID, "mp_lsh_alloc: bad head/layer/batch counts");
     MP_REQUIRE(max_length >= 1 && max_length <= (1 << 22), MP_ERR_INVALID,
                "mp_lsh_alloc: max_length must be in [1, 2^22]");
-    MP_REQUIRE(retrieve_lds_bytes(max_length, L) <= 160 * 1024, MP_ERR_UNSUPPORTED,
+    MP_REQUIRE(retrieve_lds_bytes(max_length, L) <= lsh_lds_limit(), MP_ERR_UNSUPPORTED,
                "mp_lsh_alloc: collision bitmaps for max_length do not fit the 160 KiB LDS");
     h->device = current_device();
     h->K = K; h->L = L; h->NB = 1 << K; h->layers = num_layers;

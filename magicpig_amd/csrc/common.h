@@ -68,11 +68,17 @@ __device__ __forceinline__ void dot8_bf16_chain(float& acc, const u32x4& a, cons
 __device__ __forceinline__ void dot_settle(float& acc) { asm("s_nop 3" : "+v"(acc)); }
 
 // ---------------------------------------------------------------- debug phase timestamps
-// stamp == nullptr in production; set through mp_debug_set_stamp_buffer (scripts/phase_times.py).
-// One lane of workgroup 0 records the 100 MHz wall clock at phase boundaries.
-// A translation unit that defines MP_STAMP_STRIDE (an int lvalue in device memory) lets EVERY workgroup record:
-// workgroup b writes at [b * stride + slot] when the stride is > 0 (scripts/phase_spread.py).
-#ifdef MP_STAMP_STRIDE
+// Compiled in only with -DMP_STAMPS=1 (scripts/build_variant.py stamps -DMP_STAMPS=1; the measurement scripts load that
+// build): the product's kernels carry no stamp code at all.  There: stamp == nullptr unless set through
+// mp_debug_set_stamp_buffer (scripts/phase_times.py); one lane of workgroup 0 records the 100 MHz wall clock at phase
+// boundaries.  A translation unit that defines MP_STAMP_STRIDE (an int lvalue in device memory) lets EVERY workgroup
+// record: workgroup b writes at [b * stride + slot] when the stride is > 0 (scripts/phase_spread.py).
+#ifndef MP_STAMPS
+#define MP_STAMPS 0
+#endif
+#if !MP_STAMPS
+#define MP_STAMP(stamp, slot) do { } while (0)
+#elif defined(MP_STAMP_STRIDE)
 #define MP_STAMP(stamp, slot)                                                               \
     do {                                                                                    \
         if ((stamp) != nullptr && threadIdx.x == 0) {                                       \

@@ -36,6 +36,40 @@ __device__ int d_stamp_stride = 0;    // debug: > 0 = every workgroup records it
 
 #include <type_traits>
 #include "common.h"
+
+// Phase stamps of THIS translation unit are buffered in LDS and written out when thread 0 leaves the kernel
+// (MP_STAMP_FLUSH): a stamp written straight to memory is a store the next `s_waitcnt vmcnt(0)` of its wave waits for,
+// which charged every phase boundary ~0.1-0.5 us of the stamp's own round trip (scripts/phase_spread.py).
+#if MP_STAMPS
+namespace mp {
+__shared__ unsigned long long s_stampbuf[64];
+}
+#undef MP_STAMP
+#define MP_STAMP(stamp, slot)                                                                \
+    do {                                                                                     \
+        if ((stamp) != nullptr && threadIdx.x == 0) ::mp::s_stampbuf[(slot)] = wall_clock64(); \
+    } while (0)
+#define MP_STAMP_INIT(stamp)                                                                 \
+    do {                                                                                     \
+        if ((stamp) != nullptr && threadIdx.x == 0)                                          \
+            for (int _i = 0; _i < 64; ++_i) ::mp::s_stampbuf[_i] = 0ull;                     \
+    } while (0)
+#define MP_STAMP_FLUSH(stamp)                                                                \
+    do {                                                                                     \
+        if ((stamp) != nullptr && threadIdx.x == 0) {                                        \
+            const int _ss = MP_STAMP_STRIDE;                                                 \
+            if (_ss > 0 || (blockIdx.x | blockIdx.y | blockIdx.z) == 0) {                    \
+                unsigned long long* _d = (stamp) + (_ss > 0 ? (size_t)blockIdx.x * _ss : 0); \
+                for (int _i = 0; _i < 64; ++_i)                                              \
+                    if (::mp::s_stampbuf[_i] != 0ull) _d[_i] = ::mp::s_stampbuf[_i];         \
+            }                                                                                \
+        }                                                                                    \
+    } while (0)
+#else
+#define MP_STAMP_INIT(stamp) do { } while (0)
+#define MP_STAMP_FLUSH(stamp) do { } while (0)
+#endif
+
 #include "attn_head.h"
 
 namespace mp {
@@ -487,6 +521,7 @@ __device__ __forceinline__ void lsh_head_body(
     const int64_t h = (AD > 0) ? (int64_t)(blockIdx.x % BHp) : (int64_t)blockIdx.x;
     const int rank = (AD > 0) ? (int)(blockIdx.x / BHp) : 0;
     if (AD > 0 && h >= aa.BH) return;
+    MP_STAMP_INIT(stamp);
     const int clog = (AD > 0) ? aa.cluster_log2 : 0;
     const bool lead = rank == 0;                              // the member that writes codes / ||q||
     const int64_t g = h / G;
@@ -980,7 +1015,10 @@ __device__ __forceinline__ void lsh_head_body(
     }
     if (tid == 0 && (AD == 0 || clog == 0)) nnz[h] = total;
     MP_STAMP(stamp, 21);
-    if (AD == 0) return;
+    if (AD == 0) {
+        MP_STAMP_FLUSH(stamp);
+        return;
+    }
 
     // ------------------------------------------------------------ fused sparse attention of head h
     constexpr int ADD = AD > 0 ? AD : 64;
@@ -992,6 +1030,7 @@ __device__ __forceinline__ void lsh_head_body(
     }
     if (clog == 0 && total == 0 && wlen == 0) {
         attn_head_empty<ADD>(out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
+        MP_STAMP_FLUSH(stamp);
         return;
     }
     __syncthreads();                        // s_ids complete; the spilled list drained (vmcnt) and visible in L2
@@ -1039,6 +1078,7 @@ __device__ __forceinline__ void lsh_head_body(
     if (clog == 0) {
         attn_head_finalize<ADD>(m, Z, o0, o1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
         MP_STAMP(stamp, 39);
+        MP_STAMP_FLUSH(stamp);
         return;
     }
     // ---- cluster > 1: publish this member's state (a member without tokens publishes m = -inf, Z = 0), drain,
@@ -1084,7 +1124,10 @@ __device__ __forceinline__ void lsh_head_body(
             ticket = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         MP_STAMP(stamp, 38);
-        if (ticket != nmem - 1) return;
+        if (ticket != nmem - 1) {
+            MP_STAMP_FLUSH(stamp);
+            return;
+        }
         if (lane == 0) {
             __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             // split hash: every member is past the exchange -- the next launch gets a new sequence number
@@ -1133,7 +1176,10 @@ __device__ __forceinline__ void lsh_head_body(
             ticket = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         MP_STAMP(stamp, 38);
-        if (ticket != nmem - 1) return;
+        if (ticket != nmem - 1) {
+            MP_STAMP_FLUSH(stamp);
+            return;
+        }
         if (lane == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -1179,6 +1225,7 @@ __device__ __forceinline__ void lsh_head_body(
     attn_head_finalize<ADD>(mm, ZZ, q0, q1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);   // ZZ = 0: no member had a token
     if (lane == 0) nnz[h] = csum;
     MP_STAMP(stamp, 39);
+    MP_STAMP_FLUSH(stamp);
 }
 
 // LSH::batch_retrieve (optionally with the query hash as its prologue)
@@ -1274,6 +1321,10 @@ struct DeviceOnce {
         return e;
     }
 };
+
+// dynamic LDS a retrieve / decode workgroup may ask for: the CU's 160 KiB minus the static 512-byte stamp buffer (+ slack)
+constexpr size_t RT_LDS_DYN_MAX = 160u * 1024u - 1024u;
+size_t lsh_lds_limit() { return RT_LDS_DYN_MAX; }
 
 // dynamic LDS of the retrieve body for a workgroup that owns `tokens` tokens
 static size_t body_lds_bytes(int64_t tokens, int L) {
@@ -1444,7 +1495,7 @@ static hipError_t retrieve_attr_set() {
                          reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, true, 3>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, true, 3>)};
     for (const void* f : fns) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RT_LDS_DYN_MAX);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -1494,7 +1545,7 @@ hipError_t launch_lsh_hash_retrieve(const int32_t* bounds, const int32_t* table,
 // the whole sparse layer in ONE launch (mp_decode_sparse_layer): hash + retrieve + attention.
 // D = 64 or 128; R = workgroups per head = token ranges of the tables (1, 2, 4 or 8).
 bool lsh_decode_supported(int64_t M, int L, int D, int R) {
-    return (D == 64 || D == 128) && decode_lds_bytes(lsh_range_len(M, R), L, D) <= 160u * 1024u;
+    return (D == 64 || D == 128) && decode_lds_bytes(lsh_range_len(M, R), L, D) <= RT_LDS_DYN_MAX;
 }
 
 hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const uint16_t* q,

@@ -1,5 +1,7 @@
 import sys, os, torch, numpy as np
 sys.path.insert(0, "/root/repo")
+import magicpig_amd._lib as _L0
+_L0.LIB_PATH = os.path.join(ROOT, 'magicpig_amd', 'lib', 'variants', 'stamps', 'libmagicpig_hip.so')   # -DMP_STAMPS=1 build (scripts/build_variant.py stamps -DMP_STAMPS=1)
 import magicpig_amd as mp, magicpig_amd._lib as L
 n, D, K, Lt, Hkv = 97932, 128, 10, 150, 8
 W = torch.randn((D, K*Lt), device="cuda").to(torch.bfloat16)

@@ -6,6 +6,13 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import magicpig_amd._lib as L
+# the product's kernels carry no stamp code: load the -DMP_STAMPS=1 build (built on demand; MP_LIB= overrides)
+STAMP_LIB = os.path.join(ROOT, "magicpig_amd", "lib", "variants", "stamps", "libmagicpig_hip.so")
+if not os.environ.get("MP_LIB"):
+    if not os.path.exists(STAMP_LIB):
+        import subprocess
+        subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "build_variant.py"), "stamps", "-DMP_STAMPS=1"], check=True)
+    L.LIB_PATH = STAMP_LIB
 if os.environ.get("MP_LIB"):
     L.LIB_PATH = os.path.abspath(os.environ["MP_LIB"])
 import magicpig_amd as mp
