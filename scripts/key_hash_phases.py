@@ -1,5 +1,6 @@
 import sys, os, torch, numpy as np
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import magicpig_amd._lib as _L0
 _L0.LIB_PATH = os.path.join(ROOT, 'magicpig_amd', 'lib', 'variants', 'stamps', 'libmagicpig_hip.so')   # -DMP_STAMPS=1 build (scripts/build_variant.py stamps -DMP_STAMPS=1)
 import magicpig_amd as mp, magicpig_amd._lib as L
