@@ -13,9 +13,9 @@
  *     (an ADDITION over the reference, which has no error reporting at all: lsh.cc asserts
  *     are compiled out by -DNDEBUG and wrong shapes corrupt memory);
  *   - `mem` says where caller buffers live: MP_MEM_HOST buffers (the reference's CPU-tensor callers,
- *     models/attnserver.py:59-66) are used IN PLACE by the kernels where they can be mapped -- pinned
- *     memory as it is, a large pageable buffer registered once per (pointer, size) and kept mapped
- *     until the handle is destroyed -- and staged through handle-owned pinned blocks otherwise;
+ *     models/attnserver.py:59-66) are used IN PLACE by the kernels where they are pinned; for a
+ *     pageable buffer the kernels work on a pinned mirror owned by the handle and the host copies the
+ *     live entries across (or, on request, the buffer is registered once: "host_register");
  *     MP_MEM_DEVICE buffers are used in place (fast path: codes, results and nnz never leave HBM);
  *   - `stream` is a hipStream_t (NULL = default stream); work is enqueued asynchronously for
  *     MP_MEM_DEVICE arguments, synchronously completed for MP_MEM_HOST arguments;
@@ -207,8 +207,12 @@ int mp_debug_xcd_round_robin(void);
  *   "attn_head_kernel"   -1 = auto, 0 = split-KV kernel with the in-launch ticket merge, 1 = one workgroup per head
  *   "attn_gx"            0 = auto, n = split-KV workgroups per head
  *   "attn_dense_grouped" 1 = mp_attn_full reads K/V once per kv group (default), 0 = once per query head
- *   "host_zero_copy"     1 = MP_MEM_HOST calls let the kernels read / write the caller's buffers in place (default),
- *                        0 = staged copies through the handle's pinned blocks (the fallback, kept under test) */
+ *   "host_zero_copy"     1 = MP_MEM_HOST calls let the kernels work on pinned memory in place -- the caller's pinned
+ *                        buffers, or the handle's pinned mirror of a pageable one (default); 0 = staged copies through
+ *                        the copy engine (the fallback, kept under test)
+ *   "host_register"      1 = a large PAGEABLE caller buffer (results_lsh_cpu, models/attnserver.py:60) is registered
+ *                        (hipHostRegister) once per (pointer, size) and used in place until the handle is destroyed --
+ *                        only for callers whose buffers live as long as the handle; 0 (default) = pinned mirror */
 int mp_debug_set_option(const char* name, int value);
 int mp_debug_get_option(const char* name, int* value);
 

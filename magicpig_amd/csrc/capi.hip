@@ -44,6 +44,8 @@ hipError_t launch_lsh_hash_retrieve(const int32_t*, const int32_t*, const uint16
                                     const float*, int, int, int, int32_t*, float*, int32_t*, int32_t*,
                                     int, int, int, int, int64_t, int, hipStream_t);
 hipError_t launch_lsh_compact(uint32_t*, const int*, int, int, int64_t, hipStream_t);
+hipError_t launch_lsh_hash_only(const uint16_t*, const uint16_t*, const float*, int, int, int, int32_t*, float*, int, int,
+                                hipStream_t);
 hipError_t launch_lsh_mask(const int32_t*, const int32_t*, const int32_t*, int8_t*, int, int, int, int,
                            int64_t, int, hipStream_t);
 int attn_slices_per_head(int64_t M);
@@ -92,7 +94,8 @@ struct DebugOptions {
     std::atomic<int> attn_head_kernel{-1};   // -1 = auto, 0 = split-KV kernel, 1 = one workgroup per head
     std::atomic<int> attn_gx{0};             // 0 = auto, else split-KV workgroups per head
     std::atomic<int> attn_dense_grouped{1};  // full_attention: 1 = K/V read once per kv group, 0 = once per query head
-    std::atomic<int> host_zero_copy{1};      // MP_MEM_HOST calls: 1 = kernels read / write the caller's buffers in place, 0 = staged copies
+    std::atomic<int> host_zero_copy{1};      // MP_MEM_HOST calls: 1 = kernels work on pinned memory in place (the caller's, or the handle's mirror), 0 = staged copies
+    std::atomic<int> host_register{0};       // 1 = a large PAGEABLE caller buffer is registered (hipHostRegister) once and used in place
 };
 static DebugOptions g_opt;
 
@@ -108,6 +111,7 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "attn_gx")) return &g_opt.attn_gx;
     if (!strcmp(name, "attn_dense_grouped")) return &g_opt.attn_dense_grouped;
     if (!strcmp(name, "host_zero_copy")) return &g_opt.host_zero_copy;
+    if (!strcmp(name, "host_register")) return &g_opt.host_register;
     return nullptr;
 }
 
@@ -188,16 +192,20 @@ struct Stage {
 
 // Host-buffer mode without copies: the address at which a KERNEL can read / write a caller's host buffer in place.
 // The reference's callers hold pinned tensors (models/attnserver.py:59-66: hipHostMalloc through torch's pin_memory):
-// those are mapped already.  A large pageable buffer (results_lsh_cpu, :60: 12.6 MB at cfg 1) is registered ONCE per
-// (pointer, size) and stays registered until the handle is freed; small pageable buffers are not worth a registration
-// and go through the handle's pinned block.  nullptr = not mappable: the staged path is used.
+// those are mapped already.  A PAGEABLE buffer (results_lsh_cpu and nnz, :59-60) is not touched by default: the
+// kernels work on a pinned mirror owned by the handle and the host copies the live entries across (a registration
+// outlives the buffer it was made for -- a caller that frees and re-allocates would be served the old pages).  With the
+// `host_register` option a large pageable buffer is registered ONCE per (pointer, size) and used in place until the
+// handle is freed: for callers whose buffers live as long as the handle, as the reference's server object's do.
+// nullptr = not mappable.
 struct HostMap {
     struct Reg { const char* p; size_t bytes; char* dev; };
     std::vector<Reg> regs;
-    void* resolve(const void* ptr, size_t bytes) {
+    void* resolve(const void* ptr, size_t bytes, bool may_register) {
         const char* p = reinterpret_cast<const char*>(ptr);
-        for (const Reg& r : regs)
-            if (r.p <= p && p + bytes <= r.p + r.bytes) return r.dev + (p - r.p);
+        if (may_register)
+            for (const Reg& r : regs)
+                if (r.p <= p && p + bytes <= r.p + r.bytes) return r.dev + (p - r.p);
         hipPointerAttribute_t a;
         if (hipPointerGetAttributes(&a, ptr) == hipSuccess) {
             if (a.type == hipMemoryTypeHost && a.devicePointer != nullptr) return a.devicePointer;
@@ -205,7 +213,7 @@ struct HostMap {
         } else {
             (void)hipGetLastError();                               // pageable memory: "invalid value" on older runtimes
         }
-        if (bytes < (256u << 10)) return nullptr;
+        if (!may_register || bytes < (256u << 10)) return nullptr;
         if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterMapped) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;
@@ -372,8 +380,13 @@ int mp_simhash_query(mp_simhash_t* s, const uint16_t* q, int R, int32_t* codes, 
     MP_REQUIRE(q && codes && R >= 1, MP_ERR_INVALID, "mp_simhash_query: bad argument");
     hipStream_t st = (hipStream_t)stream;
     if (mem == MP_MEM_DEVICE) {
-        MP_HIP_CHECK(launch_simhash_query(q, s->Wt, s->wnorm, R, s->D, s->K, s->L, codes, qnorm,
-                                          s->dbg_acc, st));
+        // a handful of rows (a decode step's B*H <= 64 query heads): one workgroup per row on the vector pipes; the MFMA
+        // kernel's 32-row tiles take the bulk case (same exact-sign definition: identical codes, tests/test_gpu_parity.py)
+        if (R <= 64 && s->dbg_acc == nullptr && qnorm != nullptr)
+            MP_HIP_CHECK(launch_lsh_hash_only(q, s->Wk, s->wnorm, s->D, s->K, s->KLpad, codes, qnorm, R, s->L, st));
+        else
+            MP_HIP_CHECK(launch_simhash_query(q, s->Wt, s->wnorm, R, s->D, s->K, s->L, codes, qnorm,
+                                              s->dbg_acc, st));
         return MP_OK;
     }
     DevBuf dq, dc, dn;
@@ -647,7 +660,16 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     int rc = h->small.reserve(qb + (size_t)(2 * BH + 1) * 4);
     if (rc) return rc;
     if (g_opt.host_zero_copy.load() != 0 && h->small.hd != nullptr) {
-        if (void* res_dev = h->hostmap.resolve(results, (size_t)BH * h->M * 4)) {
+        const size_t rbytes = (size_t)BH * h->M * 4;
+        void* res_dev = h->hostmap.resolve(results, rbytes, g_opt.host_register.load() != 0);
+        bool mirror = false;
+        if (res_dev == nullptr) {                 // pageable `results`: the kernel writes the handle's pinned mirror
+            rc = h->big.reserve(rbytes);
+            if (rc) return rc;
+            res_dev = h->big.hd;
+            mirror = res_dev != nullptr;
+        }
+        if (res_dev != nullptr) {
             char* hp = reinterpret_cast<char*>(h->small.hp);
             char* hd = reinterpret_cast<char*>(h->small.hd);
             const size_t o_codes = (size_t)(2 * BH + 1) * 4;
@@ -660,6 +682,14 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
                                              h->G, h->L, h->NB, h->M, h->R, st));
             MP_HIP_CHECK(hipStreamSynchronize(st));
             memcpy(nnz, hp, (size_t)BH * 4);
+            if (mirror) {                         // only the first nnz[h] entries of a row mean anything
+                const int32_t* rows = reinterpret_cast<const int32_t*>(h->big.hp);
+                for (int i = 0; i < BH; ++i) {
+                    int64_t z = nnz[i];
+                    z = z < 0 ? 0 : (z > h->M ? h->M : z);
+                    if (z > 0) memcpy(results + (size_t)i * h->M, rows + (size_t)i * h->M, (size_t)z * 4);
+                }
+            }
             return MP_OK;
         }
     }
@@ -1008,17 +1038,29 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
     memcpy(hp + o_q, query, qbytes);
     if (!dense) memcpy(hp + o_qn, qn, (size_t)BH * 4);
     memcpy(hp + o_nnz, nnz, (size_t)BH * 4);
-    // Zero copy: ONE launch brings (q | qn | nnz) and the first nnz[h] entries of every index row -- read straight from
-    // the caller's buffer (mapped once, HostMap) -- into HBM with coalesced reads, the attention kernel writes (out | mve)
-    // straight into the pinned block: two launches, ONE synchronisation, no copy engine.
+    int32_t* offs = reinterpret_cast<int32_t*>(hp + o_offs);
+    size_t total = 0;
+    for (int i = 0; i < BH; ++i) {
+        offs[i] = (int32_t)total;
+        int64_t z = nnz[i];
+        z = z < 0 ? 0 : (z > h->M ? h->M : z);
+        total += dense ? 0 : (size_t)z;
+    }
+    offs[BH] = (int32_t)total;
+    MP_REQUIRE(total <= (size_t)INT32_MAX, MP_ERR_UNSUPPORTED, std::string(who) + ": more than 2^31 index entries in one call");
+    // Zero copy: ONE launch brings (q | qn | nnz) and the first nnz[h] entries of every index row into HBM with
+    // coalesced reads over PCIe -- straight from the caller's rows where they are pinned (or registered on request,
+    // HostMap), else from the handle's pinned block, into which the host packs the live entries -- and the attention
+    // kernel writes (out | mve) straight into the pinned block: two or three launches, ONE synchronisation, no copy engine.
     if (g_opt.host_zero_copy.load() != 0 && h->small.hd != nullptr) {
-        const void* ind_dev = dense ? nullptr : h->hostmap.resolve(ind, (size_t)BH * h->M * 4);
-        if (dense || ind_dev != nullptr) {
-            char* hd = reinterpret_cast<char*>(h->small.hd);
-            if (dense) {
-                MP_HIP_CHECK(launch_relay(hd, dp, o_offs, st));
-            } else {
-                if (h->ind_rows == nullptr) MP_HIP_CHECK(hipMalloc((void**)&h->ind_rows, (size_t)BH * h->M * 4));
+        char* hd = reinterpret_cast<char*>(h->small.hd);
+        bool ok = true;
+        if (dense) {
+            MP_HIP_CHECK(launch_relay(hd, dp, o_offs, st));
+        } else {
+            if (h->ind_rows == nullptr) MP_HIP_CHECK(hipMalloc((void**)&h->ind_rows, (size_t)BH * h->M * 4));
+            const void* ind_dev = h->hostmap.resolve(ind, (size_t)BH * h->M * 4, g_opt.host_register.load() != 0);
+            if (ind_dev != nullptr) {
                 int64_t longest = 0;                                     // one PCIe round trip per thread: blocks by the longest row
                 for (int i = 0; i < BH; ++i) longest = nnz[i] > longest ? nnz[i] : longest;
                 longest = longest > h->M ? h->M : longest;
@@ -1027,7 +1069,23 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
                 MP_HIP_CHECK(launch_host_rows(reinterpret_cast<const int32_t*>(ind_dev),
                                               reinterpret_cast<const int32_t*>(hd + o_nnz), h->ind_rows, h->M, BH, hd, dp,
                                               o_offs, gx, st));
+            } else {                                                     // pageable rows: packed into the pinned block by the host
+                rc = h->big.reserve(total ? total * 4 : 4);
+                if (rc) return rc;
+                ok = h->big.hd != nullptr;
+                if (ok) {
+                    int32_t* packed = reinterpret_cast<int32_t*>(h->big.hp);
+                    for (int i = 0; i < BH; ++i)
+                        if (offs[i + 1] > offs[i])
+                            memcpy(packed + offs[i], ind + (size_t)i * h->M, (size_t)(offs[i + 1] - offs[i]) * 4);
+                    MP_HIP_CHECK(launch_relay(hd, dp, o_out, st));       // (q | qn | nnz | offsets)
+                    if (total > 0)
+                        MP_HIP_CHECK(launch_ragged_copy(false, h->ind_rows, reinterpret_cast<int32_t*>(h->big.hd),
+                                                        reinterpret_cast<const int32_t*>(dp + o_offs), BH, h->M, st));
+                }
             }
+        }
+        if (ok) {
             rc = attn_run(h, layer_id, dense, K, L, reinterpret_cast<uint16_t*>(hd + o_out),
                           reinterpret_cast<float*>(hd + o_mve), dp + o_q, query_dtype,
                           reinterpret_cast<const float*>(dp + o_qn), dense ? nullptr : h->ind_rows,
@@ -1039,16 +1097,6 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
             return MP_OK;                                         // (lastz = dp + o_nnz: valid until the next host call)
         }
     }
-    int32_t* offs = reinterpret_cast<int32_t*>(hp + o_offs);
-    size_t total = 0;
-    for (int i = 0; i < BH; ++i) {
-        offs[i] = (int32_t)total;
-        int64_t z = nnz[i];
-        z = z < 0 ? 0 : (z > h->M ? h->M : z);
-        total += dense ? 0 : (size_t)z;
-    }
-    offs[BH] = (int32_t)total;
-    MP_REQUIRE(total <= (size_t)INT32_MAX, MP_ERR_UNSUPPORTED, std::string(who) + ": more than 2^31 index entries in one call");
     MP_HIP_CHECK(hipMemcpyAsync(dp, hp, o_out, hipMemcpyHostToDevice, st));
     MP_HIP_CHECK(hipMemcpyAsync(h->last_nnz, dp + o_nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));   // outlives the call (get_score)
     const int32_t* indd = nullptr;

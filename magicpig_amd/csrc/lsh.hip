@@ -753,6 +753,13 @@ __device__ __forceinline__ void lsh_head_body(
         const uint32_t bp = (uint32_t)l * (uint32_t)ha.K, w = bp >> 5;
         return (int)(__funnelshift_r(s_bits[w], s_bits[w + 1], bp & 31u) & ((1u << ha.K) - 1u));
     };
+    if (AD == 0 && HASH == 1 && bounds == nullptr) {
+        // hash-only launch (mp_simhash_query on a handful of rows: one workgroup per row on the vector pipes is ~3.5 us
+        // in-kernel where the 32-row MFMA tiles of simhash_query_kernel, ten workgroups for 32 rows, take ~8)
+        for (int l = tid; l < L; l += RT_THREADS) ha.codes_out[h * L + l] = code_of(l);
+        MP_STAMP_FLUSH(stamp);
+        return;
+    }
     const int32_t* slots = (AD > 0) ? aa.slots : nullptr;
     if (AD > 0 && HASH != 0 && slots != nullptr) {
         // ---- DIRECT pieces: the piece (table l, bucket code, range rank) has a 128-byte slot holding its length,
@@ -1539,6 +1546,25 @@ hipError_t launch_lsh_hash_retrieve(const int32_t* bounds, const int32_t* table,
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 8>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, R, words,
                            Lpad, ha, g_stamp);
+    return hipGetLastError();
+}
+
+// the query SimHash alone, one workgroup per row (few rows; simhash.hip's MFMA kernel takes the bulk case)
+hipError_t launch_lsh_hash_only(const uint16_t* q, const uint16_t* Wk, const float* wnorm, int D, int K, int KLpad,
+                                int32_t* codes_out, float* qnorm_out, int rows, int L, hipStream_t st) {
+    const int Lpad = (L + 63) & ~63;
+    hipError_t e = retrieve_attr_once();
+    if (e != hipSuccess) return e;
+    HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
+    const size_t lds = body_lds_bytes(0, L);
+    if (D >= 128)
+        hipLaunchKernelGGL((lsh_retrieve_kernel<1, 16>), dim3(rows), dim3(RT_THREADS), lds, st, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 1, L,
+                           1 << K, (int64_t)0, 1, 0, Lpad, ha, g_stamp);
+    else
+        hipLaunchKernelGGL((lsh_retrieve_kernel<1, 8>), dim3(rows), dim3(RT_THREADS), lds, st, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 1, L,
+                           1 << K, (int64_t)0, 1, 0, Lpad, ha, g_stamp);
     return hipGetLastError();
 }
 

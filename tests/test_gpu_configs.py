@@ -385,6 +385,66 @@ def test_cfg1_clustered_full_size_vs_reference(mp):
         assert float((pieces > 30).float().mean()) > 0.02
 
 
+# ------------------------------------------------------------------ full size, non-isotropic keys, properties
+
+@pytest.mark.parametrize("cfg,data", [("cfg1", "skewed"), ("cfg2", "clustered")])
+def test_full_size_fused_decode_on_non_isotropic_keys(mp, cfg, data):
+    """bench.py's own key generators at BASELINE size -- cfg 1 on the SKEWED stress workload (9 % selected, up to
+    26 000 tokens per head, 36 % of the probed pieces leave their direct slot, 4 % go to the chunk pool, long lists
+    spill past the LDS id stage), cfg 2 (256 heads, one workgroup per head) on the CLUSTERED one -- through
+    size-independent properties: the one-launch entry equals hash -> batch_retrieve -> attention_wrapper on the same
+    stores (nnz bit for bit, outputs up to summation order), the selected sets are exactly {tokens colliding in >= 2
+    tables} recounted densely from the stored key codes, and V -> 2 V doubles the output exactly."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    c = bench.CONFIGS[cfg]
+    B, H, Hkv, D, K, L, P, M = (c[k] for k in ("B", "H", "Hkv", "D", "K", "L", "P", "M"))
+    n, BH, G = P - 68, B * H, H // Hkv
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(31)
+    W = torch.randn((D, K * L), device=dev, generator=gen).to(torch.bfloat16)
+    server = mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, max_length=M, dense_layers=(), hash_func=W)
+    kcodes = []
+    for b in range(B):
+        kc, vc = bench.synth_kv(data, P, Hkv, D, dev, gen)
+        server.fill(0, b, kc, vc, P)
+        kcodes.append(server.hash_code_buffer.clone())
+        server.build_table(0, b, P)
+    q = torch.randn((B, H, D), device=dev, generator=gen)
+    kcen = server.attn_server.get_key_cache(0)
+    j = torch.randint(0, n, (B, H), device=dev, generator=gen)
+    bi = torch.arange(B, device=dev)[:, None].expand(B, H)
+    gi = (torch.arange(H, device=dev) // G)[None, :].expand(B, H)
+    q = (0.5 * q + 3.0 * kcen[bi, gi, j].float()).to(torch.bfloat16).view(B, H, 1, D)
+    out, lse = server.decode(q, 0)
+    out, lse, nz1 = out.clone().reshape(BH, D), lse.clone().reshape(-1), server.nnz.clone()
+    server.attn_server.check()
+    codes, qn = server.hasher.query(q.reshape(BH, D))
+    res = torch.zeros((BH, M), dtype=torch.int32, device=dev)
+    nz = torch.zeros((BH,), dtype=torch.int32, device=dev)
+    server.lsh_retriever.batch_retrieve(0, codes, res, nz)
+    assert torch.equal(nz, nz1)
+    if data == "skewed":
+        assert int(nz.max()) > 8 * 4096 // 2                       # some member's list is longer than its LDS stage
+    for h in range(0, BH, max(1, BH // 6)):
+        b, g = h // H, (h % H) // G
+        cnt = (kcodes[b][g] == codes[h].to(torch.int16)[:, None]).sum(0)
+        assert torch.equal(torch.nonzero(cnt >= 2).flatten().int(), res[h, :int(nz[h])]), h
+    o_ref = torch.zeros((BH, D), dtype=torch.bfloat16, device=dev)
+    mve = torch.zeros((2, BH), dtype=torch.float32, device=dev)
+    server.attn_server.attention_wrapper(0, K, L, o_ref, mve, q.reshape(BH, D), qn, res, nz)
+    assert np.allclose(out.float().cpu().numpy(), o_ref.float().cpu().numpy(), rtol=2 ** -6, atol=2e-3)
+    assert np.allclose(lse.cpu().numpy(), mve[1].cpu().numpy(), atol=2e-3)
+    kvv = server.attn_server.get_value_cache(0)
+    kvv.mul_(2)
+    out2, lse2 = server.decode(q, 0)
+    assert torch.equal(out2.reshape(BH, D).float(), out.float() * 2)
+    assert torch.equal(lse2.reshape(-1), lse)
+
+
 # ------------------------------------------------------------------ BASELINE cfg 4 (per-GPU share) at full size
 
 def test_cfg4_full_size_fused_decode_properties(mp):

@@ -259,12 +259,13 @@ def test_pipeline_vs_reference_and_oracle(mp, name, where):
 
 
 @pytest.mark.parametrize("pinned", [True, False])
-@pytest.mark.parametrize("zero_copy", [1, 0])
-def test_host_buffer_modes_agree(mp, zero_copy, pinned):
-    """MP_MEM_HOST calls (the unchanged caller of models/attnserver.py:299-300): kernels working on the caller's
-    buffers in place (pinned tensors as :59-66, or a large pageable `results` registered once) and the staged-copy
-    fallback give what the device-buffer calls give, bit for bit; rows behind nnz stay untouched; a second call with
-    other queries reuses the mapping."""
+@pytest.mark.parametrize("mode", ["zero_copy", "register", "staged"])
+def test_host_buffer_modes_agree(mp, mode, pinned):
+    """MP_MEM_HOST calls (the unchanged caller of models/attnserver.py:299-300) give what the device-buffer calls
+    give, bit for bit, whichever way the buffers cross PCIe: kernels working on the caller's PINNED tensors in place
+    (:61-66), on the handle's pinned mirror for PAGEABLE ones (`results_lsh_cpu`, `nnz`, :59-60; the default), on a
+    pageable buffer registered once (`host_register`, for buffers that live as long as the handle), or through staged
+    copies (`host_zero_copy = 0`); rows behind nnz stay untouched; a second call with other queries works as the first."""
     import magicpig_amd._lib as L_
 
     g = cases.load_golden("gqa_32h")
@@ -278,7 +279,9 @@ def test_host_buffer_modes_agree(mp, zero_copy, pinned):
     lsh.fastfill(0, 0, sh.keys(bf16_t(keys[0], "cuda")))
     srv.fill(0, 0, bf16_t(keys[0], "cuda"), bf16_t(vals[0], "cuda"), torch.from_numpy(kns[0]).cuda())
     mk = (lambda t: t.pin_memory()) if pinned else (lambda t: t)
-    L_.set_option("host_zero_copy", zero_copy)
+    L_.set_option("host_zero_copy", 0 if mode == "staged" else 1)
+    L_.set_option("host_register", 1 if mode == "register" else 0)
+    keep = []                                           # registered buffers must outlive the handles
     try:
         for rep in range(2):
             q = bf16_t(qb if rep == 0 else np.roll(qb, 3, axis=0), "cuda")
@@ -293,6 +296,7 @@ def test_host_buffer_modes_agree(mp, zero_copy, pinned):
             d_probs = srv.get_score().reshape(BH, M).clone()
             h_codes, h_q, h_qn = mk(codes.cpu()), mk(q.cpu()), qn.cpu()
             h_res = mk(torch.full((BH, M), -7, dtype=torch.int32))
+            keep.append(h_res)
             h_nnz = torch.zeros((BH,), dtype=torch.int32)
             lsh.batch_retrieve(0, h_codes, h_res, h_nnz)
             assert torch.equal(h_nnz, d_nnz.cpu()) and torch.equal(h_res, d_res.cpu())       # incl. the -7 behind nnz
@@ -301,8 +305,10 @@ def test_host_buffer_modes_agree(mp, zero_copy, pinned):
             srv.attention_wrapper(0, K, L, h_out, h_mve, h_q, h_qn, h_res, h_nnz)
             assert torch.equal(h_out, d_out.cpu()) and torch.equal(h_mve, d_mve.cpu())
             assert torch.equal(srv.get_score().reshape(BH, M), d_probs)
+        del lsh, srv                                    # (handles first: they unregister what they registered)
     finally:
         L_.set_option("host_zero_copy", 1)
+        L_.set_option("host_register", 0)
 
 
 @pytest.mark.parametrize("name", ["lsh_small", "gqa_32h"])
