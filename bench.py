@@ -127,6 +127,8 @@ def parse():
                     help="A/B: hyperplanes split over the workgroups of a head's cluster (0 never, 1 always; default: auto)")
     ap.add_argument("--direct-slots", type=int, default=-1, choices=[-1, 0, 1],
                     help="A/B: direct piece slots: 0 never, 1 always (where R > 1); default: auto")
+    ap.add_argument("--kn-payload", type=int, default=-1, choices=[-1, 0, 1],
+                    help="A/B: key norms as a payload of the table entries (default: the library's choice)")
     ap.add_argument("--mfma-hash", action="store_true",
                     help="A/B: query SimHash by the MFMA kernel as its own launch, then the decode kernel")
     ap.add_argument("--two-launch", action="store_true",
@@ -425,6 +427,8 @@ def main():
     cfg = CONFIGS[args.config]
     if args.two_launch:
         L.set_option("decode_two_launch", 1)
+    if args.kn_payload >= 0:
+        L.set_option("decode_kn_payload", args.kn_payload)
     if args.mfma_hash:
         L.set_option("decode_mfma_hash", 1)
     if args.cluster:

@@ -135,6 +135,10 @@ __device__ __forceinline__ AhState ah_state_init(int lane, int lpr) {
 // partial dot products are reduce-scattered over the LPR lanes of a row group for log2(UPS) steps and
 // all-reduced for the rest, so the DUP = LPR/UPS lanes c with equal c / DUP all hold the score of slot
 // r*UPS + c/DUP: the importance transform runs DUP times per token, sums count one lane per token.
+// kn_lds != nullptr (wave-uniform): the key norms of the workgroup's selected tokens sit in LDS as bf16, indexed by
+// token - kn_t0 (lsh_decode_kernel scatters them there from the table entries' payload when a token is hit the second
+// time): a token's norm is then a 2-byte LDS read instead of a random 4-byte HBM access -- one line request in five of
+// the gather, which is bound by the requests a CU can keep in flight (EXPERIMENTS.md R3-10).
 template <int D, int NW, bool DENSE, int SLICE, typename IDS>   // NW: upper bound of the workgroup's waves
 __device__ __forceinline__ void attn_head_fold(
     AhState& st,
@@ -144,7 +148,8 @@ __device__ __forceinline__ void attn_head_fold(
     float qn_h, int nz, int64_t M, int K, int L, int slice0, int slice_stride, IDS&& ids,
     float* __restrict__ score_h,         // [M] transformed logits (nullable)
     unsigned long long* __restrict__ stamp,
-    int j0 = 0) {                        // first entry of the list to fold (a multiple of 32): slices start there
+    int j0 = 0,                          // first entry of the list to fold (a multiple of 32): slices start there
+    const uint16_t* kn_lds = nullptr, int kn_t0 = 0) {
     constexpr int LPR = D / 8;           // lanes per row (16 B each)
     constexpr int RPL = 64 / LPR;        // rows per load instruction
     constexpr int UPS = SLICE / RPL;     // load steps per slice
@@ -193,7 +198,10 @@ __device__ __forceinline__ void attn_head_fold(
         // the key norm FIRST in both forms: the transform needs it right behind the K rows; as the youngest load of a
         // full-size step it held the transform back until every V row was in (cfg 2 on clustered keys: 45.6 -> 43.3 us)
         float kn_my = 1.f;
-        if (!DENSE) kn_my = kn_g[id_my];
+        if (!DENSE) {
+            if (kn_lds != nullptr) kn_my = bf16_bits_to_f32(kn_lds[id_my - kn_t0]);
+            else kn_my = kn_g[id_my];
+        }
         if (SLICE < AH_SLICE) {
 #pragma unroll
             for (int u = 0; u < UPS; ++u)

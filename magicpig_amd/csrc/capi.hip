@@ -29,7 +29,7 @@ hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, co
                              int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
                              float*, float2*, int*, int*, uint16_t*, float*, float2*, const int32_t*, float*, int*,
                              int, int, bool, const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t,
-                             bool, unsigned long long*, unsigned int*, int, int, hipStream_t);
+                             bool, unsigned long long*, unsigned int*, int, int, int, const int*, hipStream_t);
 hipError_t set_stamp_stride(int);
 hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
@@ -39,15 +39,16 @@ hipError_t launch_lsh_subbounds(const int32_t*, int32_t*, int, int, int, int64_t
 hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int, int32_t*, int32_t*, int*,
                             hipStream_t);
 hipError_t launch_lsh_retrieve(const int32_t*, const int32_t*, const int32_t*, int32_t*, int32_t*, int,
-                               int, int, int, int64_t, int, hipStream_t);
+                               int, int, int, int64_t, int, int, hipStream_t);
+hipError_t launch_lsh_attach_norms(int32_t*, const float*, int, int, int64_t, int, int*, hipStream_t);
 hipError_t launch_lsh_hash_retrieve(const int32_t*, const int32_t*, const uint16_t*, const uint16_t*,
                                     const float*, int, int, int, int32_t*, float*, int32_t*, int32_t*,
-                                    int, int, int, int, int64_t, int, hipStream_t);
+                                    int, int, int, int, int64_t, int, int, hipStream_t);
 hipError_t launch_lsh_compact(uint32_t*, const int*, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_hash_only(const uint16_t*, const uint16_t*, const float*, int, int, int, int32_t*, float*, int, int,
                                 hipStream_t);
 hipError_t launch_lsh_mask(const int32_t*, const int32_t*, const int32_t*, int8_t*, int, int, int, int,
-                           int64_t, int, hipStream_t);
+                           int64_t, int, int, hipStream_t);
 int attn_slices_per_head(int64_t M);
 int attn_supported_head_dim(int D);
 hipError_t launch_attn_sparse(int, bool, bool, const uint16_t*, const float*, const void*, const float*,
@@ -94,6 +95,7 @@ struct DebugOptions {
     std::atomic<int> attn_head_kernel{-1};   // -1 = auto, 0 = split-KV kernel, 1 = one workgroup per head
     std::atomic<int> attn_gx{0};             // 0 = auto, else split-KV workgroups per head
     std::atomic<int> attn_dense_grouped{1};  // full_attention: 1 = K/V read once per kv group, 0 = once per query head
+    std::atomic<int> decode_kn_payload{1};   // 1: use the key norms attached to the table entries (where attached), 0: one HBM access per token
     std::atomic<int> host_zero_copy{1};      // MP_MEM_HOST calls: 1 = kernels work on pinned memory in place (the caller's, or the handle's mirror), 0 = staged copies
     std::atomic<int> host_register{0};       // 1 = a large PAGEABLE caller buffer is registered (hipHostRegister) once and used in place
 };
@@ -110,6 +112,7 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "attn_head_kernel")) return &g_opt.attn_head_kernel;
     if (!strcmp(name, "attn_gx")) return &g_opt.attn_gx;
     if (!strcmp(name, "attn_dense_grouped")) return &g_opt.attn_dense_grouped;
+    if (!strcmp(name, "decode_kn_payload")) return &g_opt.decode_kn_payload;
     if (!strcmp(name, "host_zero_copy")) return &g_opt.host_zero_copy;
     if (!strcmp(name, "host_register")) return &g_opt.host_register;
     return nullptr;
@@ -261,6 +264,10 @@ struct mp_lsh {
     bool allocated = false;
     int K = 0, L = 0, NB = 0, layers = 0, H = 0, Hkv = 0, B = 0, G = 0;
     int64_t M = 0;
+    int idbits = 0;                // 17 where max_length <= 2^17: the bits above carry a token's key norm once attached
+    std::vector<std::vector<uint64_t>> att_ver;   // [layers][B]: version of the store's norms the rows of (layer, request) carry (0: none)
+    const void* att_to = nullptr;  // the attention store they were taken from
+    int* pay_bad = nullptr;        // [layers][B][Hkv] device flags: a norm of the KV group could not be packed (decode reads them)
     int R = 1;                     // token ranges per table row = workgroups per head of the decode kernel
     int range_len = 0;             // tokens per range (multiple of 32)
     std::vector<int32_t*> bounds;  // per layer [B*Hkv][L][NB][R+1]
@@ -290,6 +297,7 @@ struct mp_attn {
     int64_t M = 0;
     std::vector<uint16_t*> kv;     // per layer [B*Hkv][M][2][D]
     std::vector<float*> kn;        // per layer [B*Hkv][M]
+    std::vector<std::vector<uint64_t>> kn_ver;   // [layers][B]: bumped whenever a fill rewrites the slot's norms
     float* score = nullptr;        // [BH][M] logits -> probabilities on demand
     float* part_o = nullptr;       // [max_slices][D]
     float2* part_ml = nullptr;     // [max_slices]
@@ -443,10 +451,10 @@ static void lsh_free(mp_lsh_t* h) {
     h->bounds.clear();
     h->table.clear();
     h->slots.clear();
-    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->xw, h->xseq};
+    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->xw, h->xseq, h->pay_bad};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->last_query = nullptr; h->err = nullptr; h->codes = nullptr; h->results = nullptr;
-    h->nnz = nullptr; h->qnorm = nullptr; h->xw = nullptr; h->xseq = nullptr;
+    h->nnz = nullptr; h->qnorm = nullptr; h->xw = nullptr; h->xseq = nullptr; h->pay_bad = nullptr;
     h->small.release();
     h->big.release();
     h->hostmap.release();
@@ -482,6 +490,9 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
     h->H = num_attention_heads; h->Hkv = num_key_value_heads; h->B = batch_size;
     h->G = h->H / h->Hkv; h->M = max_length;
     const size_t groups = (size_t)h->B * h->Hkv, BH = (size_t)h->B * h->H;
+    h->idbits = h->M <= (1 << 17) ? 17 : 0;
+    h->att_ver.assign((size_t)num_layers, std::vector<uint64_t>((size_t)batch_size, 0));
+    h->att_to = nullptr;
     h->R = decode_cluster_size((int)BH, h->M);
     h->range_len = lsh_range_len(h->M, h->R);
     // direct piece slots (lsh.hip: lsh_slots_kernel): one 128-byte record per (table, bucket, token range)
@@ -523,6 +534,7 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
         // words start at sequence 0, launches at 1: nothing stale can pass for a word of the first launch
         if (rc == MP_OK && hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->xseq), 1, BH) != hipSuccess) rc = MP_ERR_HIP;
     }
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->pay_bad, (size_t)num_layers * batch_size * num_key_value_heads * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->last_query, BH * L * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->err, 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->codes, BH * L * 4);
@@ -590,6 +602,7 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
     if (rc) return rc;
     int32_t* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB * (h->R + 1);
     int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
+    h->att_ver[layer_id][request_id] = 0;                // the rows are rewritten with plain ids
     MP_HIP_CHECK(launch_lsh_fill((const int16_t*)c, (const int32_t*)i, rows, n, h->NB, h->M, h->R, b, t,
                                  h->err, st));
     bool unsorted = false;
@@ -630,6 +643,7 @@ int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes
     if (rc) return rc;
     int32_t* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB * (h->R + 1);
     int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
+    h->att_ver[layer_id][request_id] = 0;                // the rows are rewritten with plain ids
     MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, h->R, b, t, h->err, st));
     MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, st));
     if (!h->slots.empty())
@@ -651,7 +665,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
         h->lastq = query;
         h->last_layer = layer_id;
         MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], query, results,
-                                         nnz, BH, h->G, h->L, h->NB, h->M, h->R, st));
+                                         nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits, st));
         return MP_OK;
     }
     // host callers (models/attnserver.py:299 passes CPU tensors).  Zero copy: the kernel reads the codes from the handle's
@@ -679,7 +693,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
             MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id],
                                              reinterpret_cast<const int32_t*>(hd + o_codes),
                                              reinterpret_cast<int32_t*>(res_dev), reinterpret_cast<int32_t*>(hd), BH,
-                                             h->G, h->L, h->NB, h->M, h->R, st));
+                                             h->G, h->L, h->NB, h->M, h->R, h->idbits, st));
             MP_HIP_CHECK(hipStreamSynchronize(st));
             memcpy(nnz, hp, (size_t)BH * 4);
             if (mirror) {                         // only the first nnz[h] entries of a row mean anything
@@ -699,7 +713,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     h->lastq = h->last_query;
     h->last_layer = layer_id;
     MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], h->last_query,
-                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, st));
+                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits, st));
     int32_t* d_offs = reinterpret_cast<int32_t*>(h->small.dp) + BH;           // dp: [nnz BH | offs BH + 1]
     MP_HIP_CHECK(launch_ragged_offsets(h->nnz, BH, h->M, d_offs, st));
     MP_HIP_CHECK(hipMemcpyAsync(h->small.dp, h->nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));
@@ -734,7 +748,32 @@ int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream) {
         if (!h->slots.empty())
             MP_HIP_CHECK(hipMemsetAsync(h->slots[i], 0, groups * h->L * h->NB * (size_t)h->R * 128, st));
     }
+    for (auto& v : h->att_ver) std::fill(v.begin(), v.end(), 0);
     h->last_layer = -1;
+    return MP_OK;
+}
+
+// Key norms as a payload of the table entries (lsh.hip: lsh_attach_norms_kernel): done by the decode entry itself, the
+// first time a layer is decoded after its tables or its store's norms changed (never under stream capture).  No
+// synchronisation: a norm that cannot ride along (not a non-negative bf16 number) sets the slot's device flag, which the
+// decode kernel reads -- the workgroups of that request then read the norms per token as before.
+static int lsh_attach_norms(mp_lsh_t* h, int layer_id, int request_id, const float* kn, hipStream_t st) {
+    const int rows = h->Hkv * h->L;
+    int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
+    int* flag = h->pay_bad + ((size_t)layer_id * h->B + request_id) * h->Hkv;
+    MP_HIP_CHECK(hipMemsetAsync(flag, 0, (size_t)h->Hkv * 4, st));
+    MP_HIP_CHECK(launch_lsh_attach_norms(t, kn, h->Hkv, h->L, h->M, h->idbits, flag, st));
+    if (!h->slots.empty()) {                            // the direct slots copy table words: rebuild them
+        int32_t* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB * (h->R + 1);
+        MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * 32, rows,
+                                      h->NB, h->R, h->M, st));
+    }
+    return MP_OK;
+}
+
+int mp_lsh_get_id_bits(mp_lsh_t* h, int* id_bits) {
+    MP_REQUIRE(h && h->allocated && id_bits, MP_ERR_STATE, "mp_lsh_get_id_bits: not allocated / null argument");
+    *id_bits = h->idbits;
     return MP_OK;
 }
 
@@ -757,7 +796,7 @@ int mp_lsh_get_mask(mp_lsh_t* h, int8_t* mask, int mem, mp_stream_t stream) {
         d = tmp.as<int8_t>();
     }
     MP_HIP_CHECK(launch_lsh_mask(h->bounds[h->last_layer], h->table[h->last_layer], h->lastq,
-                                 d, BH, h->G, h->L, h->NB, h->M, h->R, st));
+                                 d, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits, st));
     if (mem == MP_MEM_HOST) {
         MP_HIP_CHECK(hipStreamSynchronize(st));
         MP_HIP_CHECK(hipMemcpy(mask, d, bytes, hipMemcpyDeviceToHost));
@@ -829,6 +868,7 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
     h->device = current_device();
     h->layers = num_layers; h->H = num_attention_heads; h->Hkv = num_key_value_heads;
     h->D = head_dim; h->B = batch_size; h->G = h->H / h->Hkv; h->M = max_length;
+    h->kn_ver.assign((size_t)num_layers, std::vector<uint64_t>((size_t)batch_size, 1));
     const size_t groups = (size_t)h->B * h->Hkv, BH = (size_t)h->B * h->H;
     int rc = MP_OK;
     for (int i = 0; i < num_layers && rc == MP_OK; ++i) {
@@ -880,6 +920,7 @@ int mp_attn_fill(mp_attn_t* h, int layer_id, int request_id, const uint16_t* k, 
     MP_REQUIRE(n >= 0 && n <= h->M, MP_ERR_INVALID, "mp_attn_fill: sequence longer than max_length");
     MP_REQUIRE(k && v && kn, MP_ERR_INVALID, "mp_attn_fill: null argument");
     if (n == 0) return MP_OK;
+    ++h->kn_ver[layer_id][request_id];
     hipStream_t st = (hipStream_t)stream;
     DevBuf dk, dv, dn;
     const void *kd, *vd, *nd;
@@ -917,6 +958,7 @@ int mp_attn_fill_offload(mp_attn_t* h, mp_simhash_t* s, int layer_id, int reques
                    "mp_attn_fill_offload: hasher disagrees on head_dim / device");
     }
     hipStream_t st = (hipStream_t)stream;
+    ++h->kn_ver[layer_id][request_id];
     int nblk = (int)((n + 63) / 64);
     if (nblk > FILL_BLOCKS) nblk = FILL_BLOCKS;
     uint16_t* kv = h->kv[layer_id] + (size_t)request_id * h->Hkv * h->M * 2 * h->D;
@@ -1150,6 +1192,7 @@ int mp_attn_clear(mp_attn_t* h, mp_stream_t stream) {
         MP_HIP_CHECK(hipMemsetAsync(h->kn[i], 0, groups * (size_t)h->M * 4, st));
     }
     MP_HIP_CHECK(hipMemsetAsync(h->score, 0, BH * (size_t)h->M * 4, st));
+    for (auto& v : h->kn_ver) for (auto& x : v) ++x;
     h->score_state = 0;
     return MP_OK;
 }
@@ -1262,6 +1305,29 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         if (mfma_hash)
             MP_HIP_CHECK(launch_simhash_query(q, s->Wt, s->wnorm, BH, s->D, s->K, s->L, lsh->codes, lsh->qnorm,
                                               nullptr, st));
+        // Key norms as a payload of the table entries (max_length <= 2^17; A/B: decode_kn_payload = 0): the first decode
+        // of a layer after its tables or its store's norms changed packs them (two kernels per request, once; never
+        // under stream capture -- a step captured before any eager one simply reads the norms per token).
+        bool kn_payload = lsh->idbits != 0 && g_opt.decode_kn_payload.load() != 0;
+        if (kn_payload) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+            for (int b = 0; b < lsh->B && kn_payload; ++b) {
+                if (lsh->att_to == attn && lsh->att_ver[layer_id][b] == attn->kn_ver[layer_id][b]) continue;
+                if (capturing) {
+                    kn_payload = false;
+                } else {
+                    int rc = lsh_attach_norms(lsh, layer_id, b, attn->kn[layer_id] + (size_t)b * attn->Hkv * attn->M, st);
+                    if (rc) return rc;
+                    lsh->att_ver[layer_id][b] = attn->kn_ver[layer_id][b];
+                }
+            }
+            if (kn_payload && lsh->att_to != attn) {          // another store: every slot of every layer is stale
+                for (auto& v : lsh->att_ver) std::fill(v.begin(), v.end(), 0);
+                for (int b = 0; b < lsh->B; ++b) lsh->att_ver[layer_id][b] = attn->kn_ver[layer_id][b];
+                lsh->att_to = attn;
+            }
+        }
         MP_HIP_CHECK(launch_lsh_decode(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk, s->wnorm, s->D,
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
@@ -1269,7 +1335,8 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
                                        lsh->slots.empty() ? nullptr : lsh->slots[layer_id], attn->score, attn->err, attn_slices_per_head(attn->M), lsh->R,
                                        attn->xcd_rr && g_opt.decode_agent_scope.load() == 0,
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
-                                       lsh->L, lsh->NB, lsh->M, mfma_hash, lsh->xw, lsh->xseq, lsh->xwords, xmode, st));
+                                       lsh->L, lsh->NB, lsh->M, mfma_hash, lsh->xw, lsh->xseq, lsh->xwords, xmode, lsh->idbits,
+                                       kn_payload ? lsh->pay_bad + (size_t)layer_id * lsh->B * lsh->Hkv : nullptr, st));
         attn->lastz = lsh->nnz;
         attn->score_state = 1;
         attn->seg_cnt = lsh->R > 1 ? attn->part_cnt : nullptr;
@@ -1279,7 +1346,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         MP_HIP_CHECK(launch_lsh_hash_retrieve(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk,
                                               s->wnorm, s->D, s->K, s->KLpad, lsh->codes, lsh->qnorm,
                                               lsh->results, lsh->nnz, BH, lsh->G, lsh->L, lsh->NB, lsh->M,
-                                              lsh->R, st));
+                                              lsh->R, lsh->idbits, st));
         int rc = attn_run(attn, layer_id, false, s->K, s->L, output, max_value_expsum, q, MP_DTYPE_BF16,
                           lsh->qnorm, lsh->results, lsh->nnz, st);
         if (rc) return rc;

@@ -209,6 +209,40 @@ __global__ __launch_bounds__(256) void lsh_slots_kernel(const int32_t* __restric
     }
 }
 
+// ---------------------------------------------------------------- key norms as a payload of the table entries
+// table word = token id | (bits 14..0 of the token's bf16 key norm << idbits) (idbits = 17, where max_length <= 2^17).
+// The decode kernel's gather then finds a selected token's norm in LDS (scattered there when the token was hit the
+// second time) instead of spending one random HBM access per token on it.
+// one request's rows [Hkv * L][M]; kn [Hkv][M] (the request's slice of the attention store's norms); bad[kv head] is set
+// when a norm the tables reference is not a non-negative bf16 number (the decode kernel then ignores the payload)
+__global__ void lsh_attach_norms_kernel(int32_t* __restrict__ table, const float* __restrict__ kn, int L, int64_t M,
+                                        int idbits, int* __restrict__ bad) {
+    const int64_t row = blockIdx.y;
+    const float* knr = kn + (row / L) * M;
+    int32_t* t = table + row * M;
+    const uint32_t mask = (1u << idbits) - 1u;
+    bool b = false;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < M; p += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t w = t[p];
+        if (w == -1) continue;                                 // not an entry
+        const uint32_t id = (uint32_t)w & mask;
+        uint32_t u = id < (uint64_t)M ? __float_as_uint(knr[id]) : 0u;
+        if ((u & 0x8000ffffu) != 0u || (u & 0x7f800000u) == 0x7f800000u) {   // not bf16, negative, inf / nan
+            b = true;
+            u = 0u;
+        }
+        t[p] = (int32_t)(id | ((u >> 16) << idbits));
+    }
+    if (b) atomicOr(bad + row / L, 1);
+}
+hipError_t launch_lsh_attach_norms(int32_t* table, const float* kn, int Hkv, int L, int64_t M, int idbits, int* bad,
+                                   hipStream_t st) {
+    int gx = (int)((M + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(lsh_attach_norms_kernel, dim3(gx, Hkv * L), dim3(256), 0, st, table, kn, L, M, idbits, bad);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- device-side table build
 // (replacement of the half-written LSH::fastfill, lsh.cc:93-142, and of the torch.sort +
 // LSH::fill of models/attnserver.py:186-193): stable counting sort of one (kv head, table) row
@@ -475,6 +509,8 @@ struct AttnArgs {
     unsigned long long* xw;  // split hash: [BH][xwords] (launch sequence << 32 | 32 sign bits) exchanged by a cluster
     unsigned int* xseq;      // split hash: [BH] sequence number of the current launch (the merger advances it)
     int xwords, xmode;       // words per head; xmode 2 = nobody publishes (test: every member takes the fallback)
+    const int* pay_bad;      // [B*Hkv] or nullptr: the table entries of this layer carry their tokens' key norms,
+                             // unless the flag of the head's KV group says one of them could not be packed
     // optional static window (models/attnserver.py:281-308): exact attention over the first win_len[h]
     // rows of a second KV store joins the same softmax, which IS flashinfer.merge_state of the two parts
     const uint16_t* win_kv;  // [B*Hkv][win_M][2][D] or nullptr
@@ -492,7 +528,7 @@ template <int HASH, int CH, int AD, bool WIN>    // CH = min(16, D / 8): plane c
 __device__ __forceinline__ void lsh_head_body(
     const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
-    int G, int L, int NB, int64_t M, int R, int range_len, int words, int Lpad, const HashArgs& ha,
+    int G, int L, int NB, int64_t M, int R, int range_len, int words, int Lpad, int idbits, const HashArgs& ha,
     const AttnArgs& aa, unsigned long long* __restrict__ stamp) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_u32[];
     uint32_t* bmA = s_u32;
@@ -513,6 +549,13 @@ __device__ __forceinline__ void lsh_head_body(
     float* s_merge = reinterpret_cast<float*>(s_ids + (AD > 0 ? aa.cap : 0));
     int* s_tk = reinterpret_cast<int*>(s_merge + attn_head_lds_floats(RT_WAVES, AD > 0 ? AD : 2));
     uint32_t* s_qraw = reinterpret_cast<uint32_t*>(s_tk + 4);   // AD: the raw query row (bf16 pairs), 16-byte aligned
+    uint16_t* s_kn = reinterpret_cast<uint16_t*>(s_qraw + 64);  // AD, table entries with a key-norm payload: bf16 [range_len]
+    // Table entries may carry their token's key norm in the bits above `idbits` (lsh_attach_norms_kernel; max_length <=
+    // 2^17: a 17-bit id + the 15 bits of a non-negative bf16).  The id is always masked; with `pay` the decode scatters
+    // the norm of a token into LDS when it is hit the second time -- the gather then reads it from there instead of
+    // spending one HBM line request in five on a 4-byte value (EXPERIMENTS.md R3-10).
+    const uint32_t idmask = idbits ? ((1u << idbits) - 1u) : 0xffffffffu;
+    bool pay = false;                                           // uniform
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // decode: the grid is R x BHp blocks, BHp = B*H rounded up to a multiple of 8 when R > 1, so that the members of
@@ -525,6 +568,7 @@ __device__ __forceinline__ void lsh_head_body(
     const int clog = (AD > 0) ? aa.cluster_log2 : 0;
     const bool lead = rank == 0;                              // the member that writes codes / ||q||
     const int64_t g = h / G;
+    if (AD > 0 && idbits != 0 && aa.pay_bad != nullptr) pay = aa.pay_bad[g] == 0;
     const int RS = R + 1;
     const int32_t* bnd = bounds + g * L * NB * RS;
     const int32_t* tab = table + g * L * M;
@@ -734,11 +778,14 @@ __device__ __forceinline__ void lsh_head_body(
     MP_STAMP(stamp, 27);
     const uint32_t T0 = (uint32_t)t0;                                   // M <= 2^22 (mp_lsh_alloc)
     auto apply = [&](int32_t t) {
-        const uint32_t u = (uint32_t)t - T0;                            // token index inside the range
-        if (u < tlen) {                                                 // one unsigned compare: t0 <= t < t0 + tlen
+        const uint32_t u = ((uint32_t)t & idmask) - T0;                 // token index inside the range
+        if (t != -1 && u < tlen) {                                      // (-1: a lane without an id) t0 <= id < t0 + tlen
             const uint32_t bit = 1u << (u & 31);
             const uint32_t old = atomicOr(&bmA[u >> 5], bit);           // first hit: 0 -> 1
-            if (old & bit) atomicOr(&bmB[u >> 5], bit);                 // any later hit: -> 2
+            if (old & bit) {
+                atomicOr(&bmB[u >> 5], bit);                            // any later hit: -> 2
+                if (pay) s_kn[u] = (uint16_t)((uint32_t)t >> idbits);   // (every hit of a token carries the same norm)
+            }
         }
     };
     auto code_of = [&](int l) {   // HASH 1: bit i of code l <- plane l*K + i
@@ -1062,15 +1109,16 @@ __device__ __forceinline__ void lsh_head_body(
     constexpr int SHORT = (ADD == 128) ? 16 : AH_SLICE;
     const bool short_list = SHORT < AH_SLICE && total <= SHORT * RT_WAVES && !spill;
     AhState st = ah_state_init(lane, ADD / 8);
+    const uint16_t* kn_lds = pay ? s_kn : nullptr;
     if (short_list)
         attn_head_fold<ADD, RT_WAVES, false, SHORT>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1, ids_lds,
-                                                    score_h, stamp);
+                                                    score_h, stamp, 0, kn_lds, (int)T0);
     else if (!spill)
         attn_head_fold<ADD, RT_WAVES, false, AH_SLICE>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
-                                                       ids_lds, score_h, stamp);
+                                                       ids_lds, score_h, stamp, 0, kn_lds, (int)T0);
     else
         attn_head_fold<ADD, RT_WAVES, false, AH_SLICE>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
-                                                       ids_hbm, score_h, stamp);
+                                                       ids_hbm, score_h, stamp, 0, kn_lds, (int)T0);
     if (WIN && wlen > 0) {                  // the static window: dense slices rank, rank + R, ... (k runs from
                                             // `wave` again, so the waves that got no sparse slice are served first)
         auto none = [](int) { return u32x4{0u, 0u, 0u, 0u}; };
@@ -1240,10 +1288,10 @@ template <int HASH, int CH>
 __global__ __launch_bounds__(RT_THREADS, 4) void lsh_retrieve_kernel(
     const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
-    int G, int L, int NB, int64_t M, int R, int words, int Lpad, HashArgs ha,
+    int G, int L, int NB, int64_t M, int R, int words, int Lpad, int idbits, HashArgs ha,
     unsigned long long* __restrict__ stamp) {
     const AttnArgs aa = {};
-    lsh_head_body<HASH, CH, 0, false>(bounds, table, query, results, nnz, G, L, NB, M, R, 0, words, Lpad, ha, aa, stamp);
+    lsh_head_body<HASH, CH, 0, false>(bounds, table, query, results, nnz, G, L, NB, M, R, 0, words, Lpad, idbits, ha, aa, stamp);
 }
 
 // the whole sparse layer of models/attnserver.py:264-300: hash -> retrieve -> attention
@@ -1251,10 +1299,10 @@ template <int CH, int AD, bool WIN, int HASH = 1>
 __global__ __launch_bounds__(RT_THREADS, 4) void lsh_decode_kernel(
     const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     int32_t* __restrict__ results, int32_t* __restrict__ nnz,
-    int G, int L, int NB, int64_t M, int R, int range_len, int words, int Lpad, HashArgs ha, AttnArgs aa,
+    int G, int L, int NB, int64_t M, int R, int range_len, int words, int Lpad, int idbits, HashArgs ha, AttnArgs aa,
     unsigned long long* __restrict__ stamp) {
     lsh_head_body<HASH, CH, AD, WIN>(bounds, table, nullptr, results, nnz, G, L, NB, M, R, range_len, words, Lpad,
-                                     ha, aa, stamp);
+                                     idbits, ha, aa, stamp);
 }
 
 // The decode kernel leaves member r's selected ids / logits at column r * range_len of the head's row; this
@@ -1287,7 +1335,8 @@ __global__ __launch_bounds__(1024) void lsh_compact_segments_kernel(uint32_t* __
 // one workgroup per head: each workgroup zeroes its row, then walks the probed buckets table by table.
 __global__ __launch_bounds__(256) void lsh_mask_kernel(
     const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
-    const int32_t* __restrict__ query, int8_t* __restrict__ mask, int G, int L, int NB, int64_t M, int R) {
+    const int32_t* __restrict__ query, int8_t* __restrict__ mask, int G, int L, int NB, int64_t M, int R,
+    uint32_t idmask) {
     const int64_t h = blockIdx.x;
     const int64_t g = h / G;
     const int RS = R + 1;
@@ -1303,8 +1352,8 @@ __global__ __launch_bounds__(256) void lsh_mask_kernel(
         const int bx = rec[0], by = rec[R];
         const int32_t* src = table + (g * L + l) * M;
         for (int j = bx + threadIdx.x; j < by; j += blockDim.x) {
-            const int32_t t = src[j];
-            if (t >= 0 && t < M && row[t] < 2) row[t] = row[t] + 1;
+            const int64_t t = (int64_t)((uint32_t)src[j] & idmask);
+            if (t < M && row[t] < 2) row[t] = row[t] + 1;
         }
         __syncthreads();
     }
@@ -1515,14 +1564,14 @@ static hipError_t retrieve_attr_once() {
 
 hipError_t launch_lsh_retrieve(const int32_t* bounds, const int32_t* table, const int32_t* query,
                                int32_t* results, int32_t* nnz, int BH, int G, int L, int NB,
-                               int64_t M, int R, hipStream_t st) {
+                               int64_t M, int R, int idbits, hipStream_t st) {
     const int words = (int)((M + 31) / 32);
     const int Lpad = (L + 63) & ~63;
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
     HashArgs ha = {};
     hipLaunchKernelGGL((lsh_retrieve_kernel<0, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
-                       st, bounds, table, query, results, nnz, G, L, NB, M, R, words, Lpad, ha, g_stamp);
+                       st, bounds, table, query, results, nnz, G, L, NB, M, R, words, Lpad, idbits, ha, g_stamp);
     return hipGetLastError();
 }
 
@@ -1531,7 +1580,7 @@ hipError_t launch_lsh_retrieve(const int32_t* bounds, const int32_t* table, cons
 hipError_t launch_lsh_hash_retrieve(const int32_t* bounds, const int32_t* table, const uint16_t* q,
                                     const uint16_t* Wk, const float* wnorm, int D, int K, int KLpad,
                                     int32_t* codes_out, float* qnorm_out, int32_t* results,
-                                    int32_t* nnz, int BH, int G, int L, int NB, int64_t M, int R,
+                                    int32_t* nnz, int BH, int G, int L, int NB, int64_t M, int R, int idbits,
                                     hipStream_t st) {
     const int words = (int)((M + 31) / 32);
     const int Lpad = (L + 63) & ~63;
@@ -1541,11 +1590,11 @@ hipError_t launch_lsh_hash_retrieve(const int32_t* bounds, const int32_t* table,
     if (D >= 128)
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, R, words,
-                           Lpad, ha, g_stamp);
+                           Lpad, idbits, ha, g_stamp);
     else
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 8>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, R, words,
-                           Lpad, ha, g_stamp);
+                           Lpad, idbits, ha, g_stamp);
     return hipGetLastError();
 }
 
@@ -1560,11 +1609,11 @@ hipError_t launch_lsh_hash_only(const uint16_t* q, const uint16_t* Wk, const flo
     if (D >= 128)
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 16>), dim3(rows), dim3(RT_THREADS), lds, st, (const int32_t*)nullptr,
                            (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 1, L,
-                           1 << K, (int64_t)0, 1, 0, Lpad, ha, g_stamp);
+                           1 << K, (int64_t)0, 1, 0, Lpad, 0, ha, g_stamp);
     else
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 8>), dim3(rows), dim3(RT_THREADS), lds, st, (const int32_t*)nullptr,
                            (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 1, L,
-                           1 << K, (int64_t)0, 1, 0, Lpad, ha, g_stamp);
+                           1 << K, (int64_t)0, 1, 0, Lpad, 0, ha, g_stamp);
     return hipGetLastError();
 }
 
@@ -1582,7 +1631,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                              float* score, int* err, int maxs, int R, bool same_xcd, const uint16_t* win_kv,
                              const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
                              bool codes_given, unsigned long long* xw, unsigned int* xseq, int xwords, int xmode,
-                             hipStream_t st) {
+                             int idbits, const int* pay_bad, hipStream_t st) {
     const int range_len = lsh_range_len(M, R);
     const int words = range_len / 32;
     const int Lpad = (L + 63) & ~63;
@@ -1599,27 +1648,33 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     const bool split_hash = xmode != 0 && sx && xw != nullptr && xseq != nullptr && !codes_given &&
                             ((K * L + 63) / 64) <= (RT_WAVES << clog) && 2 * ((K * L + 63) / 64) <= xwords;
     AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, slots, score, err, BH, BHp, maxs,
-                   DECODE_ID_CAP, clog, sx ? 1 : 0, split_hash ? xw : nullptr, split_hash ? xseq : nullptr, xwords, xmode, win_kv, win_len, win_M};
+                   DECODE_ID_CAP, clog, sx ? 1 : 0, split_hash ? xw : nullptr, split_hash ? xseq : nullptr, xwords, xmode, nullptr,
+                   win_kv, win_len, win_M};
     const dim3 grid((unsigned)BHp << clog);
-    const size_t lds = decode_lds_bytes(range_len, L, D);
+    size_t lds = decode_lds_bytes(range_len, L, D);
+    // key norms from the table entries' payload: 2 bytes of LDS per token of a member's range, where they fit
+    if (pay_bad != nullptr && idbits != 0 && lds + (size_t)range_len * 2 + 16 <= RT_LDS_DYN_MAX) {
+        aa.pay_bad = pay_bad;
+        lds += (size_t)range_len * 2 + 16;
+    }
     if (codes_given) {   // A/B: the codes and ||q|| come from simhash_query_kernel (plain decode only)
         if (win_kv != nullptr) return hipErrorInvalidValue;
         if (D == 128)
             hipLaunchKernelGGL((lsh_decode_kernel<16, 128, false, 2>), grid, dim3(RT_THREADS), lds, st, bounds, table,
-                               results, nnz, G, L, NB, M, R, range_len, words, Lpad, ha, aa, g_stamp);
+                               results, nnz, G, L, NB, M, R, range_len, words, Lpad, idbits, ha, aa, g_stamp);
         else
             hipLaunchKernelGGL((lsh_decode_kernel<8, 64, false, 2>), grid, dim3(RT_THREADS), lds, st, bounds, table,
-                               results, nnz, G, L, NB, M, R, range_len, words, Lpad, ha, aa, g_stamp);
+                               results, nnz, G, L, NB, M, R, range_len, words, Lpad, idbits, ha, aa, g_stamp);
         return hipGetLastError();
     }
 #define MP_DECODE_CASE(DD, CHH, WW)                                                                            \
     if (D == DD && (win_kv != nullptr) == WW) {                                                                \
         if (split_hash)                                                                                        \
             hipLaunchKernelGGL((lsh_decode_kernel<CHH, DD, WW, 3>), grid, dim3(RT_THREADS), lds, st, bounds,   \
-                               table, results, nnz, G, L, NB, M, R, range_len, words, Lpad, ha, aa, g_stamp);  \
+                               table, results, nnz, G, L, NB, M, R, range_len, words, Lpad, idbits, ha, aa, g_stamp);  \
         else                                                                                                   \
             hipLaunchKernelGGL((lsh_decode_kernel<CHH, DD, WW>), grid, dim3(RT_THREADS), lds, st, bounds,      \
-                               table, results, nnz, G, L, NB, M, R, range_len, words, Lpad, ha, aa, g_stamp);  \
+                               table, results, nnz, G, L, NB, M, R, range_len, words, Lpad, idbits, ha, aa, g_stamp);  \
         return hipGetLastError();                                                                              \
     }
     MP_DECODE_CASE(128, 16, false)
@@ -1638,9 +1693,9 @@ hipError_t launch_lsh_compact(uint32_t* rows, const int* part_cnt, int BH, int R
 }
 
 hipError_t launch_lsh_mask(const int32_t* bounds, const int32_t* table, const int32_t* query,
-                           int8_t* mask, int BH, int G, int L, int NB, int64_t M, int R, hipStream_t st) {
+                           int8_t* mask, int BH, int G, int L, int NB, int64_t M, int R, int idbits, hipStream_t st) {
     hipLaunchKernelGGL(lsh_mask_kernel, dim3(BH), dim3(256), 0, st, bounds, table, query, mask, G,
-                       L, NB, M, R);
+                       L, NB, M, R, idbits ? ((1u << idbits) - 1u) : 0xffffffffu);
     return hipGetLastError();
 }
 

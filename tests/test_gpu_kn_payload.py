@@ -1,0 +1,162 @@
+"""Key norms as a payload of the table entries (include/magicpig_hip.h: mp_lsh_get_id_bits; lsh.hip:
+lsh_attach_norms_kernel).  The one-launch decode entries pack the bf16 norms the attention store holds into the
+bits above the 17-bit token ids the first time a layer is decoded, and read them from LDS afterwards.  Nothing
+observable may change: ids, counts and outputs are those of the per-token norm reads, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16_t(bits, device="cpu"):
+    return synth.to_torch_bf16(np.ascontiguousarray(bits)).to(device)
+
+
+@pytest.fixture(scope="module")
+def mp():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import magicpig_amd
+    return magicpig_amd
+
+
+@pytest.fixture(autouse=True)
+def _default_option():
+    yield
+    if torch.cuda.is_available():
+        import magicpig_amd._lib as L
+        L.set_option("decode_kn_payload", 1)
+
+
+def _server(mp, B, H, Hkv, n, M, D, K, L, seed, data="randn"):
+    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L, data=data)
+    server = mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, num_sink_tokens=0, num_local_tokens=0,
+                                    max_length=M, dense_layers=(), hash_func=bf16_t(W, "cuda"))
+    for b in range(B):
+        server.hash_code_buffer = server.hasher.keys(bf16_t(keys[b], "cuda"))
+        server.build_table(0, b, n)
+        server.attn_server.fill(0, b, bf16_t(keys[b], "cuda"), bf16_t(vals[b], "cuda"), torch.from_numpy(kns[b]).cuda())
+    return server, (keys, kns, vals, W, qb)
+
+
+def _packed(server, rows=slice(None), n=None):
+    """True when some word of the rows [groups][L][:n] carries a payload above the 17-bit id."""
+    raw = server.lsh_retriever.get_tables(0, raw=True)[1][rows, :, :n]
+    return bool((((raw >> 17) & 0x7fff) != 0).any())
+
+
+def _decode(server, q):
+    out, lse = server.decode(q, 0)
+    torch.cuda.synchronize()
+    return out.clone(), lse.clone(), server.nnz.clone()
+
+
+@pytest.mark.parametrize("B,H,Hkv,data", [(1, 32, 8, "randn"), (2, 8, 2, "clustered"), (3, 6, 3, "skewed")])
+def test_payload_changes_nothing_observable(mp, B, H, Hkv, data):
+    import magicpig_amd._lib as L
+    n, M, D, K, Lt = 6000, 6144, 128, 8, 75
+    server, (keys, kns, vals, W, qb) = _server(mp, B, H, Hkv, n, M, D, K, Lt, 99, data)
+    lsh = server.lsh_retriever
+    assert lsh.id_bits() == 17
+    _, plain = lsh.get_tables(0, raw=True)
+    plain = plain.clone()
+    assert not _packed(server, n=n)                            # plain ids until the first decode
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    qs = [torch.randn((B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16) for _ in range(4)]
+    L.set_option("decode_kn_payload", 0)
+    want = [_decode(server, q) for q in qs]
+    assert torch.equal(lsh.get_tables(0, raw=True)[1], plain)   # option off: nothing was packed
+    L.set_option("decode_kn_payload", 1)
+    got = [_decode(server, q) for q in qs]
+    for (o0, l0, z0), (o1, l1, z1) in zip(want, got):
+        assert torch.equal(z0, z1) and torch.equal(o0, o1) and torch.equal(l0, l1)
+    # the words now carry the norms: id | bf16 bits of the store's norm << 17
+    _, raw = lsh.get_tables(0, raw=True)
+    _, ids = lsh.get_tables(0)
+    assert torch.equal(ids[:, :, :n], plain[:, :, :n])
+    kn = server.attn_server.get_key_norm(0).reshape(B * Hkv, M)
+    norm_bits = (kn.view(torch.int32) >> 16)                                   # [groups, M]
+    expect = torch.gather(norm_bits[:, None, :].expand(-1, Lt, -1), 2, ids[:, :, :n].long())
+    assert torch.equal((raw[:, :, :n] >> 17) & 0x7fff, expect)
+    # the other consumers of the tables mask the ids: retrieve, get_mask
+    codes, _ = server.hasher.query(qs[0].reshape(B * H, D))
+    res = torch.zeros((B * H, M), dtype=torch.int32, device="cuda")
+    nz = torch.zeros((B * H,), dtype=torch.int32, device="cuda")
+    lsh.batch_retrieve(0, codes, res, nz)
+    assert torch.equal(nz, want[0][2])
+    assert int(res.max()) < n
+    mask = lsh.get_mask()
+    assert torch.equal((mask == 2).sum(-1).reshape(-1).int(), nz.cpu())
+    # a rebuilt table holds plain ids again, and the next decode packs again
+    server.hash_code_buffer = server.hasher.keys(bf16_t(keys[0], "cuda"))
+    server.build_table(0, 0, n)
+    assert not _packed(server, slice(0, Hkv), n)
+    again = _decode(server, qs[1])
+    assert torch.equal(again[0], want[1][0]) and torch.equal(again[2], want[1][2])
+    assert _packed(server, slice(0, Hkv), n)
+
+
+def test_norms_that_cannot_ride_along_and_norms_that_change(mp):
+    """f32 norms with mantissa bits below bf16 (a caller may pass any f32 norms to fill) keep their KV group on the
+    per-token reads -- the result is the one of the option switched off, not the one of truncated norms; a refill with
+    other norms is seen by the next decode."""
+    import magicpig_amd._lib as L
+    B, H, Hkv, n, M, D, K, Lt = 1, 8, 2, 5000, 5120, 128, 8, 60
+    server, (keys, kns, vals, W, qb) = _server(mp, B, H, Hkv, n, M, D, K, Lt, 5)
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    q = torch.randn((B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16)
+    base = _decode(server, q)                                     # packed, bf16 norms
+    odd = torch.from_numpy(kns[0]).cuda() * 1.00390625 + 1e-3     # not bf16 numbers
+    odd[1] = torch.from_numpy(kns[0]).cuda()[1]                   # KV group 1 keeps bf16 norms
+    server.attn_server.fill(0, 0, bf16_t(keys[0], "cuda"), bf16_t(vals[0], "cuda"), odd)
+    got = _decode(server, q)
+    L.set_option("decode_kn_payload", 0)
+    want = _decode(server, q)
+    L.set_option("decode_kn_payload", 1)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+    G = H // Hkv
+    assert not torch.equal(got[0][0, :G], base[0][0, :G])         # group 0: the new norms are in use
+    assert torch.equal(got[0][0, G:], base[0][0, G:])             # group 1: unchanged
+    assert not _packed(server, slice(0, 1), n) and _packed(server, slice(1, 2), n)   # group 0 carries no payload
+    # back to bf16 norms, scaled: picked up by the next decode (the store's version moved)
+    server.attn_server.fill(0, 0, bf16_t(keys[0], "cuda"), bf16_t(vals[0], "cuda"), torch.from_numpy(kns[0]).cuda() * 2)
+    got2 = _decode(server, q)
+    L.set_option("decode_kn_payload", 0)
+    want2 = _decode(server, q)
+    assert torch.equal(got2[0], want2[0]) and torch.equal(got2[1], want2[1])
+    assert not torch.equal(got2[0], base[0])
+
+
+def test_first_decode_under_capture_reads_norms_per_token(mp):
+    """Packing launches kernels that must not be baked into a caller's graph: a decode captured before any eager one
+    leaves the tables alone and gives the same result."""
+    B, H, Hkv, n, M, D, K, Lt = 1, 8, 2, 5000, 5120, 128, 8, 60
+    server, _ = _server(mp, B, H, Hkv, n, M, D, K, Lt, 6)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    q = torch.randn((B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16)
+    server.collect_nnz = False
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        server.decode(q, 0)
+    graph.replay()
+    torch.cuda.synchronize()
+    o_graph = server.output.clone()
+    assert not _packed(server, n=n)
+    server.collect_nnz = True
+    o_eager = _decode(server, q)[0]
+    assert _packed(server, n=n)
+    assert torch.equal(o_graph.view_as(o_eager), o_eager)
+
+
+def test_long_contexts_keep_plain_ids(mp):
+    lsh = mp.LSH()
+    lsh.alloc(8, 4, 1, 2, 1, 1, (1 << 17) + 64)
+    assert lsh.id_bits() == 0
+    lsh2 = mp.LSH()
+    lsh2.alloc(8, 4, 1, 2, 1, 1, 1 << 17)
+    assert lsh2.id_bits() == 17
