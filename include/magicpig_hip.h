@@ -116,15 +116,16 @@ int mp_lsh_get_mask(mp_lsh_t* h, int8_t* mask, int mem, mp_stream_t stream);
  * one query head in mp_decode_sparse_layer, chosen at alloc from B*H and the device's CU count. */
 int mp_lsh_get_tables(mp_lsh_t* h, int layer_id, void** bounds_dev, void** table_dev);
 int mp_lsh_get_ranges(mp_lsh_t* h, int* ranges, int* range_len);
-/* 17 where max_length <= 2^17, else 0.  Where it is 17, a table word is  token id | (payload << 17): the one-launch
- * decode entries let the entries carry their tokens' key norms (bits 14..0 of the bf16 norm the attention store holds:
- * what models/attnserver.py:143 stores) the first time a layer is decoded after its tables or the store's norms
- * changed -- two extra kernels per request, once, never under stream capture -- so that a selected token's norm is
- * found on chip instead of costing one random HBM access (one line request in five of the gather).  A norm that is not
- * a non-negative bf16 number keeps its request on the per-token reads.  Every retrieve masks the ids; results are plain
- * token ids; mp_lsh_get_tables' `table` holds the words as they are (mask with (1 << id_bits) - 1).  mp_lsh_fill /
- * mp_lsh_build write plain ids again. */
-int mp_lsh_get_id_bits(mp_lsh_t* h, int* id_bits);
+/* Width of the id field of the layer's table words: 17 while every token id the layer's tables hold is below 2^17
+ * (any max_length), 0 (plain ids) from the first mp_lsh_fill / mp_lsh_build that brings a wider one until mp_lsh_clear.
+ * Where it is 17, a table word is  token id | (payload << 17): the one-launch decode entries let the entries carry
+ * their tokens' key norms (bits 14..0 of the bf16 norm the attention store holds: what models/attnserver.py:143
+ * stores) the first time a layer is decoded after its tables or the store's norms changed -- two extra kernels per
+ * request, once, never under stream capture -- so that a selected token's norm is found on chip instead of costing one
+ * random HBM access (one line request in five of the gather).  A norm that is not a non-negative bf16 number keeps its
+ * KV group on the per-token reads.  Every retrieve masks the ids; results are plain token ids; mp_lsh_get_tables'
+ * `table` holds the words as they are (mask with (1 << id_bits) - 1).  mp_lsh_fill / mp_lsh_build write plain ids. */
+int mp_lsh_get_id_bits(mp_lsh_t* h, int layer_id, int* id_bits);
 
 /* ---------------------------------------------------------------- sparse attention */
 int mp_attn_create(mp_attn_t** out);                  /* sparse_attention.cc:519-527 */
@@ -211,8 +212,8 @@ int mp_debug_xcd_round_robin(void);
  *                        are split over the workgroups of a head's cluster and the sign bits exchanged through the
  *                        XCD's L2, with a bounded wait and hashing alone as the fallback; 2 = split but nobody
  *                        publishes (test: every workgroup takes the fallback)
- *   "decode_kn_payload"  1 = the decode entries pack the key norms into the table entries and use them (default, where
- *                        max_length <= 2^17), 0 = one HBM access per selected token
+ *   "decode_kn_payload"  1 = the decode entries pack the key norms into the table entries and use them (default, while
+ *                        the layer's ids fit 17 bits), 0 = one HBM access per selected token
  *   "decode_direct"      -1 = auto, 0 = never, 1 = always (where R > 1): keep 128-byte direct slots (length, position + first
  *                        30 ids) for every (table, bucket, token range) piece; read by mp_lsh_alloc
  *   "attn_head_kernel"   -1 = auto, 0 = split-KV kernel with the in-launch ticket merge, 1 = one workgroup per head

@@ -264,7 +264,8 @@ struct mp_lsh {
     bool allocated = false;
     int K = 0, L = 0, NB = 0, layers = 0, H = 0, Hkv = 0, B = 0, G = 0;
     int64_t M = 0;
-    int idbits = 0;                // 17 where max_length <= 2^17: the bits above carry a token's key norm once attached
+    std::vector<int> idbits_of;    // per layer: 17 while every id of the layer's tables is < 2^17 (the bits above carry a
+                                   // token's key norm once packed), 0 once a fill brought a wider id (lsh_widen)
     std::vector<std::vector<uint64_t>> att_ver;   // [layers][B]: version of the store's norms the rows of (layer, request) carry (0: none)
     const void* att_to = nullptr;  // the attention store they were taken from
     int* pay_bad = nullptr;        // [layers][B][Hkv] device flags: a norm of the KV group could not be packed (decode reads them)
@@ -490,7 +491,7 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
     h->H = num_attention_heads; h->Hkv = num_key_value_heads; h->B = batch_size;
     h->G = h->H / h->Hkv; h->M = max_length;
     const size_t groups = (size_t)h->B * h->Hkv, BH = (size_t)h->B * h->H;
-    h->idbits = h->M <= (1 << 17) ? 17 : 0;
+    h->idbits_of.assign((size_t)num_layers, 17);
     h->att_ver.assign((size_t)num_layers, std::vector<uint64_t>((size_t)batch_size, 0));
     h->att_to = nullptr;
     h->R = decode_cluster_size((int)BH, h->M);
@@ -574,15 +575,38 @@ static int lsh_check_slot(mp_lsh_t* h, int layer_id, int request_id, int64_t n, 
 
 // reads and clears the device flag: bit 0 -> MP_ERR_DATA; *unsorted (optional) <- bit 2 (a bucket whose ids
 // do not ascend: not an error, the caller re-sorts)
-static int lsh_read_err(mp_lsh_t* h, hipStream_t st, const char* who, bool* unsorted = nullptr) {
+static int lsh_read_err(mp_lsh_t* h, hipStream_t st, const char* who, bool* unsorted = nullptr, bool* wide = nullptr) {
     int flag = 0;
     MP_HIP_CHECK(hipMemcpyAsync(&flag, h->err, 4, hipMemcpyDeviceToHost, st));
     MP_HIP_CHECK(hipStreamSynchronize(st));
     if (flag) MP_HIP_CHECK(hipMemsetAsync(h->err, 0, 4, st));
     if (unsorted) *unsorted = (flag & 4) != 0;
+    if (wide) *wide = (flag & 32) != 0;
     if (flag & 1)
         return fail(MP_ERR_DATA, std::string(who) + ": device-side validation failed (codes not sorted / "
                                                     "out of [0, 2^K) or token id out of [0, max_length))");
+    return MP_OK;
+}
+
+// A table word is  id | payload << 17  while every id of the LAYER is below 2^17.  The first fill that brings a wider
+// id (a context past 131 072 offloaded tokens) turns the layer's words into plain ids for good (until mp_lsh_clear):
+// the payloads the other requests' rows may carry are stripped, their direct slots rebuilt.
+static int lsh_widen(mp_lsh_t* h, int layer_id, int except_request, hipStream_t st) {
+    if (h->idbits_of[layer_id] == 0) return MP_OK;
+    const int rows = h->Hkv * h->L;
+    for (int r = 0; r < h->B; ++r) {
+        if (r == except_request || h->att_ver[layer_id][r] == 0) continue;
+        int32_t* t = h->table[layer_id] + (size_t)r * rows * h->M;
+        int* flag = h->pay_bad + ((size_t)layer_id * h->B + r) * h->Hkv;
+        MP_HIP_CHECK(launch_lsh_attach_norms(t, nullptr, h->Hkv, h->L, h->M, 17, flag, st));
+        if (!h->slots.empty()) {
+            int32_t* b = h->bounds[layer_id] + (size_t)r * rows * h->NB * (h->R + 1);
+            MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)r * rows * h->NB * h->R * 32, rows, h->NB,
+                                          h->R, h->M, st));
+        }
+        h->att_ver[layer_id][r] = 0;
+    }
+    h->idbits_of[layer_id] = 0;
     return MP_OK;
 }
 
@@ -605,9 +629,10 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
     h->att_ver[layer_id][request_id] = 0;                // the rows are rewritten with plain ids
     MP_HIP_CHECK(launch_lsh_fill((const int16_t*)c, (const int32_t*)i, rows, n, h->NB, h->M, h->R, b, t,
                                  h->err, st));
-    bool unsorted = false;
-    rc = lsh_read_err(h, st, "mp_lsh_fill", &unsorted);
+    bool unsorted = false, wide = false;
+    rc = lsh_read_err(h, st, "mp_lsh_fill", &unsorted, &wide);
     if (rc) return rc;
+    if (wide && (rc = lsh_widen(h, layer_id, request_id, st)) != MP_OK) return rc;
     if (unsorted) {
         // R > 1 and some bucket's ids do not ascend (an unstable sort, models/attnserver.py:187): put the codes
         // back in token order and let the device counting sort rebuild the rows -- same buckets, ascending ids
@@ -644,6 +669,7 @@ int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes
     int32_t* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB * (h->R + 1);
     int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
     h->att_ver[layer_id][request_id] = 0;                // the rows are rewritten with plain ids
+    if (n > (1 << 17) && (rc = lsh_widen(h, layer_id, request_id, st)) != MP_OK) return rc;
     MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, h->R, b, t, h->err, st));
     MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, st));
     if (!h->slots.empty())
@@ -665,7 +691,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
         h->lastq = query;
         h->last_layer = layer_id;
         MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], query, results,
-                                         nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits, st));
+                                         nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_of[layer_id], st));
         return MP_OK;
     }
     // host callers (models/attnserver.py:299 passes CPU tensors).  Zero copy: the kernel reads the codes from the handle's
@@ -693,7 +719,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
             MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id],
                                              reinterpret_cast<const int32_t*>(hd + o_codes),
                                              reinterpret_cast<int32_t*>(res_dev), reinterpret_cast<int32_t*>(hd), BH,
-                                             h->G, h->L, h->NB, h->M, h->R, h->idbits, st));
+                                             h->G, h->L, h->NB, h->M, h->R, h->idbits_of[layer_id], st));
             MP_HIP_CHECK(hipStreamSynchronize(st));
             memcpy(nnz, hp, (size_t)BH * 4);
             if (mirror) {                         // only the first nnz[h] entries of a row mean anything
@@ -713,7 +739,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     h->lastq = h->last_query;
     h->last_layer = layer_id;
     MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], h->last_query,
-                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits, st));
+                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_of[layer_id], st));
     int32_t* d_offs = reinterpret_cast<int32_t*>(h->small.dp) + BH;           // dp: [nnz BH | offs BH + 1]
     MP_HIP_CHECK(launch_ragged_offsets(h->nnz, BH, h->M, d_offs, st));
     MP_HIP_CHECK(hipMemcpyAsync(h->small.dp, h->nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));
@@ -749,6 +775,7 @@ int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream) {
             MP_HIP_CHECK(hipMemsetAsync(h->slots[i], 0, groups * h->L * h->NB * (size_t)h->R * 128, st));
     }
     for (auto& v : h->att_ver) std::fill(v.begin(), v.end(), 0);
+    std::fill(h->idbits_of.begin(), h->idbits_of.end(), 17);
     h->last_layer = -1;
     return MP_OK;
 }
@@ -762,7 +789,7 @@ static int lsh_attach_norms(mp_lsh_t* h, int layer_id, int request_id, const flo
     int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
     int* flag = h->pay_bad + ((size_t)layer_id * h->B + request_id) * h->Hkv;
     MP_HIP_CHECK(hipMemsetAsync(flag, 0, (size_t)h->Hkv * 4, st));
-    MP_HIP_CHECK(launch_lsh_attach_norms(t, kn, h->Hkv, h->L, h->M, h->idbits, flag, st));
+    MP_HIP_CHECK(launch_lsh_attach_norms(t, kn, h->Hkv, h->L, h->M, 17, flag, st));
     if (!h->slots.empty()) {                            // the direct slots copy table words: rebuild them
         int32_t* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB * (h->R + 1);
         MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * 32, rows,
@@ -771,9 +798,10 @@ static int lsh_attach_norms(mp_lsh_t* h, int layer_id, int request_id, const flo
     return MP_OK;
 }
 
-int mp_lsh_get_id_bits(mp_lsh_t* h, int* id_bits) {
+int mp_lsh_get_id_bits(mp_lsh_t* h, int layer_id, int* id_bits) {
     MP_REQUIRE(h && h->allocated && id_bits, MP_ERR_STATE, "mp_lsh_get_id_bits: not allocated / null argument");
-    *id_bits = h->idbits;
+    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_lsh_get_id_bits: layer_id out of range");
+    *id_bits = h->idbits_of[layer_id];
     return MP_OK;
 }
 
@@ -796,7 +824,7 @@ int mp_lsh_get_mask(mp_lsh_t* h, int8_t* mask, int mem, mp_stream_t stream) {
         d = tmp.as<int8_t>();
     }
     MP_HIP_CHECK(launch_lsh_mask(h->bounds[h->last_layer], h->table[h->last_layer], h->lastq,
-                                 d, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits, st));
+                                 d, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_of[h->last_layer], st));
     if (mem == MP_MEM_HOST) {
         MP_HIP_CHECK(hipStreamSynchronize(st));
         MP_HIP_CHECK(hipMemcpy(mask, d, bytes, hipMemcpyDeviceToHost));
@@ -1308,7 +1336,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         // Key norms as a payload of the table entries (max_length <= 2^17; A/B: decode_kn_payload = 0): the first decode
         // of a layer after its tables or its store's norms changed packs them (two kernels per request, once; never
         // under stream capture -- a step captured before any eager one simply reads the norms per token).
-        bool kn_payload = lsh->idbits != 0 && g_opt.decode_kn_payload.load() != 0;
+        bool kn_payload = lsh->idbits_of[layer_id] != 0 && g_opt.decode_kn_payload.load() != 0;
         if (kn_payload) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
@@ -1335,7 +1363,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
                                        lsh->slots.empty() ? nullptr : lsh->slots[layer_id], attn->score, attn->err, attn_slices_per_head(attn->M), lsh->R,
                                        attn->xcd_rr && g_opt.decode_agent_scope.load() == 0,
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
-                                       lsh->L, lsh->NB, lsh->M, mfma_hash, lsh->xw, lsh->xseq, lsh->xwords, xmode, lsh->idbits,
+                                       lsh->L, lsh->NB, lsh->M, mfma_hash, lsh->xw, lsh->xseq, lsh->xwords, xmode, lsh->idbits_of[layer_id],
                                        kn_payload ? lsh->pay_bad + (size_t)layer_id * lsh->B * lsh->Hkv : nullptr, st));
         attn->lastz = lsh->nnz;
         attn->score_state = 1;
@@ -1346,7 +1374,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         MP_HIP_CHECK(launch_lsh_hash_retrieve(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk,
                                               s->wnorm, s->D, s->K, s->KLpad, lsh->codes, lsh->qnorm,
                                               lsh->results, lsh->nnz, BH, lsh->G, lsh->L, lsh->NB, lsh->M,
-                                              lsh->R, lsh->idbits, st));
+                                              lsh->R, lsh->idbits_of[layer_id], st));
         int rc = attn_run(attn, layer_id, false, s->K, s->L, output, max_value_expsum, q, MP_DTYPE_BF16,
                           lsh->qnorm, lsh->results, lsh->nnz, st);
         if (rc) return rc;

@@ -95,7 +95,8 @@ constexpr int DIRECT_MORE = 96;            // ids of a longer piece its half-wav
 // grid = Hkv*L rows of one request; one workgroup per (kv head, table) row.  RS = R + 1 entries per
 // bucket: this kernel writes entries 0 (start) and R (end); lsh_subbounds_kernel fills the rest.
 // err bits: 1 = invalid input (unsorted codes, code or id out of range); 4 = ids not ascending inside a
-// bucket (only looked at when R > 1; the host then re-sorts the row's buckets on device).
+// bucket (only looked at when R > 1; the host then re-sorts the row's buckets on device); 32 = an id >= 2^17 (the
+// layer's table words then have no room for a payload: capi.hip lsh_widen).
 __global__ __launch_bounds__(256) void lsh_fill_kernel(
     const int16_t* __restrict__ codes,   // [Hkv*L][n] sorted ascending per row
     const int32_t* __restrict__ ids,     // [Hkv*L][n]
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void lsh_fill_kernel(
     // buckets that do not occur keep start = end = 0 (lsh.cc:177-185 on zeroed arrays)
     for (int i = threadIdx.x; i < NB * RS; i += blockDim.x) b[i] = 0;
     __syncthreads();
-    bool bad = false, unsorted = false;
+    bool bad = false, unsorted = false, wide = false;
     for (int64_t k = threadIdx.x; k < n; k += blockDim.x) {
         const int v = c[k];
         const int prev = (k > 0) ? (int)c[k - 1] : -1;
@@ -125,9 +126,11 @@ __global__ __launch_bounds__(256) void lsh_fill_kernel(
             if (v != next) b[v * RS + RS - 1] = (int)(k + 1);   // one past the last
         }
         dst[k] = id;
+        if (id >= (1 << 17)) wide = true;
     }
     if (bad) atomicOr(err, 1);
     if (unsorted) atomicOr(err, 4);
+    if (wide) atomicOr(err, 32);
 }
 
 // codes of a reference-sorted row back in token order (the fallback of mp_lsh_fill when a bucket's ids are
@@ -214,11 +217,12 @@ __global__ __launch_bounds__(256) void lsh_slots_kernel(const int32_t* __restric
 // The decode kernel's gather then finds a selected token's norm in LDS (scattered there when the token was hit the
 // second time) instead of spending one random HBM access per token on it.
 // one request's rows [Hkv * L][M]; kn [Hkv][M] (the request's slice of the attention store's norms); bad[kv head] is set
-// when a norm the tables reference is not a non-negative bf16 number (the decode kernel then ignores the payload)
+// when a norm the tables reference is not a non-negative bf16 number (the decode kernel then ignores the payload).
+// kn == nullptr strips the payloads again (a layer whose ids outgrow 17 bits).
 __global__ void lsh_attach_norms_kernel(int32_t* __restrict__ table, const float* __restrict__ kn, int L, int64_t M,
                                         int idbits, int* __restrict__ bad) {
     const int64_t row = blockIdx.y;
-    const float* knr = kn + (row / L) * M;
+    const float* knr = kn ? kn + (row / L) * M : nullptr;
     int32_t* t = table + row * M;
     const uint32_t mask = (1u << idbits) - 1u;
     bool b = false;
@@ -226,7 +230,7 @@ __global__ void lsh_attach_norms_kernel(int32_t* __restrict__ table, const float
         const int32_t w = t[p];
         if (w == -1) continue;                                 // not an entry
         const uint32_t id = (uint32_t)w & mask;
-        uint32_t u = id < (uint64_t)M ? __float_as_uint(knr[id]) : 0u;
+        uint32_t u = (knr != nullptr && id < (uint64_t)M) ? __float_as_uint(knr[id]) : 0u;
         if ((u & 0x8000ffffu) != 0u || (u & 0x7f800000u) == 0x7f800000u) {   // not bf16, negative, inf / nan
             b = true;
             u = 0u;

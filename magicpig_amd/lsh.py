@@ -86,10 +86,11 @@ class LSH:
         return out
 
     # debug views (declared but never defined in the reference, lsh.h:24-26)
-    def id_bits(self) -> int:
-        """17 where max_length <= 2^17 (a table word = token id | payload << 17, include/magicpig_hip.h), else 0."""
+    def id_bits(self, layer_id: int) -> int:
+        """17 while every id of the layer's tables is below 2^17 (a table word = token id | payload << 17,
+        include/magicpig_hip.h), else 0."""
         bits = C.c_int32(0)
-        L.check(L.lib().mp_lsh_get_id_bits(self._h, C.byref(bits)))
+        L.check(L.lib().mp_lsh_get_id_bits(self._h, layer_id, C.byref(bits)))
         return bits.value
 
     def get_tables(self, layer_id: int, raw: bool = False):
@@ -100,7 +101,7 @@ class LSH:
         # entry 0 = start, entry R = end of a bucket; entry r = first position whose token id >= r * range_len
         bounds = L.device_tensor(b.value, (groups, self.L, self.NB, self.R + 1), "<i4", device=dev)
         table = L.device_tensor(t.value, (groups, self.L, self.M), "<i4", device=dev)
-        bits = self.id_bits()
+        bits = self.id_bits(layer_id)
         if bits and not raw:    # entries may carry a key-norm payload above the id (packed by the decode entry): show ids
             table = table & ((1 << bits) - 1)
         return bounds, table

@@ -50,6 +50,9 @@ server.collect_nnz = False
 for r in range(3):
     for li in range(NLAYER): server.decode(qs[r % reps, li], li)
 torch.cuda.synchronize()
+for kv in os.environ.get("MP_OPTIONS", "").split(","):      # e.g. MP_OPTIONS=decode_split_hash=0,decode_kn_payload=0
+    if "=" in kv:
+        L.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 L.set_option("stamp_stride", STRIDE)
 L.check(L.lib().mp_debug_set_stamp_buffer(L.ptr(stamp)))
 slots = [16, 28, 22, 23, 27, 42, 43, 44, 45, 17, 19, 20, 21, 33, 34, 35, 36, 37, 40, 41, 38, 39]

@@ -61,7 +61,7 @@ def test_payload_changes_nothing_observable(mp, B, H, Hkv, data):
     n, M, D, K, Lt = 6000, 6144, 128, 8, 75
     server, (keys, kns, vals, W, qb) = _server(mp, B, H, Hkv, n, M, D, K, Lt, 99, data)
     lsh = server.lsh_retriever
-    assert lsh.id_bits() == 17
+    assert lsh.id_bits(0) == 17
     _, plain = lsh.get_tables(0, raw=True)
     plain = plain.clone()
     assert not _packed(server, n=n)                            # plain ids until the first decode
@@ -153,10 +153,62 @@ def test_first_decode_under_capture_reads_norms_per_token(mp):
     assert torch.equal(o_graph.view_as(o_eager), o_eager)
 
 
-def test_long_contexts_keep_plain_ids(mp):
-    lsh = mp.LSH()
-    lsh.alloc(8, 4, 1, 2, 1, 1, (1 << 17) + 64)
-    assert lsh.id_bits() == 0
-    lsh2 = mp.LSH()
-    lsh2.alloc(8, 4, 1, 2, 1, 1, 1 << 17)
-    assert lsh2.id_bits() == 17
+def test_a_layer_whose_ids_outgrow_17_bits_goes_back_to_plain_ids(mp):
+    """max_length > 2^17 (BASELINE cfg 4: 131 264): the words carry payloads while every id of the layer is below
+    2^17; the first build / fill with a wider id strips the layer's other requests' payloads and the layer stays plain
+    until clear().  Results never change."""
+    B, H, Hkv, D, K, Lt = 2, 2, 1, 128, 8, 6
+    n0, n1, M = 5000, (1 << 17) + 40, (1 << 17) + 64
+    keys, kns, vals, W, qb = cases.case_inputs(31, 1, H, Hkv, n0, D, K, Lt)
+    server = mp.LSHSparseAttnServer(2, H, Hkv, D, K=K, L=Lt, batch_size=B, num_sink_tokens=0, num_local_tokens=0,
+                                    max_length=M, dense_layers=(), hash_func=bf16_t(W, "cuda"))
+    lsh = server.lsh_retriever
+    assert lsh.id_bits(0) == 17 and lsh.id_bits(1) == 17
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    big_k = torch.randn((Hkv, n1, D), device="cuda", generator=gen).to(torch.bfloat16)
+    big_v = torch.randn((Hkv, n1, D), device="cuda", generator=gen).to(torch.bfloat16)
+    for layer in (0, 1):
+        server.hash_code_buffer = server.hasher.keys(bf16_t(keys[0], "cuda"))
+        server.build_table(layer, 0, n0)
+        server.attn_server.fill(layer, 0, bf16_t(keys[0], "cuda"), bf16_t(vals[0], "cuda"), torch.from_numpy(kns[0]).cuda())
+        server.hash_code_buffer = server.hasher.keys(big_k[:, :n0].contiguous())
+        server.build_table(layer, 1, n0)
+        server.attn_server.fill(layer, 1, big_k[:, :n0].contiguous(), big_v[:, :n0].contiguous(),
+                                big_k[:, :n0].float().norm(dim=-1).to(torch.bfloat16).float())
+    q = torch.randn((B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16)
+
+    def dec(layer):
+        out, lse = server.decode(q, layer)
+        torch.cuda.synchronize()
+        return out.clone(), lse.clone(), server.nnz.clone()
+
+    first = [dec(0), dec(1)]
+    raw0 = lsh.get_tables(0, raw=True)[1]
+    assert bool((((raw0[:, :, :n0] >> 17) & 0x7fff) != 0).any())          # packed, although max_length > 2^17
+    # request 1 of layer 0 grows past 2^17 tokens (device build; then the reference's sorted-rows fill)
+    server.hash_code_buffer = server.hasher.keys(big_k)
+    codes = server.hash_code_buffer.clone()
+    server.build_table(0, 1, n1)
+    server.attn_server.fill(0, 1, big_k, big_v, big_k.float().norm(dim=-1).to(torch.bfloat16).float())
+    assert lsh.id_bits(0) == 0 and lsh.id_bits(1) == 17
+    raw0 = lsh.get_tables(0, raw=True)[1]
+    assert int(raw0[:Hkv, :, :n0].min()) >= 0 and int(raw0[:Hkv, :, :n0].max()) < n0      # request 0: stripped
+    assert int(raw0[Hkv:, :, :n1].max()) == n1 - 1
+    wide = dec(0)
+    assert torch.equal(wide[0][0], first[0][0][0]) and torch.equal(wide[2][:H], first[0][2][:H])   # request 0 unchanged
+    again1 = dec(1)
+    assert torch.equal(again1[0], first[1][0]) and torch.equal(again1[2], first[1][2])               # layer 1 untouched
+    import magicpig_amd._lib as L
+    L.set_option("decode_kn_payload", 0)
+    plain = dec(0)
+    assert torch.equal(plain[0], wide[0]) and torch.equal(plain[2], wide[2])
+    L.set_option("decode_kn_payload", 1)
+    # the same through mp_lsh_fill (sorted rows with ids >= 2^17) on layer 1
+    sv, si = codes.sort(dim=-1, stable=True)
+    lsh.fill(1, 1, sv.contiguous(), si.int().contiguous())
+    assert lsh.id_bits(1) == 0
+    server.attn_server.fill(1, 1, big_k, big_v, big_k.float().norm(dim=-1).to(torch.bfloat16).float())
+    w1 = dec(1)
+    assert torch.equal(w1[0], wide[0]) and torch.equal(w1[2], wide[2])      # layer 1 now holds what layer 0 holds
+    server.clear()
+    assert lsh.id_bits(0) == 17 and lsh.id_bits(1) == 17
