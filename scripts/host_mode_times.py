@@ -11,6 +11,9 @@ if os.environ.get("MP_LIB"):            # A/B builds of the library (this script
     L.LIB_PATH = os.path.abspath(os.environ["MP_LIB"])
 import magicpig_amd as mp
 from bench import CONFIGS
+for kv in os.environ.get("MP_OPTIONS", "").split(","):      # e.g. MP_OPTIONS=host_spin_wait=1 (this script only)
+    if "=" in kv:
+        L.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg1"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
