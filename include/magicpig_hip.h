@@ -239,7 +239,11 @@ int mp_simhash_debug_acc(mp_simhash_t* s, float* dev_buf);
  * ids stay on chip, while codes, results and nnz are still written to the handles' HBM buffers as
  * by-products (get_mask / get_score keep working).  q bf16 [B*H, D] device; output bf16 [B*H, D]
  * device; max_value_expsum f32 [2, B*H] device.  nnz_out (optional, device int32 [B*H]) receives
- * the per-head selected-token counts for statistics. */
+ * the per-head selected-token counts for statistics.
+ * Side effect on `lsh` (see mp_lsh_get_id_bits): the first call for a layer after its tables or `attn`'s key norms
+ * changed packs the norms into the layer's table words -- two extra kernels per request on `stream`, once (at cfg 1
+ * ~1.4 ms per layer: one pass over the 472-MB tables, the 1.26-GB direct slots rebuilt); a call under stream capture
+ * never packs (it reads the norms per token if the words are not packed yet). */
 int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int layer_id,
                            const uint16_t* q, uint16_t* output, float* max_value_expsum,
                            int32_t* nnz_out, mp_stream_t stream);
