@@ -243,7 +243,10 @@ int mp_simhash_debug_acc(mp_simhash_t* s, float* dev_buf);
  * Side effect on `lsh` (see mp_lsh_get_id_bits): the first call for a layer after its tables or `attn`'s key norms
  * changed packs the norms into the layer's table words -- two extra kernels per request on `stream`, once (at cfg 1
  * ~1.4 ms per layer: one pass over the 472-MB tables, the 1.26-GB direct slots rebuilt); a call under stream capture
- * never packs (it reads the norms per token if the words are not packed yet). */
+ * never packs.  Whether a KV group's payloads are USED is decided by the kernel from device words the fills and the
+ * packing write in stream order (the version of the norms the rows carry against the version the store holds now): a
+ * graph captured before the packing uses the payloads once they exist, one replayed after mp_attn_fill* / mp_lsh_fill /
+ * mp_lsh_build reads the norms per token until an eager call has packed again. */
 int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int layer_id,
                            const uint16_t* q, uint16_t* output, float* max_value_expsum,
                            int32_t* nnz_out, mp_stream_t stream);

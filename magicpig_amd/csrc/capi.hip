@@ -29,7 +29,8 @@ hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, co
                              int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
                              float*, float2*, int*, int*, uint16_t*, float*, float2*, const int32_t*, float*, int*,
                              int, int, bool, const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t,
-                             bool, unsigned long long*, unsigned int*, int, int, int, const int*, hipStream_t);
+                             bool, unsigned long long*, unsigned int*, int, int, int, const int*, const unsigned int*,
+                             const unsigned int*, hipStream_t);
 hipError_t set_stamp_stride(int);
 hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
@@ -266,8 +267,9 @@ struct mp_lsh {
     int64_t M = 0;
     std::vector<int> idbits_of;    // per layer: 17 while every id of the layer's tables is < 2^17 (the bits above carry a
                                    // token's key norm once packed), 0 once a fill brought a wider id (lsh_widen)
-    std::vector<std::vector<uint64_t>> att_ver;   // [layers][B]: version of the store's norms the rows of (layer, request) carry (0: none)
-    const void* att_to = nullptr;  // the attention store they were taken from
+    std::vector<std::vector<uint32_t>> att_ver;   // [layers][B]: version of the store's norms the rows of (layer, request) carry (0: none)
+    unsigned int* att_ver_dev = nullptr;          // [layers][B][Hkv] the same on the device, written in stream order:
+                                                  // what the decode kernel compares with the store's kn_ver_dev
     int* pay_bad = nullptr;        // [layers][B][Hkv] device flags: a norm of the KV group could not be packed (decode reads them)
     int R = 1;                     // token ranges per table row = workgroups per head of the decode kernel
     int range_len = 0;             // tokens per range (multiple of 32)
@@ -298,7 +300,9 @@ struct mp_attn {
     int64_t M = 0;
     std::vector<uint16_t*> kv;     // per layer [B*Hkv][M][2][D]
     std::vector<float*> kn;        // per layer [B*Hkv][M]
-    std::vector<std::vector<uint64_t>> kn_ver;   // [layers][B]: bumped whenever a fill rewrites the slot's norms
+    std::vector<std::vector<uint32_t>> kn_ver;   // [layers][B]: a process-wide unique number, renewed whenever a fill rewrites
+                                                 // the slot's norms
+    unsigned int* kn_ver_dev = nullptr;          // [layers][B][Hkv] the same on the device (written in stream order)
     float* score = nullptr;        // [BH][M] logits -> probabilities on demand
     float* part_o = nullptr;       // [max_slices][D]
     float2* part_ml = nullptr;     // [max_slices]
@@ -452,10 +456,10 @@ static void lsh_free(mp_lsh_t* h) {
     h->bounds.clear();
     h->table.clear();
     h->slots.clear();
-    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->xw, h->xseq, h->pay_bad};
+    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->xw, h->xseq, h->pay_bad, h->att_ver_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->last_query = nullptr; h->err = nullptr; h->codes = nullptr; h->results = nullptr;
-    h->nnz = nullptr; h->qnorm = nullptr; h->xw = nullptr; h->xseq = nullptr; h->pay_bad = nullptr;
+    h->nnz = nullptr; h->qnorm = nullptr; h->xw = nullptr; h->xseq = nullptr; h->pay_bad = nullptr; h->att_ver_dev = nullptr;
     h->small.release();
     h->big.release();
     h->hostmap.release();
@@ -492,8 +496,7 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
     h->G = h->H / h->Hkv; h->M = max_length;
     const size_t groups = (size_t)h->B * h->Hkv, BH = (size_t)h->B * h->H;
     h->idbits_of.assign((size_t)num_layers, 17);
-    h->att_ver.assign((size_t)num_layers, std::vector<uint64_t>((size_t)batch_size, 0));
-    h->att_to = nullptr;
+    h->att_ver.assign((size_t)num_layers, std::vector<uint32_t>((size_t)batch_size, 0));
     h->R = decode_cluster_size((int)BH, h->M);
     h->range_len = lsh_range_len(h->M, h->R);
     // direct piece slots (lsh.hip: lsh_slots_kernel): one 128-byte record per (table, bucket, token range)
@@ -536,6 +539,7 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
         if (rc == MP_OK && hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->xseq), 1, BH) != hipSuccess) rc = MP_ERR_HIP;
     }
     if (rc == MP_OK) rc = alloc_zero((void**)&h->pay_bad, (size_t)num_layers * batch_size * num_key_value_heads * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->att_ver_dev, (size_t)num_layers * batch_size * num_key_value_heads * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->last_query, BH * L * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->err, 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->codes, BH * L * 4);
@@ -588,6 +592,14 @@ static int lsh_read_err(mp_lsh_t* h, hipStream_t st, const char* who, bool* unso
     return MP_OK;
 }
 
+// the version of the store's norms the rows of (layer, request) carry, on the host and -- in stream order -- on the device
+static int lsh_set_version(mp_lsh_t* h, int layer_id, int request_id, uint32_t v, hipStream_t st) {
+    h->att_ver[layer_id][request_id] = v;
+    unsigned int* d = h->att_ver_dev + ((size_t)layer_id * h->B + request_id) * h->Hkv;
+    MP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d), (int)v, (size_t)h->Hkv, st));
+    return MP_OK;
+}
+
 // A table word is  id | payload << 17  while every id of the LAYER is below 2^17.  The first fill that brings a wider
 // id (a context past 131 072 offloaded tokens) turns the layer's words into plain ids for good (until mp_lsh_clear):
 // the payloads the other requests' rows may carry are stripped, their direct slots rebuilt.
@@ -604,7 +616,8 @@ static int lsh_widen(mp_lsh_t* h, int layer_id, int except_request, hipStream_t 
             MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)r * rows * h->NB * h->R * 32, rows, h->NB,
                                           h->R, h->M, st));
         }
-        h->att_ver[layer_id][r] = 0;
+        int rc = lsh_set_version(h, layer_id, r, 0, st);
+        if (rc) return rc;
     }
     h->idbits_of[layer_id] = 0;
     return MP_OK;
@@ -626,7 +639,7 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
     if (rc) return rc;
     int32_t* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB * (h->R + 1);
     int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
-    h->att_ver[layer_id][request_id] = 0;                // the rows are rewritten with plain ids
+    if ((rc = lsh_set_version(h, layer_id, request_id, 0, st)) != MP_OK) return rc;   // the rows are rewritten with plain ids
     MP_HIP_CHECK(launch_lsh_fill((const int16_t*)c, (const int32_t*)i, rows, n, h->NB, h->M, h->R, b, t,
                                  h->err, st));
     bool unsorted = false, wide = false;
@@ -668,7 +681,7 @@ int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes
     if (rc) return rc;
     int32_t* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB * (h->R + 1);
     int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
-    h->att_ver[layer_id][request_id] = 0;                // the rows are rewritten with plain ids
+    if ((rc = lsh_set_version(h, layer_id, request_id, 0, st)) != MP_OK) return rc;   // the rows are rewritten with plain ids
     if (n > (1 << 17) && (rc = lsh_widen(h, layer_id, request_id, st)) != MP_OK) return rc;
     MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, h->R, b, t, h->err, st));
     MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, st));
@@ -775,6 +788,7 @@ int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream) {
             MP_HIP_CHECK(hipMemsetAsync(h->slots[i], 0, groups * h->L * h->NB * (size_t)h->R * 128, st));
     }
     for (auto& v : h->att_ver) std::fill(v.begin(), v.end(), 0);
+    MP_HIP_CHECK(hipMemsetAsync(h->att_ver_dev, 0, (size_t)h->layers * h->B * h->Hkv * 4, st));
     std::fill(h->idbits_of.begin(), h->idbits_of.end(), 17);
     h->last_layer = -1;
     return MP_OK;
@@ -856,15 +870,31 @@ int mp_attn_create(mp_attn_t** out) {
     return MP_OK;
 }
 
+// Versions of the key norms a store holds: unique across stores and fills, never 0.  A table's words may carry the
+// norms of version v (mp_lsh_t::att_ver*); the decode kernel uses them only while the store still says v.
+static std::atomic<uint32_t> g_kn_version{0};
+static uint32_t next_kn_version() {
+    uint32_t v = ++g_kn_version;
+    if (v == 0) v = ++g_kn_version;
+    return v;
+}
+static int attn_new_version(mp_attn_t* h, int layer_id, int request_id, hipStream_t st) {
+    const uint32_t v = next_kn_version();
+    h->kn_ver[layer_id][request_id] = v;
+    unsigned int* d = h->kn_ver_dev + ((size_t)layer_id * h->B + request_id) * h->Hkv;
+    MP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d), (int)v, (size_t)h->Hkv, st));
+    return MP_OK;
+}
+
 static void attn_free(mp_attn_t* h) {
     for (auto p : h->kv) if (p) (void)hipFree(p);
     for (auto p : h->kn) if (p) (void)hipFree(p);
     h->kv.clear();
     h->kn.clear();
-    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt, h->err, h->colsum, h->part_cnt};
+    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt, h->err, h->colsum, h->part_cnt, h->kn_ver_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->score = nullptr; h->part_o = nullptr; h->part_ml = nullptr; h->head_mz = nullptr;
-    h->last_nnz = nullptr; h->head_cnt = nullptr; h->err = nullptr; h->colsum = nullptr; h->part_cnt = nullptr;
+    h->last_nnz = nullptr; h->head_cnt = nullptr; h->err = nullptr; h->colsum = nullptr; h->part_cnt = nullptr; h->kn_ver_dev = nullptr;
     if (h->ind_rows) (void)hipFree(h->ind_rows);
     h->ind_rows = nullptr;
     h->small.release();
@@ -896,7 +926,7 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
     h->device = current_device();
     h->layers = num_layers; h->H = num_attention_heads; h->Hkv = num_key_value_heads;
     h->D = head_dim; h->B = batch_size; h->G = h->H / h->Hkv; h->M = max_length;
-    h->kn_ver.assign((size_t)num_layers, std::vector<uint64_t>((size_t)batch_size, 1));
+
     const size_t groups = (size_t)h->B * h->Hkv, BH = (size_t)h->B * h->H;
     int rc = MP_OK;
     for (int i = 0; i < num_layers && rc == MP_OK; ++i) {
@@ -915,6 +945,13 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
     if (rc == MP_OK) rc = alloc_zero((void**)&h->head_cnt, BH * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->err, 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->part_cnt, BH * 8 * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->kn_ver_dev, (size_t)num_layers * groups * 4);
+    if (rc == MP_OK) {   // every slot's norms (zeros) get a version no table can carry yet
+        const uint32_t v = next_kn_version();
+        h->kn_ver.assign((size_t)num_layers, std::vector<uint32_t>((size_t)batch_size, v));
+        if (hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->kn_ver_dev), (int)v, (size_t)num_layers * groups) != hipSuccess)
+            rc = MP_ERR_HIP;
+    }
     // scratch of mp_attn_fill_offload (8 MB at Llama shapes): here, not lazily -- a first call under stream capture
     // could not allocate
     if (rc == MP_OK) rc = alloc_zero((void**)&h->colsum, (size_t)FILL_BLOCKS * h->Hkv * h->D * sizeof(double));
@@ -948,8 +985,8 @@ int mp_attn_fill(mp_attn_t* h, int layer_id, int request_id, const uint16_t* k, 
     MP_REQUIRE(n >= 0 && n <= h->M, MP_ERR_INVALID, "mp_attn_fill: sequence longer than max_length");
     MP_REQUIRE(k && v && kn, MP_ERR_INVALID, "mp_attn_fill: null argument");
     if (n == 0) return MP_OK;
-    ++h->kn_ver[layer_id][request_id];
     hipStream_t st = (hipStream_t)stream;
+    if (int vrc = attn_new_version(h, layer_id, request_id, st)) return vrc;
     DevBuf dk, dv, dn;
     const void *kd, *vd, *nd;
     const size_t eb = (size_t)h->Hkv * n * h->D * 2;
@@ -986,7 +1023,7 @@ int mp_attn_fill_offload(mp_attn_t* h, mp_simhash_t* s, int layer_id, int reques
                    "mp_attn_fill_offload: hasher disagrees on head_dim / device");
     }
     hipStream_t st = (hipStream_t)stream;
-    ++h->kn_ver[layer_id][request_id];
+    if (int vrc = attn_new_version(h, layer_id, request_id, st)) return vrc;
     int nblk = (int)((n + 63) / 64);
     if (nblk > FILL_BLOCKS) nblk = FILL_BLOCKS;
     uint16_t* kv = h->kv[layer_id] + (size_t)request_id * h->Hkv * h->M * 2 * h->D;
@@ -1220,7 +1257,12 @@ int mp_attn_clear(mp_attn_t* h, mp_stream_t stream) {
         MP_HIP_CHECK(hipMemsetAsync(h->kn[i], 0, groups * (size_t)h->M * 4, st));
     }
     MP_HIP_CHECK(hipMemsetAsync(h->score, 0, BH * (size_t)h->M * 4, st));
-    for (auto& v : h->kn_ver) for (auto& x : v) ++x;
+    {
+        const uint32_t nv = next_kn_version();
+        for (auto& v : h->kn_ver) std::fill(v.begin(), v.end(), nv);
+        MP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->kn_ver_dev), (int)nv,
+                                       (size_t)h->layers * h->B * h->Hkv, st));
+    }
     h->score_state = 0;
     return MP_OK;
 }
@@ -1333,29 +1375,23 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         if (mfma_hash)
             MP_HIP_CHECK(launch_simhash_query(q, s->Wt, s->wnorm, BH, s->D, s->K, s->L, lsh->codes, lsh->qnorm,
                                               nullptr, st));
-        // Key norms as a payload of the table entries (max_length <= 2^17; A/B: decode_kn_payload = 0): the first decode
-        // of a layer after its tables or its store's norms changed packs them (two kernels per request, once; never
-        // under stream capture -- a step captured before any eager one simply reads the norms per token).
-        bool kn_payload = lsh->idbits_of[layer_id] != 0 && g_opt.decode_kn_payload.load() != 0;
+        // Key norms as a payload of the table entries (while the layer's ids fit 17 bits; A/B: decode_kn_payload = 0): the
+        // first decode of a layer after its tables or its store's norms changed packs them (two kernels per request,
+        // once; never under stream capture).  Whether a KV group's payload is USED is decided by the kernel from device
+        // words written in stream order (the version the rows carry == the version the store holds, no norm refused):
+        // a graph captured before the packing uses it afterwards, one replayed after a refill does not.
+        const bool kn_payload = lsh->idbits_of[layer_id] != 0 && g_opt.decode_kn_payload.load() != 0;
         if (kn_payload) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
-            for (int b = 0; b < lsh->B && kn_payload; ++b) {
-                if (lsh->att_to == attn && lsh->att_ver[layer_id][b] == attn->kn_ver[layer_id][b]) continue;
-                if (capturing) {
-                    kn_payload = false;
-                } else {
-                    int rc = lsh_attach_norms(lsh, layer_id, b, attn->kn[layer_id] + (size_t)b * attn->Hkv * attn->M, st);
-                    if (rc) return rc;
-                    lsh->att_ver[layer_id][b] = attn->kn_ver[layer_id][b];
-                }
-            }
-            if (kn_payload && lsh->att_to != attn) {          // another store: every slot of every layer is stale
-                for (auto& v : lsh->att_ver) std::fill(v.begin(), v.end(), 0);
-                for (int b = 0; b < lsh->B; ++b) lsh->att_ver[layer_id][b] = attn->kn_ver[layer_id][b];
-                lsh->att_to = attn;
+            for (int b = 0; b < lsh->B && !capturing; ++b) {
+                if (lsh->att_ver[layer_id][b] == attn->kn_ver[layer_id][b]) continue;
+                int rc = lsh_attach_norms(lsh, layer_id, b, attn->kn[layer_id] + (size_t)b * attn->Hkv * attn->M, st);
+                if (rc == MP_OK) rc = lsh_set_version(lsh, layer_id, b, attn->kn_ver[layer_id][b], st);
+                if (rc) return rc;
             }
         }
+        const size_t goff = (size_t)layer_id * lsh->B * lsh->Hkv;
         MP_HIP_CHECK(launch_lsh_decode(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk, s->wnorm, s->D,
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
@@ -1364,7 +1400,8 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
                                        attn->xcd_rr && g_opt.decode_agent_scope.load() == 0,
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
                                        lsh->L, lsh->NB, lsh->M, mfma_hash, lsh->xw, lsh->xseq, lsh->xwords, xmode, lsh->idbits_of[layer_id],
-                                       kn_payload ? lsh->pay_bad + (size_t)layer_id * lsh->B * lsh->Hkv : nullptr, st));
+                                       kn_payload ? lsh->pay_bad + goff : nullptr, lsh->att_ver_dev + goff,
+                                       attn->kn_ver_dev + goff, st));
         attn->lastz = lsh->nnz;
         attn->score_state = 1;
         attn->seg_cnt = lsh->R > 1 ? attn->part_cnt : nullptr;

@@ -514,7 +514,11 @@ struct AttnArgs {
     unsigned int* xseq;      // split hash: [BH] sequence number of the current launch (the merger advances it)
     int xwords, xmode;       // words per head; xmode 2 = nobody publishes (test: every member takes the fallback)
     const int* pay_bad;      // [B*Hkv] or nullptr: the table entries of this layer carry their tokens' key norms,
-                             // unless the flag of the head's KV group says one of them could not be packed
+                             // unless the flag of the head's KV group says one of them could not be packed ...
+    const unsigned int* att_ver;   // [B*Hkv] ... or the version of the norms the group's rows carry (0: plain ids)
+    const unsigned int* kn_ver;    // [B*Hkv] is not the version of the norms the attention store holds now: both are
+                                   // device words written in stream order by the fills / the packing, so a replayed
+                                   // graph sees the state of its replay, not of its capture
     // optional static window (models/attnserver.py:281-308): exact attention over the first win_len[h]
     // rows of a second KV store joins the same softmax, which IS flashinfer.merge_state of the two parts
     const uint16_t* win_kv;  // [B*Hkv][win_M][2][D] or nullptr
@@ -572,7 +576,7 @@ __device__ __forceinline__ void lsh_head_body(
     const int clog = (AD > 0) ? aa.cluster_log2 : 0;
     const bool lead = rank == 0;                              // the member that writes codes / ||q||
     const int64_t g = h / G;
-    if (AD > 0 && idbits != 0 && aa.pay_bad != nullptr) pay = aa.pay_bad[g] == 0;
+    if (AD > 0 && idbits != 0 && aa.pay_bad != nullptr) pay = aa.pay_bad[g] == 0 && aa.att_ver[g] == aa.kn_ver[g];
     const int RS = R + 1;
     const int32_t* bnd = bounds + g * L * NB * RS;
     const int32_t* tab = table + g * L * M;
@@ -1635,7 +1639,8 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                              float* score, int* err, int maxs, int R, bool same_xcd, const uint16_t* win_kv,
                              const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
                              bool codes_given, unsigned long long* xw, unsigned int* xseq, int xwords, int xmode,
-                             int idbits, const int* pay_bad, hipStream_t st) {
+                             int idbits, const int* pay_bad, const unsigned int* att_ver, const unsigned int* kn_ver,
+                             hipStream_t st) {
     const int range_len = lsh_range_len(M, R);
     const int words = range_len / 32;
     const int Lpad = (L + 63) & ~63;
@@ -1652,13 +1657,16 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     const bool split_hash = xmode != 0 && sx && xw != nullptr && xseq != nullptr && !codes_given &&
                             ((K * L + 63) / 64) <= (RT_WAVES << clog) && 2 * ((K * L + 63) / 64) <= xwords;
     AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, slots, score, err, BH, BHp, maxs,
-                   DECODE_ID_CAP, clog, sx ? 1 : 0, split_hash ? xw : nullptr, split_hash ? xseq : nullptr, xwords, xmode, nullptr,
+                   DECODE_ID_CAP, clog, sx ? 1 : 0, split_hash ? xw : nullptr, split_hash ? xseq : nullptr, xwords, xmode, nullptr, nullptr, nullptr,
                    win_kv, win_len, win_M};
     const dim3 grid((unsigned)BHp << clog);
     size_t lds = decode_lds_bytes(range_len, L, D);
     // key norms from the table entries' payload: 2 bytes of LDS per token of a member's range, where they fit
-    if (pay_bad != nullptr && idbits != 0 && lds + (size_t)range_len * 2 + 16 <= RT_LDS_DYN_MAX) {
+    if (pay_bad != nullptr && att_ver != nullptr && kn_ver != nullptr && idbits != 0 &&
+        lds + (size_t)range_len * 2 + 16 <= RT_LDS_DYN_MAX) {
         aa.pay_bad = pay_bad;
+        aa.att_ver = att_ver;
+        aa.kn_ver = kn_ver;
         lds += (size_t)range_len * 2 + 16;
     }
     if (codes_given) {   // A/B: the codes and ||q|| come from simhash_query_kernel (plain decode only)

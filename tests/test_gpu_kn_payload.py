@@ -131,11 +131,15 @@ def test_norms_that_cannot_ride_along_and_norms_that_change(mp):
     assert not torch.equal(got2[0], base[0])
 
 
-def test_first_decode_under_capture_reads_norms_per_token(mp):
-    """Packing launches kernels that must not be baked into a caller's graph: a decode captured before any eager one
-    leaves the tables alone and gives the same result."""
+def test_captured_decodes_follow_the_state_of_their_replay(mp):
+    """Whether a KV group's payload is used is decided on the device, from words written in stream order: (1) a decode
+    captured before any eager one packs nothing (no packing kernels in a caller's graph) and reads the norms per token;
+    (2) once an eager decode has packed the words the SAME graph uses them; (3) after a refill of the store alone
+    (other norms, tables untouched) or of both the replayed graph follows the new state -- a graph captured in the
+    packed state must not read stale payloads."""
+    import magicpig_amd._lib as L
     B, H, Hkv, n, M, D, K, Lt = 1, 8, 2, 5000, 5120, 128, 8, 60
-    server, _ = _server(mp, B, H, Hkv, n, M, D, K, Lt, 6)
+    server, (keys, kns, vals, W, qb) = _server(mp, B, H, Hkv, n, M, D, K, Lt, 6)
     gen = torch.Generator(device="cuda").manual_seed(3)
     q = torch.randn((B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16)
     server.collect_nnz = False
@@ -143,14 +147,41 @@ def test_first_decode_under_capture_reads_norms_per_token(mp):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         server.decode(q, 0)
-    graph.replay()
-    torch.cuda.synchronize()
-    o_graph = server.output.clone()
+
+    def replay():
+        graph.replay()
+        torch.cuda.synchronize()
+        return server.output.clone()
+
+    def eager(option):
+        L.set_option("decode_kn_payload", option)
+        out = _decode(server, q)[0].reshape(-1, D).clone()
+        L.set_option("decode_kn_payload", 1)
+        return out
+
+    o1 = replay()
+    assert not _packed(server, n=n)                               # (1)
+    want = eager(0)
     assert not _packed(server, n=n)
+    assert torch.equal(o1, want)
+    assert torch.equal(eager(1), want) and _packed(server, n=n)   # packs
+    assert torch.equal(replay(), want)                            # (2)
+    # (3a) the store alone gets other norms: the packed words are stale, the graph must not use them
+    server.attn_server.fill(0, 0, bf16_t(keys[0], "cuda"), bf16_t(vals[0], "cuda"), torch.from_numpy(kns[0]).cuda() * 2)
+    o3 = replay()
+    want3 = eager(0)
+    assert torch.equal(o3, want3) and not torch.equal(want3, want)
+    assert torch.equal(eager(1), want3) and torch.equal(replay(), want3)      # re-packed with the new norms
+    # (3b) a new prompt: tables rebuilt (plain ids again) and store refilled, then only the graph runs
+    keys2, kns2, vals2, _, _ = cases.case_inputs(77, B, H, Hkv, n, D, K, Lt)
+    server.hash_code_buffer = server.hasher.keys(bf16_t(keys2[0], "cuda"))
+    server.build_table(0, 0, n)
+    server.attn_server.fill(0, 0, bf16_t(keys2[0], "cuda"), bf16_t(vals2[0], "cuda"), torch.from_numpy(kns2[0]).cuda())
+    o4 = replay()
+    assert not _packed(server, n=n)
+    want4 = eager(0)
+    assert torch.equal(o4, want4) and not torch.equal(want4, want3)
     server.collect_nnz = True
-    o_eager = _decode(server, q)[0]
-    assert _packed(server, n=n)
-    assert torch.equal(o_graph.view_as(o_eager), o_eager)
 
 
 def test_a_layer_whose_ids_outgrow_17_bits_goes_back_to_plain_ids(mp):
