@@ -29,7 +29,7 @@ hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, co
                              int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
                              float*, float2*, int*, int*, uint16_t*, float*, float2*, const int32_t*, float*, int*,
                              int, int, bool, const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t,
-                             bool, unsigned long long*, unsigned int*, int, int, int, const int*, const unsigned int*,
+                             bool, unsigned long long*, unsigned int*, int, int, int, const int*, const int*, const unsigned int*,
                              const unsigned int*, hipStream_t);
 hipError_t set_stamp_stride(int);
 hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
@@ -268,6 +268,7 @@ struct mp_lsh {
     std::vector<int> idbits_of;    // per layer: 17 while every id of the layer's tables is < 2^17 (the bits above carry a
                                    // token's key norm once packed), 0 once a fill brought a wider id (lsh_widen)
     std::vector<std::vector<uint32_t>> att_ver;   // [layers][B]: version of the store's norms the rows of (layer, request) carry (0: none)
+    int* idbits_dev = nullptr;                    // [layers] idbits_of on the device, written in stream order
     unsigned int* att_ver_dev = nullptr;          // [layers][B][Hkv] the same on the device, written in stream order:
                                                   // what the decode kernel compares with the store's kn_ver_dev
     int* pay_bad = nullptr;        // [layers][B][Hkv] device flags: a norm of the KV group could not be packed (decode reads them)
@@ -456,10 +457,10 @@ static void lsh_free(mp_lsh_t* h) {
     h->bounds.clear();
     h->table.clear();
     h->slots.clear();
-    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->xw, h->xseq, h->pay_bad, h->att_ver_dev};
+    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->xw, h->xseq, h->pay_bad, h->att_ver_dev, h->idbits_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->last_query = nullptr; h->err = nullptr; h->codes = nullptr; h->results = nullptr;
-    h->nnz = nullptr; h->qnorm = nullptr; h->xw = nullptr; h->xseq = nullptr; h->pay_bad = nullptr; h->att_ver_dev = nullptr;
+    h->nnz = nullptr; h->qnorm = nullptr; h->xw = nullptr; h->xseq = nullptr; h->pay_bad = nullptr; h->att_ver_dev = nullptr; h->idbits_dev = nullptr;
     h->small.release();
     h->big.release();
     h->hostmap.release();
@@ -540,6 +541,9 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
     }
     if (rc == MP_OK) rc = alloc_zero((void**)&h->pay_bad, (size_t)num_layers * batch_size * num_key_value_heads * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->att_ver_dev, (size_t)num_layers * batch_size * num_key_value_heads * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->idbits_dev, (size_t)num_layers * 4);
+    if (rc == MP_OK && hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->idbits_dev), 17, (size_t)num_layers) != hipSuccess)
+        rc = MP_ERR_HIP;
     if (rc == MP_OK) rc = alloc_zero((void**)&h->last_query, BH * L * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->err, 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->codes, BH * L * 4);
@@ -620,6 +624,7 @@ static int lsh_widen(mp_lsh_t* h, int layer_id, int except_request, hipStream_t 
         if (rc) return rc;
     }
     h->idbits_of[layer_id] = 0;
+    MP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->idbits_dev + layer_id), 0, 1, st));
     return MP_OK;
 }
 
@@ -790,6 +795,7 @@ int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream) {
     for (auto& v : h->att_ver) std::fill(v.begin(), v.end(), 0);
     MP_HIP_CHECK(hipMemsetAsync(h->att_ver_dev, 0, (size_t)h->layers * h->B * h->Hkv * 4, st));
     std::fill(h->idbits_of.begin(), h->idbits_of.end(), 17);
+    MP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->idbits_dev), 17, (size_t)h->layers, st));
     h->last_layer = -1;
     return MP_OK;
 }
@@ -1399,7 +1405,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
                                        lsh->slots.empty() ? nullptr : lsh->slots[layer_id], attn->score, attn->err, attn_slices_per_head(attn->M), lsh->R,
                                        attn->xcd_rr && g_opt.decode_agent_scope.load() == 0,
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
-                                       lsh->L, lsh->NB, lsh->M, mfma_hash, lsh->xw, lsh->xseq, lsh->xwords, xmode, lsh->idbits_of[layer_id],
+                                       lsh->L, lsh->NB, lsh->M, mfma_hash, lsh->xw, lsh->xseq, lsh->xwords, xmode, lsh->idbits_of[layer_id], lsh->idbits_dev + layer_id,
                                        kn_payload ? lsh->pay_bad + goff : nullptr, lsh->att_ver_dev + goff,
                                        attn->kn_ver_dev + goff, st));
         attn->lastz = lsh->nnz;

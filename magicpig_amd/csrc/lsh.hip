@@ -515,6 +515,8 @@ struct AttnArgs {
     int xwords, xmode;       // words per head; xmode 2 = nobody publishes (test: every member takes the fallback)
     const int* pay_bad;      // [B*Hkv] or nullptr: the table entries of this layer carry their tokens' key norms,
                              // unless the flag of the head's KV group says one of them could not be packed ...
+    const int* idbits_dev;         // the layer's id width as the device knows it (a fill that widens the layer clears it
+                                   // in stream order): overrides the launch argument, which a replayed graph froze
     const unsigned int* att_ver;   // [B*Hkv] ... or the version of the norms the group's rows carry (0: plain ids)
     const unsigned int* kn_ver;    // [B*Hkv] is not the version of the norms the attention store holds now: both are
                                    // device words written in stream order by the fills / the packing, so a replayed
@@ -562,6 +564,7 @@ __device__ __forceinline__ void lsh_head_body(
     // 2^17: a 17-bit id + the 15 bits of a non-negative bf16).  The id is always masked; with `pay` the decode scatters
     // the norm of a token into LDS when it is hit the second time -- the gather then reads it from there instead of
     // spending one HBM line request in five on a 4-byte value (EXPERIMENTS.md R3-10).
+    if (AD > 0 && aa.idbits_dev != nullptr) idbits = *aa.idbits_dev;
     const uint32_t idmask = idbits ? ((1u << idbits) - 1u) : 0xffffffffu;
     bool pay = false;                                           // uniform
 
@@ -1639,8 +1642,8 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                              float* score, int* err, int maxs, int R, bool same_xcd, const uint16_t* win_kv,
                              const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
                              bool codes_given, unsigned long long* xw, unsigned int* xseq, int xwords, int xmode,
-                             int idbits, const int* pay_bad, const unsigned int* att_ver, const unsigned int* kn_ver,
-                             hipStream_t st) {
+                             int idbits, const int* idbits_dev, const int* pay_bad, const unsigned int* att_ver,
+                             const unsigned int* kn_ver, hipStream_t st) {
     const int range_len = lsh_range_len(M, R);
     const int words = range_len / 32;
     const int Lpad = (L + 63) & ~63;
@@ -1657,7 +1660,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     const bool split_hash = xmode != 0 && sx && xw != nullptr && xseq != nullptr && !codes_given &&
                             ((K * L + 63) / 64) <= (RT_WAVES << clog) && 2 * ((K * L + 63) / 64) <= xwords;
     AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, slots, score, err, BH, BHp, maxs,
-                   DECODE_ID_CAP, clog, sx ? 1 : 0, split_hash ? xw : nullptr, split_hash ? xseq : nullptr, xwords, xmode, nullptr, nullptr, nullptr,
+                   DECODE_ID_CAP, clog, sx ? 1 : 0, split_hash ? xw : nullptr, split_hash ? xseq : nullptr, xwords, xmode, nullptr, idbits_dev, nullptr, nullptr,
                    win_kv, win_len, win_M};
     const dim3 grid((unsigned)BHp << clog);
     size_t lds = decode_lds_bytes(range_len, L, D);

@@ -216,6 +216,13 @@ def test_a_layer_whose_ids_outgrow_17_bits_goes_back_to_plain_ids(mp):
     first = [dec(0), dec(1)]
     raw0 = lsh.get_tables(0, raw=True)[1]
     assert bool((((raw0[:, :, :n0] >> 17) & 0x7fff) != 0).any())          # packed, although max_length > 2^17
+    # a graph of layer 0's decode captured in the packed, 17-bit state
+    server.collect_nnz = False
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        server.decode(q, 0)
+    server.collect_nnz = True
     # request 1 of layer 0 grows past 2^17 tokens (device build; then the reference's sorted-rows fill)
     server.hash_code_buffer = server.hasher.keys(big_k)
     codes = server.hash_code_buffer.clone()
@@ -226,6 +233,9 @@ def test_a_layer_whose_ids_outgrow_17_bits_goes_back_to_plain_ids(mp):
     assert int(raw0[:Hkv, :, :n0].min()) >= 0 and int(raw0[:Hkv, :, :n0].max()) < n0      # request 0: stripped
     assert int(raw0[Hkv:, :, :n1].max()) == n1 - 1
     wide = dec(0)
+    graph.replay()                       # the id width is read from the device: the frozen launch argument says 17
+    torch.cuda.synchronize()
+    assert torch.equal(server.output.view_as(wide[0]), wide[0])
     assert torch.equal(wide[0][0], first[0][0][0]) and torch.equal(wide[2][:H], first[0][2][:H])   # request 0 unchanged
     again1 = dec(1)
     assert torch.equal(again1[0], first[1][0]) and torch.equal(again1[2], first[1][2])               # layer 1 untouched
