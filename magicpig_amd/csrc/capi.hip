@@ -40,11 +40,11 @@ hipError_t launch_lsh_subbounds(const int32_t*, int32_t*, int, int, int, int64_t
 hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int, int32_t*, int32_t*, int*,
                             hipStream_t);
 hipError_t launch_lsh_retrieve(const int32_t*, const int32_t*, const int32_t*, int32_t*, int32_t*, int,
-                               int, int, int, int64_t, int, int, hipStream_t);
+                               int, int, int, int64_t, int, const int*, hipStream_t);
 hipError_t launch_lsh_attach_norms(int32_t*, const float*, int, int, int64_t, int, int*, hipStream_t);
 hipError_t launch_lsh_hash_retrieve(const int32_t*, const int32_t*, const uint16_t*, const uint16_t*,
                                     const float*, int, int, int, int32_t*, float*, int32_t*, int32_t*,
-                                    int, int, int, int, int64_t, int, int, hipStream_t);
+                                    int, int, int, int, int64_t, int, const int*, hipStream_t);
 hipError_t launch_lsh_compact(uint32_t*, const int*, int, int, int64_t, hipStream_t);
 hipError_t launch_lsh_hash_only(const uint16_t*, const uint16_t*, const float*, int, int, int, int32_t*, float*, int, int,
                                 hipStream_t);
@@ -709,7 +709,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
         h->lastq = query;
         h->last_layer = layer_id;
         MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], query, results,
-                                         nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_of[layer_id], st));
+                                         nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, st));
         return MP_OK;
     }
     // host callers (models/attnserver.py:299 passes CPU tensors).  Zero copy: the kernel reads the codes from the handle's
@@ -737,7 +737,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
             MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id],
                                              reinterpret_cast<const int32_t*>(hd + o_codes),
                                              reinterpret_cast<int32_t*>(res_dev), reinterpret_cast<int32_t*>(hd), BH,
-                                             h->G, h->L, h->NB, h->M, h->R, h->idbits_of[layer_id], st));
+                                             h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, st));
             MP_HIP_CHECK(hipStreamSynchronize(st));
             memcpy(nnz, hp, (size_t)BH * 4);
             if (mirror) {                         // only the first nnz[h] entries of a row mean anything
@@ -757,7 +757,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     h->lastq = h->last_query;
     h->last_layer = layer_id;
     MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], h->last_query,
-                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_of[layer_id], st));
+                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, st));
     int32_t* d_offs = reinterpret_cast<int32_t*>(h->small.dp) + BH;           // dp: [nnz BH | offs BH + 1]
     MP_HIP_CHECK(launch_ragged_offsets(h->nnz, BH, h->M, d_offs, st));
     MP_HIP_CHECK(hipMemcpyAsync(h->small.dp, h->nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));
@@ -1417,7 +1417,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         MP_HIP_CHECK(launch_lsh_hash_retrieve(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk,
                                               s->wnorm, s->D, s->K, s->KLpad, lsh->codes, lsh->qnorm,
                                               lsh->results, lsh->nnz, BH, lsh->G, lsh->L, lsh->NB, lsh->M,
-                                              lsh->R, lsh->idbits_of[layer_id], st));
+                                              lsh->R, lsh->idbits_dev + layer_id, st));
         int rc = attn_run(attn, layer_id, false, s->K, s->L, output, max_value_expsum, q, MP_DTYPE_BF16,
                           lsh->qnorm, lsh->results, lsh->nnz, st);
         if (rc) return rc;

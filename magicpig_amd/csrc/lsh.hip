@@ -1299,9 +1299,12 @@ template <int HASH, int CH>
 __global__ __launch_bounds__(RT_THREADS, 4) void lsh_retrieve_kernel(
     const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
-    int G, int L, int NB, int64_t M, int R, int words, int Lpad, int idbits, HashArgs ha,
+    int G, int L, int NB, int64_t M, int R, int words, int Lpad, const int* __restrict__ idbits_dev, HashArgs ha,
     unsigned long long* __restrict__ stamp) {
     const AttnArgs aa = {};
+    // the layer's id width from the device word (written in stream order by a fill that widens the layer): a launch
+    // argument would be frozen in a captured graph
+    const int idbits = idbits_dev ? *idbits_dev : 0;
     lsh_head_body<HASH, CH, 0, false>(bounds, table, query, results, nnz, G, L, NB, M, R, 0, words, Lpad, idbits, ha, aa, stamp);
 }
 
@@ -1575,7 +1578,7 @@ static hipError_t retrieve_attr_once() {
 
 hipError_t launch_lsh_retrieve(const int32_t* bounds, const int32_t* table, const int32_t* query,
                                int32_t* results, int32_t* nnz, int BH, int G, int L, int NB,
-                               int64_t M, int R, int idbits, hipStream_t st) {
+                               int64_t M, int R, const int* idbits, hipStream_t st) {
     const int words = (int)((M + 31) / 32);
     const int Lpad = (L + 63) & ~63;
     hipError_t e = retrieve_attr_once();
@@ -1591,7 +1594,7 @@ hipError_t launch_lsh_retrieve(const int32_t* bounds, const int32_t* table, cons
 hipError_t launch_lsh_hash_retrieve(const int32_t* bounds, const int32_t* table, const uint16_t* q,
                                     const uint16_t* Wk, const float* wnorm, int D, int K, int KLpad,
                                     int32_t* codes_out, float* qnorm_out, int32_t* results,
-                                    int32_t* nnz, int BH, int G, int L, int NB, int64_t M, int R, int idbits,
+                                    int32_t* nnz, int BH, int G, int L, int NB, int64_t M, int R, const int* idbits,
                                     hipStream_t st) {
     const int words = (int)((M + 31) / 32);
     const int Lpad = (L + 63) & ~63;
@@ -1620,11 +1623,11 @@ hipError_t launch_lsh_hash_only(const uint16_t* q, const uint16_t* Wk, const flo
     if (D >= 128)
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 16>), dim3(rows), dim3(RT_THREADS), lds, st, (const int32_t*)nullptr,
                            (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 1, L,
-                           1 << K, (int64_t)0, 1, 0, Lpad, 0, ha, g_stamp);
+                           1 << K, (int64_t)0, 1, 0, Lpad, (const int*)nullptr, ha, g_stamp);
     else
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 8>), dim3(rows), dim3(RT_THREADS), lds, st, (const int32_t*)nullptr,
                            (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 1, L,
-                           1 << K, (int64_t)0, 1, 0, Lpad, 0, ha, g_stamp);
+                           1 << K, (int64_t)0, 1, 0, Lpad, (const int*)nullptr, ha, g_stamp);
     return hipGetLastError();
 }
 
