@@ -1,0 +1,66 @@
+"""The committed measurement artefacts are self-consistent (CPU only): every bench line under profiles/ carries the
+fields the bench contract names, its roofline arithmetic closes (achieved = algorithmic bytes / average launch time,
+frac = achieved / peak), the GPU's first layer matched the compiled reference in that run, and
+profiles/hbm_traffic_latest.json -- the file bench.py copies `roofline.traffic` from -- is what the PMC passes it cites
+say (FETCH_SIZE x 2 + WRITE_SIZE, KB = 1024 B)."""
+import glob
+import json
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+
+
+def _latest_tag():
+    src = json.load(open(os.path.join(PROF, "hbm_traffic_latest.json")))["source"]
+    return re.search(r"profiles/(r\d+[a-z]?)_pmc_hbm_traffic", src).group(1)
+
+
+def test_traffic_json_is_what_the_pmc_passes_say():
+    tag = _latest_tag()
+    traffic = json.load(open(os.path.join(PROF, "hbm_traffic_latest.json")))
+    seen = 0
+    for key, suffix in (("lsh_decode_bytes_per_launch", ""), ("lsh_decode_bytes_per_launch_clustered", "_clustered")):
+        for cfg, total in traffic[key].items():
+            text = open(os.path.join(PROF, f"{tag}_pmc_hbm_traffic_{cfg}{suffix}.md")).read()
+            kb = {}
+            for m in re.finditer(r"\|\s*void mp::lsh_decode_kernel.*\|\s*(FETCH_SIZE|WRITE_SIZE)\s*\|\s*\d+\s*\|\s*([\d.]+)\s*\|", text):
+                kb[m.group(1)] = float(m.group(2))
+            assert set(kb) == {"FETCH_SIZE", "WRITE_SIZE"}, (cfg, suffix)
+            assert abs((2 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024 - total) <= 1e-6 * total, (cfg, suffix)
+            seen += 1
+    assert seen >= 6
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(PROF, f"{_latest_tag()}_bench_cfg*.json"))),
+                         ids=lambda p: os.path.basename(p))
+def test_bench_lines_close(path):
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["higher_is_better"] is True
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["achieved"] - r["bytes_per_launch"] / r["avg_launch_us"] / 1e3) <= 1e-6 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9
+    # whole-job throughput = batch / step time; a step is all sparse layers of one token
+    batch = d["config"]["global_batch"]
+    assert abs(d["value"] - batch / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] >= 1 and c["value"] > 0
+    assert c["gpu_matches"]["nnz_equal"] is True and c["gpu_matches"]["max_abs_out_diff"] <= 1e-2
+    if "cfg0" not in path:
+        cfg = re.search(r"(cfg\d)", path).group(1)
+        key = "lsh_decode_bytes_per_launch" + ("_clustered" if "clustered" in path else "")
+        assert r["traffic"] is not None and r["traffic"] >= r["bytes_per_launch"]      # never below the algorithmic bytes
+        assert "not measured in this run" in r["traffic_source"]
+        # the rocprofv3 average of the same command agrees with the HIP-event time of the line
+        stats = open(os.path.join(PROF, os.path.basename(path).replace("_bench_", "_kernel_stats_").replace(".json", ".md"))).read()
+        m = re.search(r"\|\s*void mp::lsh_decode_kernel[^|]*\|\s*\d+\s*\|\s*([\d.]+)\s*\|", stats)
+        assert m and abs(float(m.group(1)) - r["avg_launch_us"]) <= 0.03 * r["avg_launch_us"], (m and m.group(1), r["avg_launch_us"])
+        assert key and cfg
