@@ -109,6 +109,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-mode", action="store_true", help="skip the untimed host-buffer (unchanged caller) leg")
+    ap.add_argument("--host-register-leg", action="store_true",
+                    help="host-buffer leg: also time the opt-in host_register mode (hipHostRegister of `results`)")
     ap.add_argument("--cpu-steps", type=int, default=8192,
                     help="decode steps of ONE sparse layer timed on the host cores per thread placement (medians): "
                          "~5 s of CPU work at cfg 1, ~20 s at cfg 2")
@@ -262,7 +264,7 @@ def run_cpu_baseline(cfg, server, qs, steps, H, Hkv):
 
 # ---------------------------------------------------------------------------- host-buffer mode leg
 
-def host_mode_leg(server, cfg, qs, H, reps=40):
+def host_mode_leg(server, cfg, qs, H, reps=40, register_leg=False):
     """Per-layer cost of the UNCHANGED caller: the decode lines of models/attnserver.py:264-303 -- q hash on the GPU,
     codes + query copied to pinned CPU tensors, batch_retrieve and attention_wrapper on CPU tensors (`results` and
     `nnz` pageable, the rest pinned, exactly as :59-66), output + LSE copied back -- eager, synchronised per layer.
@@ -301,12 +303,17 @@ def host_mode_leg(server, cfg, qs, H, reps=40):
         return (time.perf_counter() - t0) / reps * 1e6
 
     us = timed()
-    # the same with the pageable `results` registered once and used in place (these buffers outlive the handles)
-    L.set_option("host_register", 1)
-    try:
-        us_reg = timed()
-    finally:
-        L.set_option("host_register", 0)
+    # the same with the pageable `results` registered once and used in place (these buffers outlive the handles).  On
+    # request only (--host-register-leg): hipHostRegister aborted inside the ROCm runtime in two test-suite runs of
+    # round 3 (EXPERIMENTS.md R3-9), and an abort here would cost the whole bench line; profiles/r03g_bench_*.json
+    # carry the figure (151-158 us per layer at cfg 1).
+    us_reg = None
+    if register_leg:
+        L.set_option("host_register", 1)
+        try:
+            us_reg = timed()
+        finally:
+            L.set_option("host_register", 0)
     host_layer(qs[(reps - 1) % NQ, 0])
     server.collect_nnz = True
     server.decode(qs[(reps - 1) % NQ, 0], 0)
@@ -645,7 +652,7 @@ def main():
 
     if rank == 0 and world == 1 and shard is None and not args.no_host_mode:
         try:
-            out["host_mode"] = host_mode_leg(server, cfg, qs, H)
+            out["host_mode"] = host_mode_leg(server, cfg, qs, H, register_leg=args.host_register_leg)
         except Exception as e:
             out["host_mode"] = {"us_per_layer": None, "what": f"failed: {e!r}"[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

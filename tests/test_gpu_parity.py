@@ -259,10 +259,10 @@ def test_pipeline_vs_reference_and_oracle(mp, name, where):
     _check_attention(r, g)
 
 
-# hipHostRegister of caller buffers (the opt-in `host_register` mode) aborted INSIDE the ROCm runtime once in a full
-# suite run of round 3 (EXPERIMENTS.md R3-9) -- an abort takes the whole pytest process with it, so the mode is
-# exercised on request (MP_TEST_HOST_REGISTER=1; it passed in every run of the round after R3-9) and timed by every
-# bench.py run (host_mode.us_per_layer_host_register), not by default here.
+# hipHostRegister of caller buffers (the opt-in `host_register` mode) aborted INSIDE the ROCm runtime in two suite runs
+# of round 3 (EXPERIMENTS.md R3-9; the second time right at this test) -- an abort takes the whole pytest process with
+# it, so the mode is exercised on request (MP_TEST_HOST_REGISTER=1; bench.py --host-register-leg times it), not by
+# default.
 _REGISTER = pytest.param("register", marks=pytest.mark.skipif(not os.environ.get("MP_TEST_HOST_REGISTER"),
                                                               reason="opt-in: MP_TEST_HOST_REGISTER=1"))
 
