@@ -182,6 +182,13 @@ int mp_attn_check(mp_attn_t* h, mp_stream_t stream);
 int mp_attn_get_kv(mp_attn_t* h, int layer_id, void** key_dev, void** value_dev,
                    int64_t* row_stride_elems);
 int mp_attn_get_key_norm(mp_attn_t* h, int layer_id, void** kn_dev);
+/* The key-norm view above is writable (the reference's get_key_norm is a from_blob alias too,
+ * sparse_attention.cc:1228-1233).  The one-launch decode entries may carry a request's norms inside its LSH table words
+ * (see mp_lsh_get_id_bits): a caller that WRITES norms through the view says so here -- the request's norms get a new
+ * version and the next mp_decode_* call of the layer packs them again.  mp_attn_fill* do this themselves;
+ * mp_attn_append* mark the layer's norms "changed outside a fill" (in stream order, also inside a replayed graph): the
+ * decode kernels then read the norms per token until the next fill.  No reference counterpart. */
+int mp_attn_invalidate_norms(mp_attn_t* h, int layer_id, int request_id, mp_stream_t stream);
 /* get_score, sparse_attention.cc:1235-1241: probabilities of the last sparse/full call,
  * f32 [B, H, M], first nnz entries per head in `ind` order.  Normalised (and, after the one-launch
  * decode, compacted) on demand, ONCE per call that produced logits: the library tracks that on the host,

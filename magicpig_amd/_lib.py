@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
         "mp_attn_get_kv": ([p, i32, pp, pp, C.POINTER(i64)], i32),
         "mp_attn_get_key_norm": ([p, i32, pp], i32),
         "mp_attn_get_score": ([p, pp, p], i32),
+        "mp_attn_invalidate_norms": ([p, i32, i32, p], i32),
         "mp_decode_sparse_layer": ([p, p, p, i32, p, p, p, p, p], i32),
         "mp_decode_layer_window": ([p, p, p, p, i32, p, p, p, p, p, p], i32),
         "mp_merge_state": ([p, p, p, p, i32, i32, p, p, p], i32),

@@ -692,7 +692,7 @@ __global__ void attn_append_kernel(const uint16_t* __restrict__ k, const uint16_
                                    const int32_t* __restrict__ pos, int pos_delta,
                                    const uint16_t* __restrict__ centre,   // [B*Hkv][D] bf16 or nullptr
                                    int Hkv, int D, int64_t M, uint16_t* __restrict__ kv,
-                                   float* __restrict__ kn, int* __restrict__ err) {
+                                   float* __restrict__ kn, unsigned int* __restrict__ kn_ver, int* __restrict__ err) {
     const int b = blockIdx.x / Hkv;
     const int64_t unit = blockIdx.x;                 // b*Hkv + kv head
     const int p = pos[b] + pos_delta;
@@ -700,6 +700,10 @@ __global__ void attn_append_kernel(const uint16_t* __restrict__ k, const uint16_
         if (threadIdx.x == 0) atomicOr(err, 2);
         return;
     }
+    // a norm of this KV group changes: its version becomes "unknown" in stream order (also in a replayed graph), which
+    // no LSH table can carry -- a decode kernel whose table words hold this group's norms reads them per token again
+    // until the store is refilled (capi.hip: KN_VERSION_UNKNOWN)
+    if (threadIdx.x == 0 && kn_ver != nullptr) kn_ver[unit] = 0xffffffffu;
     const int cpr = D / 8;
     double ss = 0.0;
     if ((int)threadIdx.x < cpr) {
@@ -943,9 +947,9 @@ hipError_t launch_key_centre_fill(const uint16_t* key_cache, const uint16_t* val
 
 hipError_t launch_attn_append(const uint16_t* k, const uint16_t* v, const int32_t* pos, int pos_delta,
                               const uint16_t* centre, int B, int Hkv, int D, int64_t M, uint16_t* kv, float* kn,
-                              int* err, hipStream_t st) {
+                              unsigned int* kn_ver, int* err, hipStream_t st) {
     hipLaunchKernelGGL(attn_append_kernel, dim3(B * Hkv), dim3(64), 0, st, k, v, pos, pos_delta, centre, Hkv, D,
-                       M, kv, kn, err);
+                       M, kv, kn, kn_ver, err);
     return hipGetLastError();
 }
 

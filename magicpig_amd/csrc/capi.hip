@@ -27,7 +27,7 @@ bool lsh_decode_supported(int64_t M, int L, int D, int R);
 bool xcd_round_robin_verified();
 hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, const uint16_t*, const float*, int,
                              int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
-                             float*, float2*, int*, int*, uint16_t*, float*, float2*, const int32_t*, float*, int*,
+                             float*, float2*, int*, int*, int*, uint16_t*, float*, float2*, const int32_t*, float*, int*,
                              int, int, bool, const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t,
                              bool, unsigned long long*, unsigned int*, int, int, int, const int*, const int*, const unsigned int*,
                              const unsigned int*, hipStream_t);
@@ -69,7 +69,8 @@ hipError_t launch_ragged_copy(bool, int32_t*, int32_t*, const int32_t*, int, int
 hipError_t launch_merge_state(const uint16_t*, const float*, const uint16_t*, const float*, int,
                               int, uint16_t*, float*, hipStream_t);
 hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, int, const uint16_t*, int, int, int, int64_t,
-                              uint16_t*, float*, int*, hipStream_t);
+                              uint16_t*, float*, unsigned int*, int*, hipStream_t);
+bool lsh_hash_only_supported(int L);
 hipError_t launch_attn_ticket_check(int*, int, int*, hipStream_t);
 hipError_t launch_relay(const void*, void*, size_t, hipStream_t);
 hipError_t launch_host_rows(const int32_t*, const int32_t*, int32_t*, int64_t, int, const void*, void*, size_t, int,
@@ -172,13 +173,14 @@ struct Stage {
     void* hd = nullptr;   // the same block as the device sees it (kernels read / write it over PCIe)
     void* dp = nullptr;   // device
     size_t cap = 0;
-    int reserve(size_t bytes) {
-        if (bytes <= cap) return MP_OK;
+    // host_only: the block is a pinned MIRROR the kernels write over PCIe (hp / hd); no device twin is allocated
+    int reserve(size_t bytes, bool host_only = false) {
+        if (bytes <= cap && (host_only || dp != nullptr)) return MP_OK;
         size_t want = cap ? cap : 4096;
         while (want < bytes) want *= 2;
         release();
         MP_HIP_CHECK(hipHostMalloc(&hp, want, hipHostMallocMapped));
-        MP_HIP_CHECK(hipMalloc(&dp, want));
+        if (!host_only) MP_HIP_CHECK(hipMalloc(&dp, want));
         if (hipHostGetDevicePointer(&hd, hp, 0) != hipSuccess) {
             (void)hipGetLastError();
             hd = nullptr;                      // no alias: callers fall back to copies
@@ -238,6 +240,7 @@ struct HostMap {
 };
 
 constexpr int FILL_BLOCKS = 1024;   // row blocks of mp_attn_fill_offload's column sums
+constexpr int MAX_CLUSTER = 32;     // workgroups per query head of the one-launch decode, at most
 
 static int alloc_zero(void** p, size_t bytes) {
     MP_HIP_CHECK(hipMalloc(p, bytes ? bytes : 1));
@@ -309,8 +312,9 @@ struct mp_attn {
     float2* part_ml = nullptr;     // [max_slices]
     float2* head_mz = nullptr;     // [BH] (max logit, Z) of the last call
     int* head_cnt = nullptr;       // [BH] arrival tickets of the in-launch merge (zero between calls)
-    int* part_cnt = nullptr;       // [BH][8] selected tokens of every cluster member in the last one-launch decode (owned
-                                   // here, not by the lsh handle: get_score compacts the score rows with it later)
+    int* part_cnt = nullptr;       // [BH][8] selected tokens of every cluster member in the last one-launch decode
+    int* wave_cnt = nullptr;       // [BH][MAX_CLUSTER][16] selected tokens of every wave of every member in the last one-launch
+                                   // decode (owned here, not by the lsh handle: get_score compacts the score rows with it later)
     int* err = nullptr;            // device-side validation flag (append past max_length)
     double* colsum = nullptr;      // [FILL_BLOCKS][Hkv*D] scratch of mp_attn_fill_offload
     Stage small, big;              // host-buffer mode: (q | qn | nnz | offsets | out | mve) and the packed index rows
@@ -320,8 +324,8 @@ struct mp_attn {
     const int32_t* lastz = nullptr;// device nnz of the last call (for get_score): last_nnz or the
                                    // caller's own device buffer (valid until it changes)
     int score_state = 0;           // 0 none, 1 logits, 2 probabilities
-    const int* seg_cnt = nullptr;  // score rows are in R segments (decode kernel, R > 1): per-member counts,
-    int seg_R = 1;                 // compacted on demand by mp_attn_get_score
+    const int* seg_cnt = nullptr;  // score rows are in 16 R segments (decode kernel: one per wave of every member): the
+    int seg_R = 1;                 // per-wave counts; compacted on demand by mp_attn_get_score
     int grid = 8;                  // workgroups per head of the partial kernel (grid.x)
     bool head_kernel = false;      // one workgroup per head (attn_head_kernel) instead of split-KV
     bool xcd_rr = false;           // block b -> XCD b % 8 observed on this device (xcd_round_robin_verified)
@@ -396,7 +400,7 @@ int mp_simhash_query(mp_simhash_t* s, const uint16_t* q, int R, int32_t* codes, 
     if (mem == MP_MEM_DEVICE) {
         // a handful of rows (a decode step's B*H <= 64 query heads): one workgroup per row on the vector pipes; the MFMA
         // kernel's 32-row tiles take the bulk case (same exact-sign definition: identical codes, tests/test_gpu_parity.py)
-        if (R <= 64 && s->dbg_acc == nullptr && qnorm != nullptr)
+        if (R <= 64 && s->dbg_acc == nullptr && qnorm != nullptr && lsh_hash_only_supported(s->L))
             MP_HIP_CHECK(launch_lsh_hash_only(q, s->Wk, s->wnorm, s->D, s->K, s->KLpad, codes, qnorm, R, s->L, st));
         else
             MP_HIP_CHECK(launch_simhash_query(q, s->Wt, s->wnorm, R, s->D, s->K, s->L, codes, qnorm,
@@ -722,7 +726,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
         void* res_dev = h->hostmap.resolve(results, rbytes, g_opt.host_register.load() != 0);
         bool mirror = false;
         if (res_dev == nullptr) {                 // pageable `results`: the kernel writes the handle's pinned mirror
-            rc = h->big.reserve(rbytes);
+            rc = h->big.reserve(rbytes, true);
             if (rc) return rc;
             res_dev = h->big.hd;
             mirror = res_dev != nullptr;
@@ -878,10 +882,13 @@ int mp_attn_create(mp_attn_t** out) {
 
 // Versions of the key norms a store holds: unique across stores and fills, never 0.  A table's words may carry the
 // norms of version v (mp_lsh_t::att_ver*); the decode kernel uses them only while the store still says v.
+// KN_VERSION_UNKNOWN: what an append (or mp_attn_get_key_norm's writable view, through mp_attn_invalidate_norms' absence)
+// leaves behind -- "these norms changed outside a fill": never equal to a version a table carries, and never packed.
+constexpr uint32_t KN_VERSION_UNKNOWN = 0xffffffffu;
 static std::atomic<uint32_t> g_kn_version{0};
 static uint32_t next_kn_version() {
     uint32_t v = ++g_kn_version;
-    if (v == 0) v = ++g_kn_version;
+    while (v == 0 || v == KN_VERSION_UNKNOWN) v = ++g_kn_version;
     return v;
 }
 static int attn_new_version(mp_attn_t* h, int layer_id, int request_id, hipStream_t st) {
@@ -897,10 +904,10 @@ static void attn_free(mp_attn_t* h) {
     for (auto p : h->kn) if (p) (void)hipFree(p);
     h->kv.clear();
     h->kn.clear();
-    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt, h->err, h->colsum, h->part_cnt, h->kn_ver_dev};
+    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt, h->err, h->colsum, h->part_cnt, h->kn_ver_dev, h->wave_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->score = nullptr; h->part_o = nullptr; h->part_ml = nullptr; h->head_mz = nullptr;
-    h->last_nnz = nullptr; h->head_cnt = nullptr; h->err = nullptr; h->colsum = nullptr; h->part_cnt = nullptr; h->kn_ver_dev = nullptr;
+    h->last_nnz = nullptr; h->head_cnt = nullptr; h->err = nullptr; h->colsum = nullptr; h->part_cnt = nullptr; h->kn_ver_dev = nullptr; h->wave_cnt = nullptr;
     if (h->ind_rows) (void)hipFree(h->ind_rows);
     h->ind_rows = nullptr;
     h->small.release();
@@ -951,6 +958,7 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
     if (rc == MP_OK) rc = alloc_zero((void**)&h->head_cnt, BH * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->err, 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->part_cnt, BH * 8 * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->wave_cnt, BH * (size_t)MAX_CLUSTER * 16 * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->kn_ver_dev, (size_t)num_layers * groups * 4);
     if (rc == MP_OK) {   // every slot's norms (zeros) get a version no table can carry yet
         const uint32_t v = next_kn_version();
@@ -1049,8 +1057,13 @@ static int attn_append(mp_attn_t* h, int layer_id, const uint16_t* k, const uint
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, w + ": not allocated");
     MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, w + ": layer_id out of range");
     MP_REQUIRE(k && v && pos, MP_ERR_INVALID, w + ": null argument");
+    // the norms of every request's KV groups change at a caller-chosen position (possibly one the LSH tables index):
+    // the version of the layer's norms becomes "unknown" -- on the device by the kernel itself, in stream order and
+    // in every replay of a captured graph; on the host here, so that the decode entry does not re-pack table words
+    // from norms that keep changing (it packs again after the next fill)
+    for (int b = 0; b < h->B; ++b) h->kn_ver[layer_id][b] = KN_VERSION_UNKNOWN;
     MP_HIP_CHECK(launch_attn_append(k, v, pos, pos_delta, centre, h->B, h->Hkv, h->D, h->M, h->kv[layer_id],
-                                    h->kn[layer_id], h->err, st));
+                                    h->kn[layer_id], h->kn_ver_dev + (size_t)layer_id * h->B * h->Hkv, h->err, st));
     return MP_OK;
 }
 
@@ -1317,13 +1330,21 @@ int mp_attn_get_key_norm(mp_attn_t* h, int layer_id, void** kn_dev) {
     return MP_OK;
 }
 
+int mp_attn_invalidate_norms(mp_attn_t* h, int layer_id, int request_id, mp_stream_t stream) {
+    MP_ON_DEVICE(h);
+    MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_invalidate_norms: not allocated");
+    MP_REQUIRE(layer_id >= 0 && layer_id < h->layers, MP_ERR_INVALID, "mp_attn_invalidate_norms: layer_id out of range");
+    MP_REQUIRE(request_id >= 0 && request_id < h->B, MP_ERR_INVALID, "mp_attn_invalidate_norms: request_id out of range");
+    return attn_new_version(h, layer_id, request_id, (hipStream_t)stream);
+}
+
 int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream) {
     MP_ON_DEVICE(h);
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_get_score: not allocated");
     MP_REQUIRE(score_dev, MP_ERR_INVALID, "mp_attn_get_score: null argument");
     hipStream_t st = (hipStream_t)stream;
     if (h->score_state == 1) {
-        if (h->seg_cnt != nullptr && h->seg_R > 1) {   // one-launch decode: R per-member segments -> one list
+        if (h->seg_cnt != nullptr) {                   // one-launch decode: per-wave segments -> one list
             MP_HIP_CHECK(launch_lsh_compact(reinterpret_cast<uint32_t*>(h->score), h->seg_cnt, h->B * h->H,
                                             h->seg_R, h->M, st));
             h->seg_cnt = nullptr;
@@ -1392,6 +1413,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
             const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
             for (int b = 0; b < lsh->B && !capturing; ++b) {
                 if (lsh->att_ver[layer_id][b] == attn->kn_ver[layer_id][b]) continue;
+                if (attn->kn_ver[layer_id][b] == KN_VERSION_UNKNOWN) continue;   // norms changed outside a fill: never packed
                 int rc = lsh_attach_norms(lsh, layer_id, b, attn->kn[layer_id] + (size_t)b * attn->Hkv * attn->M, st);
                 if (rc == MP_OK) rc = lsh_set_version(lsh, layer_id, b, attn->kn_ver[layer_id][b], st);
                 if (rc) return rc;
@@ -1401,7 +1423,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         MP_HIP_CHECK(launch_lsh_decode(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk, s->wnorm, s->D,
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
-                                       attn->part_cnt, attn->head_cnt, output, max_value_expsum, attn->head_mz,
+                                       attn->part_cnt, attn->wave_cnt, attn->head_cnt, output, max_value_expsum, attn->head_mz,
                                        lsh->slots.empty() ? nullptr : lsh->slots[layer_id], attn->score, attn->err, attn_slices_per_head(attn->M), lsh->R,
                                        attn->xcd_rr && g_opt.decode_agent_scope.load() == 0,
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
@@ -1410,7 +1432,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
                                        attn->kn_ver_dev + goff, st));
         attn->lastz = lsh->nnz;
         attn->score_state = 1;
-        attn->seg_cnt = lsh->R > 1 ? attn->part_cnt : nullptr;
+        attn->seg_cnt = attn->wave_cnt;
         attn->seg_R = lsh->R;
     } else {
         // two launches: (hash + retrieve), then attention (models/attnserver.py:264-299, :300)

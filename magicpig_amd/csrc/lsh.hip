@@ -501,6 +501,7 @@ struct AttnArgs {
     float* part_o;           // [BH][maxs][D]
     float2* part_ml;         // [BH][maxs]
     int* part_cnt;           // [BH][8] selected tokens of every member (R > 1), bits 0..23; bits 24..27 its XCC_ID
+    int* wave_cnt;           // [BH][R][16] selected tokens of every wave of every member: the segments of the score rows
     int* head_cnt;           // [BH] arrival tickets, zero between launches
     uint16_t* out;           // [BH][D] bf16
     float* mve;              // [2][BH]
@@ -564,8 +565,9 @@ __device__ __forceinline__ void lsh_head_body(
     // 2^17: a 17-bit id + the 15 bits of a non-negative bf16).  The id is always masked; with `pay` the decode scatters
     // the norm of a token into LDS when it is hit the second time -- the gather then reads it from there instead of
     // spending one HBM line request in five on a 4-byte value (EXPERIMENTS.md R3-10).
-    if (AD > 0 && aa.idbits_dev != nullptr) idbits = *aa.idbits_dev;
-    const uint32_t idmask = idbits ? ((1u << idbits) - 1u) : 0xffffffffu;
+    // (read BEHIND the query row's request, below: in front of it the four device words were three dependent scalar round
+    // trips at the head of the kernel -- EXPERIMENTS.md R3-14)
+    uint32_t idmask = idbits ? ((1u << idbits) - 1u) : 0xffffffffu;
     bool pay = false;                                           // uniform
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -579,7 +581,6 @@ __device__ __forceinline__ void lsh_head_body(
     const int clog = (AD > 0) ? aa.cluster_log2 : 0;
     const bool lead = rank == 0;                              // the member that writes codes / ||q||
     const int64_t g = h / G;
-    if (AD > 0 && idbits != 0 && aa.pay_bad != nullptr) pay = aa.pay_bad[g] == 0 && aa.att_ver[g] == aa.kn_ver[g];
     const int RS = R + 1;
     const int32_t* bnd = bounds + g * L * NB * RS;
     const int32_t* tab = table + g * L * M;
@@ -613,6 +614,21 @@ __device__ __forceinline__ void lsh_head_body(
     // collision bitmaps and piece lengths start at zero: done here, under the query row's round trip
     for (int i = tid; i < 2 * words; i += RT_THREADS) s_u32[i] = 0u;
     for (int l = tid; l < Lpad; l += RT_THREADS) s_len[l] = 0;
+    // -- the layer's id width and the state of this KV group's payloads, as the device knows them: independent scalar
+    //    loads behind the row's request, one wait, no short-circuit between them; first needed when table words are counted
+    if (AD > 0 && aa.idbits_dev != nullptr) {
+        const int ib = *aa.idbits_dev;
+        int bad = 1;
+        unsigned int av = 0u, kv = 1u;
+        if (aa.pay_bad != nullptr) {
+            bad = aa.pay_bad[g];
+            av = aa.att_ver[g];
+            kv = aa.kn_ver[g];
+        }
+        idbits = ib;
+        pay = (ib != 0) & (bad == 0) & (av == kv);
+        idmask = idbits ? ((1u << idbits) - 1u) : 0xffffffffu;
+    }
     if (HASH == 2) {   // the hash ran as its own launch: only the raw query row (for q.k) and ||q|| are fetched here
         const int per = ha.D >> 6;
         if (wave == 0) {
@@ -1051,85 +1067,144 @@ __device__ __forceinline__ void lsh_head_body(
     if (!(AD > 0 && HASH != 0 && slots != nullptr && ntail == 0)) __syncthreads();
     MP_STAMP(stamp, 19);
 
-    // sweep B: contiguous words per thread, block-wide exclusive scan, ascending emission
-    int cnt = 0;
-    // the stand-alone retrieve writes the head's list; a decode member writes ITS list at column t0 of the
-    // head's row (a by-product: get_score's order, the spill path below), nnz is summed at the hand-off
-    int32_t* out = results + h * M + t0;
-    const int nsw = words;
-    const int wpt = (nsw + RT_THREADS - 1) / RT_THREADS;
-    const int w0 = tid * wpt;
-    for (int k = 0; k < wpt; ++k)
-        if (w0 + k < nsw) cnt += __popc(bmB[w0 + k]);
-    int total;
-    int off = block_excl_scan(cnt, s_tmp, total);
-    MP_STAMP(stamp, 20);
-    // AD: the member's ids stay in LDS; a list longer than the stage (cap ids) is read back from HBM
-    const bool spill = AD > 0 && total > aa.cap;
-    for (int k = 0; k < wpt; ++k) {
-        if (w0 + k >= nsw) break;
-        uint32_t bits = bmB[w0 + k];
-        const int base = (int)T0 + ((w0 + k) << 5);
-        while (bits) {
-            const int p = __ffs((int)bits) - 1;
-            bits &= bits - 1;
-            out[off] = base + p;
-            if (AD > 0 && off < aa.cap) s_ids[off] = base + p;
-            ++off;
-        }
-    }
-    if (tid == 0 && (AD == 0 || clog == 0)) nnz[h] = total;
-    MP_STAMP(stamp, 21);
     if (AD == 0) {
+        // ---- stand-alone retrieve: sweep B with contiguous words per thread, block-wide exclusive scan, ascending
+        // emission of the head's list
+        int cnt = 0;
+        int32_t* out = results + h * M;
+        const int nsw = words;
+        const int wpt = (nsw + RT_THREADS - 1) / RT_THREADS;
+        const int w0 = tid * wpt;
+        for (int k = 0; k < wpt; ++k)
+            if (w0 + k < nsw) cnt += __popc(bmB[w0 + k]);
+        int total;
+        int off = block_excl_scan(cnt, s_tmp, total);
+        MP_STAMP(stamp, 20);
+        for (int k = 0; k < wpt; ++k) {
+            if (w0 + k >= nsw) break;
+            uint32_t bits = bmB[w0 + k];
+            const int base = (int)T0 + ((w0 + k) << 5);
+            while (bits) {
+                const int p = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                out[off++] = base + p;
+            }
+        }
+        if (tid == 0) nnz[h] = total;
+        MP_STAMP(stamp, 21);
         MP_STAMP_FLUSH(stamp);
         return;
     }
 
     // ------------------------------------------------------------ fused sparse attention of head h
+    // Every WAVE gathers straight from its own words of bitmap B (round 4).  Wave w owns words [w * wpw, (w + 1) * wpw)
+    // of the member's range (cfg 1: 24 words = 768 tokens, ~12 selected): its lanes read the words, a DPP prefix sum
+    // gives every id its place in a wave-private piece of the LDS stage, and the wave requests the K / V rows of its
+    // ids at once -- no block-wide scan, no emission to HBM and no workgroup barrier between "counted" and the first
+    // row request (1.6 us of the dependent chain until round 3).  The mapping wave -> tokens is fixed, the waves'
+    // states are merged in wave order: results stay deterministic.  Logits (get_score) land in the wave's segment of
+    // the head's score row (column t0 + 32 * w * wpw); the per-wave counts go to wave_cnt, which get_score's
+    // compaction and the hand-off's count (nnz) read.
     constexpr int ADD = AD > 0 ? AD : 64;
     uint16_t* out_h = aa.out + h * ADD;
     int wlen = 0;
     if (WIN && aa.win_kv != nullptr) {
-        wlen = aa.win_len[h];
+        wlen = __builtin_amdgcn_readfirstlane(aa.win_len[h]);
         wlen = wlen < 0 ? 0 : (wlen > aa.win_M ? (int)aa.win_M : wlen);
     }
-    if (clog == 0 && total == 0 && wlen == 0) {
-        attn_head_empty<ADD>(out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
-        MP_STAMP_FLUSH(stamp);
-        return;
-    }
-    __syncthreads();                        // s_ids complete; the spilled list drained (vmcnt) and visible in L2
-    MP_STAMP(stamp, 33);
-    // two instantiations of the sparse fold: the LDS path carries no global load ahead of its gathers
     float m, Z, o0, o1;
     const u32x4 qv = *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADD / 8)) * 4);
-    float* score_h = aa.score ? aa.score + h * M + t0 : nullptr;
     const uint16_t* kv_g = aa.kv + g * M * 2 * ADD;
     const float* kn_g = aa.kn + g * M;
-    auto ids_lds = [&](int j) { return *reinterpret_cast<const u32x4*>(s_ids + j); };
-    auto ids_hbm = [&](int j) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        for (int e = 0; e < 4; ++e)
-            v[e] = ((uint32_t)(j + e) < tlen) ? (uint32_t)__builtin_nontemporal_load(out + j + e) : 0u;
-        return v;
-    };
-    // lists that one round of 16-token steps covers (a member's ~190 ids at cfg 1) take those: twice the waves,
-    // half the rows per wave (head_dim 128; at 64 a 16-token step would be two load instructions).  Measured and
-    // rejected: 16-token steps for the last partial round of a long list (cfg 2: 641 ids = one round of 32-token
-    // steps + 129 ids) -- 37.2 us per layer against 35.6 with HBM saturated.
-    constexpr int SHORT = (ADD == 128) ? 16 : AH_SLICE;
-    const bool short_list = SHORT < AH_SLICE && total <= SHORT * RT_WAVES && !spill;
+    constexpr int SHORT = (ADD == 128) ? 16 : AH_SLICE;      // 16-token steps exist for head_dim 128 only
+    const int wpw = (words + RT_WAVES - 1) / RT_WAVES;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar: everything derived from it stays in SGPRs
+    const int wlo = wave_u * wpw < words ? wave_u * wpw : words;
+    const int whi = wlo + wpw < words ? wlo + wpw : words;
+    const int capw = aa.cap / RT_WAVES;                      // ids of the wave's piece of the stage (256 = 8 full words)
+    int32_t* mylist = s_ids + wave_u * capw;
+    float* score_w = aa.score ? aa.score + h * M + t0 + ((int64_t)wlo << 5) : nullptr;
     AhState st = ah_state_init(lane, ADD / 8);
     const uint16_t* kn_lds = pay ? s_kn : nullptr;
-    if (short_list)
-        attn_head_fold<ADD, RT_WAVES, false, SHORT>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1, ids_lds,
-                                                    score_h, stamp, 0, kn_lds, (int)T0);
-    else if (!spill)
-        attn_head_fold<ADD, RT_WAVES, false, AH_SLICE>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
-                                                       ids_lds, score_h, stamp, 0, kn_lds, (int)T0);
-    else
-        attn_head_fold<ADD, RT_WAVES, false, AH_SLICE>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
-                                                       ids_hbm, score_h, stamp, 0, kn_lds, (int)T0);
+    const float qn_h = s_rn[1];
+    auto ids_own = [&](int j) { return *reinterpret_cast<const u32x4*>(mylist + j); };
+    // Rounds of (stage, fold); with a sampled selection (a few per cent of the tokens) ONE round covers the wave's words.
+    // A round stages whole 64-word chunks while they fit the wave's piece of the stage; a chunk that alone holds more
+    // than 256 ids (dense selections: more than an eighth of 2 048 tokens) is taken in groups of 8 words (<= 256 ids).
+    int done = 0;                                             // wave-uniform: ids folded so far
+    int c0 = wlo, sg = 0;                                     // next chunk, first 8-lane group of it not yet staged
+    for (;;) {
+        int run = 0;                                          // ids staged in this round
+        while (c0 < whi) {
+            const int wi = c0 + lane;
+            uint32_t bits = (wi < whi && (lane >> 3) >= sg) ? bmB[wi] : 0u;
+            int cnt = __popc(bits);
+            int incl = wave_incl_scan(cnt);
+            int tot = __builtin_amdgcn_readlane(incl, 63);
+            MP_STAMP(stamp, 20);                              // this wave's words of bitmap B read and prefix-summed
+            int ngrp = 8 - sg;                                // groups of this chunk staged by this pass
+            if (run + tot > capw) {
+                if (run > 0) break;                           // fold what is staged first
+                // an empty stage and still too many: the leading groups that fit (at least one: 8 words <= 256 ids)
+                // (the running count at the end of every group; nondecreasing, and zero in front of group sg)
+                int last = sg, taken = 0;
+#define MP_GROUP_END(gq, ln)                                                         \
+                {                                                                     \
+                    const int e = __builtin_amdgcn_readlane(incl, ln);                \
+                    if (gq >= sg && e <= capw) {                                      \
+                        last = gq;                                                    \
+                        taken = e;                                                    \
+                    }                                                                 \
+                }
+                MP_GROUP_END(0, 7) MP_GROUP_END(1, 15) MP_GROUP_END(2, 23) MP_GROUP_END(3, 31)
+                MP_GROUP_END(4, 39) MP_GROUP_END(5, 47) MP_GROUP_END(6, 55) MP_GROUP_END(7, 63)
+#undef MP_GROUP_END
+                ngrp = last - sg + 1;
+                if ((lane >> 3) > last) bits = 0u;
+                cnt = __popc(bits);
+                tot = taken;
+            }
+            const int base = (int)T0 + (wi << 5);
+            int off = run + incl - cnt;
+            while (bits) {
+                const int p = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                mylist[off++] = base + p;
+            }
+            run += tot;
+            sg += ngrp;
+            if (sg >= 8) {
+                sg = 0;
+                c0 += 64;
+            } else {
+                break;                                        // a partial chunk fills the round
+            }
+        }
+        if (run == 0) {
+            if (c0 >= whi) break;                             // nothing left
+            continue;                                         // (a partial chunk whose leading groups were empty)
+        }
+        // the wave's own LDS writes, read back by other lanes of the same wave: program order is enough for the
+        // hardware (one wave's LDS accesses execute in order), the fences keep the compiler from moving them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        MP_STAMP(stamp, 33);                                  // the wave's ids are staged
+        float* sc = score_w ? score_w + done : nullptr;
+        // a wave's ~12 ids at cfg 1 are ONE 16-token step (8 row loads in flight); longer lists take 32-token steps.
+        // (The two forms in mutually exclusive branches: a 16-token step for the rest of a longer list, behind the
+        // 32-token loop, kept both forms' constants and addresses live at once and spilled 9-16 vector registers.)
+        if (SHORT < AH_SLICE && run <= SHORT)
+            attn_head_fold<ADD, RT_WAVES, false, SHORT, true>(st, kv_g, kn_g, qv, qn_h, run, M, ha.K, L, 0, 1, ids_own,
+                                                              sc, stamp, 0, kn_lds, (int)T0);
+        else
+            attn_head_fold<ADD, RT_WAVES, false, AH_SLICE, true>(st, kv_g, kn_g, qv, qn_h, run, M, ha.K, L, 0, 1, ids_own,
+                                                                 sc, stamp, 0, kn_lds, (int)T0);
+        done += run;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the stage is rewritten only after these reads
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) s_tmp[wave_u] = done;    // read by wave 0 behind the barrier of attn_head_merge
     if (WIN && wlen > 0) {                  // the static window: dense slices rank, rank + R, ... (k runs from
                                             // `wave` again, so the waves that got no sparse slice are served first)
         auto none = [](int) { return u32x4{0u, 0u, 0u, 0u}; };
@@ -1141,8 +1216,13 @@ __device__ __forceinline__ void lsh_head_body(
     // from here on WAVE 0 alone holds the workgroup's state: one wave needs no workgroup barrier to order its
     // own stores, ticket and loads, and the other fifteen are done
     if (wave != 0) return;
+    // the waves' counts: one LDS read, one store for get_score's compaction, a DPP sum for nnz / the hand-off
+    const int cnt_w = lane < RT_WAVES ? s_tmp[lane] : 0;
+    if (lane < RT_WAVES && aa.wave_cnt != nullptr) aa.wave_cnt[((h << clog) + rank) * RT_WAVES + lane] = cnt_w;
+    const int total = __builtin_amdgcn_readlane(wave_incl_scan(cnt_w), 63);
     if (clog == 0) {
-        attn_head_finalize<ADD>(m, Z, o0, o1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
+        attn_head_finalize<ADD>(m, Z, o0, o1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);   // Z = 0: out = 0, LSE = -inf
+        if (lane == 0) nnz[h] = total;
         MP_STAMP(stamp, 39);
         MP_STAMP_FLUSH(stamp);
         return;
@@ -1319,19 +1399,20 @@ __global__ __launch_bounds__(RT_THREADS, 4) void lsh_decode_kernel(
                                      idbits, ha, aa, stamp);
 }
 
-// The decode kernel leaves member r's selected ids / logits at column r * range_len of the head's row; this
-// moves the R segments of every row down into one contiguous list (get_score's `ind` order).  One workgroup
-// per head; a segment only ever moves to lower addresses, chunk by chunk (read, barrier, write, barrier).
+// The decode kernel leaves the logits of wave w of member r at column r * range_len + w * wave_tokens of the head's
+// score row (wave_cnt[h][r][w] of them); this moves the 16 R segments of every row down into one contiguous list
+// (get_score's `ind` order: ascending token ids).  One workgroup per head; a segment only ever moves to lower
+// addresses, chunk by chunk (read, barrier, write, barrier).
 __global__ __launch_bounds__(1024) void lsh_compact_segments_kernel(uint32_t* __restrict__ rows,
-                                                                   const int* __restrict__ part_cnt, int R,
-                                                                   int range_len, int64_t M) {
+                                                                   const int* __restrict__ wave_cnt, int R,
+                                                                   int range_len, int wave_tokens, int64_t M) {
     const int64_t h = blockIdx.x;
     uint32_t* row = rows + h * M;
-    int off = part_cnt[h * 8] & 0xffffff;   // bits 24+ : the XCD a member reported (same-XCD hand-off)
-    for (int r = 1; r < R; ++r) {
-        const int cnt = part_cnt[h * 8 + r] & 0xffffff;
-        const int64_t src = (int64_t)r * range_len;
-        if (off != src) {
+    int off = 0;
+    for (int seg = 0; seg < R * RT_WAVES; ++seg) {
+        const int cnt = wave_cnt[h * R * RT_WAVES + seg];
+        const int64_t src = (int64_t)(seg / RT_WAVES) * range_len + (int64_t)(seg % RT_WAVES) * wave_tokens;
+        if (cnt > 0 && off != src) {
             for (int base = 0; base < cnt; base += blockDim.x) {
                 const int j = base + threadIdx.x;
                 const uint32_t v = (j < cnt) ? row[src + j] : 0u;
@@ -1366,7 +1447,9 @@ __global__ __launch_bounds__(256) void lsh_mask_kernel(
         const int bx = rec[0], by = rec[R];
         const int32_t* src = table + (g * L + l) * M;
         for (int j = bx + threadIdx.x; j < by; j += blockDim.x) {
-            const int64_t t = (int64_t)((uint32_t)src[j] & idmask);
+            const int32_t w = src[j];
+            if (w == -1) continue;                                   // not an entry (as the retrieve's apply())
+            const int64_t t = (int64_t)((uint32_t)w & idmask);
             if (t < M && row[t] < 2) row[t] = row[t] + 1;
         }
         __syncthreads();
@@ -1392,8 +1475,13 @@ struct DeviceOnce {
     }
 };
 
-// dynamic LDS a retrieve / decode workgroup may ask for: the CU's 160 KiB minus the static 512-byte stamp buffer (+ slack)
+// dynamic LDS a retrieve / decode workgroup may ask for: the CU's 160 KiB -- minus, in the -DMP_STAMPS=1 measurement
+// build only, the static 512-byte stamp buffer (+ slack)
+#if MP_STAMPS
 constexpr size_t RT_LDS_DYN_MAX = 160u * 1024u - 1024u;
+#else
+constexpr size_t RT_LDS_DYN_MAX = 160u * 1024u;
+#endif
 size_t lsh_lds_limit() { return RT_LDS_DYN_MAX; }
 
 // dynamic LDS of the retrieve body for a workgroup that owns `tokens` tokens
@@ -1403,6 +1491,8 @@ static size_t body_lds_bytes(int64_t tokens, int L) {
     return (size_t)(2 * ((tokens + 31) / 32) + 2 * Lpad + RT_TAIL_CAP + 64 + 140 + (16 * L + 31) / 32 + 2 * RT_WAVES + 4) * 4;
 }
 size_t retrieve_lds_bytes(int64_t M, int L) { return body_lds_bytes(M, L); }
+// the hash-only launch (mp_simhash_query on a handful of rows) keeps the sign bits of all K*L planes in LDS
+bool lsh_hash_only_supported(int L) { return body_lds_bytes(0, L) <= RT_LDS_DYN_MAX; }
 
 // tokens per range for a head split over R workgroups (multiple of 32: whole bitmap words)
 int lsh_range_len(int64_t M, int R) { return (int)((((M + R - 1) / R) + 31) & ~(int64_t)31); }
@@ -1641,7 +1731,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                              const uint16_t* Wk, const float* wnorm, int D, int K, int KLpad,
                              int32_t* codes_out, float* qnorm_out, int32_t* results, int32_t* nnz,
                              const uint16_t* kv, const float* kn, float* part_o, float2* part_ml, int* part_cnt,
-                             int* head_cnt, uint16_t* out, float* mve, float2* head_mz, const int32_t* slots,
+                             int* wave_cnt, int* head_cnt, uint16_t* out, float* mve, float2* head_mz, const int32_t* slots,
                              float* score, int* err, int maxs, int R, bool same_xcd, const uint16_t* win_kv,
                              const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
                              bool codes_given, unsigned long long* xw, unsigned int* xseq, int xwords, int xmode,
@@ -1662,7 +1752,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     // cluster share an XCD (sx) and every unit of 64 planes finds a wave (K*L <= 1024 R)
     const bool split_hash = xmode != 0 && sx && xw != nullptr && xseq != nullptr && !codes_given &&
                             ((K * L + 63) / 64) <= (RT_WAVES << clog) && 2 * ((K * L + 63) / 64) <= xwords;
-    AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, slots, score, err, BH, BHp, maxs,
+    AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, wave_cnt, head_cnt, out, mve, head_mz, slots, score, err, BH, BHp, maxs,
                    DECODE_ID_CAP, clog, sx ? 1 : 0, split_hash ? xw : nullptr, split_hash ? xseq : nullptr, xwords, xmode, nullptr, idbits_dev, nullptr, nullptr,
                    win_kv, win_len, win_M};
     const dim3 grid((unsigned)BHp << clog);
@@ -1703,10 +1793,12 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_lsh_compact(uint32_t* rows, const int* part_cnt, int BH, int R, int64_t M, hipStream_t st) {
-    if (R <= 1) return hipSuccess;
-    hipLaunchKernelGGL(lsh_compact_segments_kernel, dim3(BH), dim3(1024), 0, st, rows, part_cnt, R,
-                       lsh_range_len(M, R), M);
+// tokens a wave of a decode workgroup owns (the last waves of a range may own fewer, or none)
+int lsh_wave_tokens(int64_t M, int R) { return ((lsh_range_len(M, R) / 32 + RT_WAVES - 1) / RT_WAVES) * 32; }
+
+hipError_t launch_lsh_compact(uint32_t* rows, const int* wave_cnt, int BH, int R, int64_t M, hipStream_t st) {
+    hipLaunchKernelGGL(lsh_compact_segments_kernel, dim3(BH), dim3(1024), 0, st, rows, wave_cnt, R,
+                       lsh_range_len(M, R), lsh_wave_tokens(M, R), M);
     return hipGetLastError();
 }
 

@@ -95,6 +95,16 @@ def gather_outputs(local: torch.Tensor, shard: Shard, batch_size: int, num_atten
     local = local.reshape(shard.local_batch, shard.local_heads, D)
     if dist is None:
         return local
+    # the shard describes the process group it was cut for: a one-rank shard inside a larger group owns everything
+    # already, and a group of another size cannot be gathered with this shard's block arithmetic
+    if shard.world_size != dist.get_world_size():
+        if shard.world_size == 1:
+            return local
+        raise ValueError(f"gather_outputs: shard of {shard.world_size} ranks in a process group of {dist.get_world_size()}")
+    # (a ONE-rank group still runs the collective on RCCL -- tests/test_gpu_rccl.py; gloo has no all_gather of
+    # device tensors, so there a single rank keeps its block)
+    if shard.world_size == 1 and local.is_cuda and dist.get_backend() != "nccl":
+        return local
     full = torch.zeros((batch_size, num_attention_heads, D), dtype=local.dtype, device=local.device)
     # ragged batch blocks: gather through a padded buffer of the largest block
     if shard.mode == "batch":

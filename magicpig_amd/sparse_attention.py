@@ -138,6 +138,11 @@ class SparseAttentionServer:
         L.check(L.lib().mp_attn_append_centred(self._h, layer_id, L.ptr(k), L.ptr(v), L.ptr(centre), L.ptr(pos),
                                                pos_delta, L.current_stream(k, self._device)))
 
+    def invalidate_norms(self, layer_id: int, request_id: int) -> None:
+        """After writing key norms through the get_key_norm() view: the request's norms get a new version, so that the
+        one-launch decode packs them into its LSH table words again (include/magicpig_hip.h: mp_attn_invalidate_norms)."""
+        L.check(L.lib().mp_attn_invalidate_norms(self._h, layer_id, request_id, L.current_stream(device=self._device)))
+
     def check(self) -> None:
         """Raise if a device-side validation failed since the last check (append past max_length)."""
         L.check(L.lib().mp_attn_check(self._h, L.current_stream(device=self._device)))

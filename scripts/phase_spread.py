@@ -55,9 +55,9 @@ for kv in os.environ.get("MP_OPTIONS", "").split(","):      # e.g. MP_OPTIONS=de
         L.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 L.set_option("stamp_stride", STRIDE)
 L.check(L.lib().mp_debug_set_stamp_buffer(L.ptr(stamp)))
-slots = [16, 28, 22, 23, 27, 42, 43, 44, 45, 17, 19, 20, 21, 33, 34, 35, 36, 37, 40, 41, 38, 39]
+slots = [16, 28, 22, 23, 27, 42, 43, 44, 45, 17, 19, 20, 33, 34, 35, 36, 37, 40, 41, 38, 39]
 names = ["start", "q row in", "normalised", "own unit", "hashed", "slots issued", "first slot in", "last slot in",
-         "wave counted", "pieces in", "stream done", "scanned", "emitted", "ids staged", "gathers issued",
+         "wave counted", "pieces in", "stream done", "own words scanned", "ids staged", "gathers issued",
          "qk", "transform", "pv", "states met", "stores acked", "ticket", "end (merger)"]
 acc = []
 for r in range(reps):

@@ -19,7 +19,7 @@ def test_header_declares_the_reference_surface():
     syms = declared_symbols()
     for must in ("mp_lsh_alloc", "mp_lsh_fill", "mp_lsh_batch_retrieve", "mp_lsh_clear", "mp_lsh_get_mask",
                  "mp_attn_alloc", "mp_attn_fill", "mp_attn_sparse", "mp_attn_full", "mp_attn_clear",
-                 "mp_attn_get_kv", "mp_attn_get_key_norm", "mp_attn_get_score", "mp_simhash_query",
+                 "mp_attn_get_kv", "mp_attn_get_key_norm", "mp_attn_get_score", "mp_attn_invalidate_norms", "mp_simhash_query",
                  "mp_decode_sparse_layer", "mp_merge_state"):
         assert must in syms
 

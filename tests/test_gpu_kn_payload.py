@@ -184,6 +184,72 @@ def test_captured_decodes_follow_the_state_of_their_replay(mp):
     server.collect_nnz = True
 
 
+def test_norms_written_outside_a_fill_are_never_read_from_stale_table_words(mp):
+    """mp_attn_append* and the writable get_key_norm() view change norms without a fill.  An append marks
+    the layer's norms "changed outside a fill" on the device, in stream order -- also inside a replayed graph: the decode
+    kernel then reads the norms per token (result of the option switched off) until the next fill.  A write through the
+    view followed by invalidate_norms() is packed again by the next decode."""
+    import magicpig_amd._lib as L
+    B, H, Hkv, n, M, D, K, Lt = 1, 8, 2, 5000, 5120, 128, 8, 60
+    server, (keys, kns, vals, W, qb) = _server(mp, B, H, Hkv, n, M, D, K, Lt, 8)
+    srv = server.attn_server
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.randn((B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16)
+    base = _decode(server, q)                                       # packs the norms into the table words
+    assert _packed(server, n=n)
+
+    def both():
+        got = _decode(server, q)
+        L.set_option("decode_kn_payload", 0)
+        want = _decode(server, q)
+        L.set_option("decode_kn_payload", 1)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+        return got
+
+    # -- an append INTO the indexed range: a selected token's key (and norm) is replaced by a 3x longer one
+    probs = srv.get_score().reshape(B * H, M)
+    codes, _ = server.hasher.query(q.reshape(B * H, D))
+    res = torch.zeros((B * H, M), dtype=torch.int32, device="cuda")
+    nz = torch.zeros((B * H,), dtype=torch.int32, device="cuda")
+    server.lsh_retriever.batch_retrieve(0, codes, res, nz)
+    assert int(nz[0]) > 0
+    tok = int(res[0, 0])                                            # selected by head 0 (KV group 0)
+    kc = srv.get_key_cache(0)[:, :, tok].clone()                    # [B, Hkv, D]
+    vc = srv.get_value_cache(0)[:, :, tok].clone()
+    pos = torch.full((B,), tok, dtype=torch.int32, device="cuda")
+    srv.append(0, (kc.float() * 3).to(torch.bfloat16), vc, pos)
+    after = both()
+    assert not torch.equal(after[0][0, 0], base[0][0, 0])           # the new key (norm x 3) is what the kernel saw
+    # -- the same under graph replay: append + decode captured once, the appended key changes between replays
+    kbuf = (kc.float() * 3).to(torch.bfloat16).clone()
+    server.collect_nnz = False
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        srv.append(0, kbuf, vc, pos)
+        server.decode(q, 0)
+    for scale in (0.5, 2.0):
+        kbuf.copy_((kc.float() * scale).to(torch.bfloat16))
+        graph.replay()
+        torch.cuda.synchronize()
+        o_graph = server.output.clone()
+        L.set_option("decode_kn_payload", 0)
+        want = _decode(server, q)[0].reshape(-1, D)
+        L.set_option("decode_kn_payload", 1)
+        assert torch.equal(o_graph, want)
+    server.collect_nnz = True
+    # -- a refill brings the payload back
+    srv.fill(0, 0, bf16_t(keys[0], "cuda"), bf16_t(vals[0], "cuda"), torch.from_numpy(kns[0]).cuda())
+    again = both()
+    assert torch.equal(again[0], base[0])
+    # -- the writable view + invalidate_norms: doubled norms of KV group 1 reach the next decode, through the payload
+    srv.get_key_norm(0)[0, 1].mul_(2.0)
+    srv.invalidate_norms(0, 0)
+    got = both()
+    G = H // Hkv
+    assert torch.equal(got[0][0, :G], base[0][0, :G]) and not torch.equal(got[0][0, G:], base[0][0, G:])
+
+
 def test_a_layer_whose_ids_outgrow_17_bits_goes_back_to_plain_ids(mp):
     """max_length > 2^17 (BASELINE cfg 4: 131 264): the words carry payloads while every id of the layer is below
     2^17; the first build / fill with a wider id strips the layer's other requests' payloads and the layer stays plain
