@@ -99,7 +99,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--config", default="cfg1", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="cfg1", choices=sorted(CONFIGS) + ["custom"])
     ap.add_argument("--data", default="randn", choices=sorted(DATA),
                     help="synthetic key distribution: randn (isotropic), clustered (anisotropic clusters + low-rank "
                          "component, ~2 %% selected at cfg 1), skewed (stress)")
@@ -109,6 +109,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-mode", action="store_true", help="skip the untimed host-buffer (unchanged caller) leg")
+    ap.add_argument("--no-clustered-leg", action="store_true",
+                    help="skip the second workload of the default run (clustered keys + heavy-hitter queries, the README's "
+                         "~2 %% sampling rate), reported as value_clustered next to the headline value")
     ap.add_argument("--host-register-leg", action="store_true",
                     help="host-buffer leg: also time the opt-in host_register mode (hipHostRegister of `results`)")
     ap.add_argument("--cpu-steps", type=int, default=8192,
@@ -116,6 +119,15 @@ def parse():
                          "~5 s of CPU work at cfg 1, ~20 s at cfg 2")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # tests: control flow on CPU / gloo
+    ap.add_argument("--config-json", default=None,
+                    help="tests: a workload shape as JSON (the keys of a CONFIGS entry), used as --config custom")
+    ap.add_argument("--emulate-rank", default=None,
+                    help="R/W: ONE process that serves the units rank R of W would own (no process group): what the "
+                         "multi-GPU tests compare a real rank's outputs with")
+    ap.add_argument("--distinct-layers", type=int, default=0,
+                    help="DIAGNOSTIC (not a valid bench line): the step's launches cycle over only this many of the "
+                         "model's sparse layers -- the HBM footprint a step touches shrinks (address translation, "
+                         "MALL) while launch count and shapes stay")
     ap.add_argument("--table-build", default="counting", choices=["sort", "counting"])
     ap.add_argument("--shard", default="batch", choices=["batch", "head"],
                     help="batch: every rank serves its own B requests (weak scaling); head: the kv heads of the "
@@ -138,7 +150,12 @@ def parse():
     ap.add_argument("--end-to-end", action="store_true",
                     help="examples/bench.py-style full decode step with synthetic weights (SURVEY 8f-3) "
                          "instead of the hot path alone")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config_json:
+        CONFIGS["custom"] = dict(json.loads(args.config_json))
+        CONFIGS["custom"]["dense"] = tuple(CONFIGS["custom"].get("dense", ()))
+        args.config = "custom"
+    return args
 
 
 # ---------------------------------------------------------------------------- CPU baseline worker
@@ -449,13 +466,24 @@ def main():
     if args.end_to_end:
         return end_to_end(args, cfg, rank, world, dev, dist)
     B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
+    # which units (request, kv head) this process serves: by its rank in the process group, or -- --emulate-rank R/W,
+    # one process, no group -- those rank R of W would serve
+    urank, uworld = rank, world
+    if args.emulate_rank:
+        urank, uworld = (int(x) for x in args.emulate_rank.split("/"))
+        assert world == 1 and 0 <= urank < uworld
     shard = None
     if args.shard == "head":
         # the model's heads over the ranks (evaluations/RULER/pred/attnserver_dist.py:252-254): rank r owns kv heads
         # [r * Hkv_full / world, ...) and their query heads; nothing is exchanged inside the path
         H_full, Hkv_full = cfg.get("H_full", H), cfg.get("Hkv_full", Hkv)
-        shard = sharding.partition(B, H_full, Hkv_full, world, rank, mode="head")
+        shard = sharding.partition(B, H_full, Hkv_full, uworld, urank, mode="head")
         H, Hkv = shard.local_heads, shard.local_kv_heads
+    # global ids of the units: synthetic K/V and queries are drawn PER UNIT from its global id, so a unit's data does
+    # not depend on how many ranks share the work (a rank's outputs equal the single-process outputs of the same units)
+    G_heads = H // Hkv
+    g_requests = list(range(B)) if shard is not None else list(range(urank * B, (urank + 1) * B))
+    g_kv_heads = list(shard.kv_heads) if shard is not None else list(range(Hkv))
     sparse_layers = [i for i in range(cfg["layers"]) if i not in cfg["dense"]]
     NL = len(sparse_layers)
     BH = B * H
@@ -465,38 +493,50 @@ def main():
     gen0 = torch.Generator(device="cpu").manual_seed(7 + rank)
     hash_func = torch.randn((D, K * Lt), generator=gen0, dtype=torch.float32).to(torch.bfloat16).to(dev)
     hash_func = sharding.sync_hash_func(hash_func, src=0)
-    server = mp.LSHSparseAttnServer(NL, H, Hkv, D, K=K, L=Lt, batch_size=B, max_length=M,
-                                    dense_layers=(), device=str(dev), hash_func=hash_func,
-                                    table_build=args.table_build)
-    t_setup = time.time()
-    for li in range(NL):
-        for b in range(B):
-            gen = torch.Generator(device=dev).manual_seed(1000 * (rank + 1) + 37 * li + b)
-            kc, vc = synth_kv(args.data, P, Hkv, D, dev, gen)
-            server.fill(li, b, kc, vc, P)
-            server.build_table(li, b, P)
-            del kc, vc
-    torch.cuda.synchronize()
-    t_setup = time.time() - t_setup
-
     NQ = 16
-    gen = torch.Generator(device=dev).manual_seed(2000 + rank)
-    qs = torch.randn((NQ, NL, B, H, 1, D), device=dev, dtype=torch.float32, generator=gen)
-    heavy = args.queries == "heavy" or (args.queries == "auto" and args.data != "randn")
-    if heavy:   # every query is pulled toward one (centred) key of its kv group: q <- 0.5 q + 3 k_j
-        G = H // Hkv
-        bi = torch.arange(B, device=dev)[None, :, None].expand(NQ, B, H)
-        gi = (torch.arange(H, device=dev) // G)[None, None, :].expand(NQ, B, H)
+
+    def build_workload(data, queries):
+        """A server holding all sparse layers of the model shape on `data` keys, and NQ steps' worth of queries."""
+        srv = mp.LSHSparseAttnServer(NL, H, Hkv, D, K=K, L=Lt, batch_size=B, max_length=M,
+                                     dense_layers=(), device=str(dev), hash_func=hash_func,
+                                     table_build=args.table_build)
+        t_s = time.time()
         for li in range(NL):
-            kc = server.attn_server.get_key_cache(li)                              # [B, Hkv, M, D] centred keys
-            j = torch.randint(0, n, (NQ, B, H), device=dev, generator=gen)
-            qs[:, li, :, :, 0] = 0.5 * qs[:, li, :, :, 0] + 3.0 * kc[bi, gi, j].float()
-    qs = qs.to(torch.bfloat16)
+            for b in range(B):
+                ks, vs = [], []
+                for gkv in g_kv_heads:          # one (request, kv head) unit at a time, seeded by its GLOBAL id
+                    gen_kv = torch.Generator(device=dev).manual_seed(1000 + 1_000_003 * li + 10_007 * g_requests[b] + gkv)
+                    k1, v1 = synth_kv(data, P, 1, D, dev, gen_kv)
+                    ks.append(k1)
+                    vs.append(v1)
+                kc, vc = torch.cat(ks, dim=1), torch.cat(vs, dim=1)
+                srv.fill(li, b, kc, vc, P)
+                srv.build_table(li, b, P)
+                del kc, vc, ks, vs
+        torch.cuda.synchronize()
+        t_s = time.time() - t_s
+        q = torch.empty((NQ, NL, B, H, 1, D), device=dev, dtype=torch.float32)
+        hv = queries == "heavy" or (queries == "auto" and data != "randn")
+        for b in range(B):
+            for hl in range(H):                 # one query head of one request at a time, seeded by its GLOBAL id
+                gh = g_kv_heads[hl // G_heads] * G_heads + hl % G_heads
+                gen_q = torch.Generator(device=dev).manual_seed(2000 + 100_003 * g_requests[b] + gh)
+                q[:, :, b, hl, 0] = torch.randn((NQ, NL, D), device=dev, dtype=torch.float32, generator=gen_q)
+                if hv:   # pulled toward one (centred) key of its kv group: q <- 0.5 q + 3 k_j
+                    j = torch.randint(0, n, (NQ, NL), device=dev, generator=gen_q)
+                    for li in range(NL):
+                        kc = srv.attn_server.get_key_cache(li)                     # [B, Hkv, M, D] centred keys
+                        q[:, li, b, hl, 0] = 0.5 * q[:, li, b, hl, 0] + 3.0 * kc[b, hl // G_heads, j[:, li]].float()
+        return srv, q.to(torch.bfloat16), hv, t_s
+
+    server, qs, heavy, t_setup = build_workload(args.data, args.queries)
     q_static = qs[0].clone()
+
+    ND = args.distinct_layers if args.distinct_layers > 0 else NL
 
     def step():
         for li in range(NL):
-            server.decode(q_static[li], li)
+            server.decode(q_static[li], li % ND)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -572,6 +612,16 @@ def main():
         gathered = {"allgather_us": (time.perf_counter() - t_g) * 1e6, "shape": list(full.shape),
                     "checksum": int(full.view(torch.int16).to(torch.int64).sum().item())}
 
+    # per-rank checksum of the last layer's outputs + counts on step 0's queries, gathered from every rank: what the
+    # multi-GPU tests compare with single-process runs of the same units (--emulate-rank)
+    q_static.copy_(qs[0])
+    server.collect_nnz = True
+    o_chk, _ = server.decode(q_static[NL - 1], NL - 1)
+    torch.cuda.synchronize()
+    my_sum = int(o_chk.reshape(-1).view(torch.int16).to(torch.int64).sum().item()) * 1_000_003 + int(server.nnz.sum().item())
+    server.collect_nnz = False
+    rank_checksums = sharding.gather_scalars(my_sum, device=dev)
+
     # ---- roofline leg.  A sparse layer is ONE launch (lsh_decode_kernel: hash -> retrieve -> attention),
     # so the dominant kernel is the step itself: its average duration is taken from HIP events recorded
     # on the launch stream around back-to-back launches (graph replays when the step is captured), its
@@ -637,6 +687,9 @@ def main():
                    "launch": "eager" if graph is None else "hipGraph",
                    "process_group": None if dist is None else f"{dist.get_backend()} x{dist.get_world_size()}"},
         "sparse_attn_us_per_layer": us_per_layer,
+        "rank_checksums": rank_checksums,
+        **({"emulated_rank": args.emulate_rank} if args.emulate_rank else {}),
+        **({"DIAGNOSTIC_distinct_layers": ND} if ND != NL else {}),
         "observed": {"nnz_per_head": nnz_mean, "candidates_per_head": cand_mean,
                      "selected_fraction": nnz_mean / n, "nnz_max_head": float(nnz_all.max()),
                      "probed_pieces": piece_stats, "key_distribution": args.data,
@@ -678,6 +731,64 @@ def main():
         except Exception as e:  # the GPU number must still be reported
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
                                    "sample": f"failed: {e!r}"[:300]}
+    # ---- second workload in the same line: clustered keys + heavy-hitter queries, the README's
+    # ~2 % sampling rate -- randn keys are the easiest case SimHash can see.  Same model shape, same loop, after the
+    # headline region and its legs; the first workload's HBM is released first.
+    if rank == 0 and world == 1 and shard is None and args.data == "randn" and not args.no_clustered_leg:
+        try:
+            del graph
+            server = None
+            torch.cuda.empty_cache()
+            srv2, qs2, _, _ = build_workload("clustered", "auto")
+            q2 = qs2[0].clone()
+            srv2.collect_nnz = True
+            nz2 = []
+            for li in range(NL):
+                srv2.decode(q2[li], li)
+                nz2.append(srv2.nnz.clone())
+            torch.cuda.synchronize()
+            nz2 = torch.stack(nz2).float()
+            srv2.collect_nnz = False
+
+            def step2():
+                for li in range(NL):
+                    srv2.decode(q2[li], li)
+
+            g2 = None
+            if not args.no_graph:
+                s2 = torch.cuda.Stream()
+                s2.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s2):
+                    step2()
+                torch.cuda.current_stream().wait_stream(s2)
+                torch.cuda.synchronize()
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    step2()
+
+            def run2(k0, count):
+                for i in range(count):
+                    q2.copy_(qs2[(k0 + i) % NQ])
+                    if g2 is not None:
+                        g2.replay()
+                    else:
+                        step2()
+
+            run2(0, args.warmup)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run2(args.warmup, args.steps)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            srv2.attn_server.check()
+            out["value_clustered"] = B * args.steps / dt2
+            out["sparse_attn_us_per_layer_clustered"] = dt2 / args.steps * 1e6 / NL
+            out["observed_clustered"] = {"nnz_per_head": float(nz2.mean()), "selected_fraction": float(nz2.mean()) / n,
+                                         "nnz_max_head": float(nz2.max()), "key_distribution": "clustered",
+                                         "queries": "heavy", "steps": args.steps, "warmup": args.warmup}
+        except Exception as e:  # the headline number must still be reported
+            out["value_clustered"] = None
+            out["observed_clustered"] = {"failed": f"{e!r}"[:300]}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -100,6 +100,14 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
  * ids inside every bucket). */
 int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes, int64_t n,
                  int mem, mp_stream_t stream);
+/* mp_lsh_build for a caller that has ALREADY filled the attention store of (layer_id, request_id) -- the reference's
+ * order: key norms and K/V at models/attnserver.py:146, 174, the tables at :178-193.  The sort then writes every table
+ * word as  id | bf16 key norm << 17  itself (see mp_lsh_get_id_bits) and the direct slots are built once from the
+ * packed words, so the first mp_decode_* call of the layer has nothing left to pack.  Same tables, same results as
+ * mp_lsh_build; falls back to plain ids where the payload does not apply (an id >= 2^17 in the layer, norms changed by
+ * an append, K >= 14).  `attn` must agree with `h` on device, batch size, kv heads and max_length. */
+int mp_lsh_build_with_norms(mp_lsh_t* h, mp_attn_t* attn, int layer_id, int request_id, const int16_t* codes,
+                            int64_t n, int mem, mp_stream_t stream);
 /* LSH::batch_retrieve, lsh.cc:210-288.  query int32 [B*H, L]; results int32 [B*H, M] (first
  * nnz[h] entries valid, ASCENDING token ids; the rest untouched); nnz int32 [B*H]. */
 int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32_t* results,

@@ -59,6 +59,7 @@ def lib() -> C.CDLL:
         "mp_lsh_alloc": ([p, i32, i32, i32, i32, i32, i32, i32], i32),
         "mp_lsh_fill": ([p, i32, i32, p, p, i64, i32, p], i32),
         "mp_lsh_build": ([p, i32, i32, p, i64, i32, p], i32),
+        "mp_lsh_build_with_norms": ([p, p, i32, i32, p, i64, i32, p], i32),
         "mp_lsh_batch_retrieve": ([p, i32, p, p, p, i32, p], i32),
         "mp_lsh_clear": ([p, p], i32),
         "mp_lsh_get_mask": ([p, p, i32, p], i32),

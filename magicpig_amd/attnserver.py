@@ -66,6 +66,7 @@ class LSHSparseAttnServer:
         self.avg_k = [torch.zeros(batch_size, num_key_value_heads, 1, head_dim, device=self.device,
                                   dtype=dtype) for _ in range(num_layers)]
         self.hash_code_buffer = None
+        self._filled = {}           # (layer, request) slots whose store was filled by fill(): build_table packs their norms
         self.output = torch.zeros((BH, head_dim), dtype=torch.bfloat16, device=self.device)
         self.max_value_expsum = torch.zeros((2, BH), dtype=torch.float32, device=self.device)
         self.nnz = torch.zeros((BH,), dtype=torch.int32, device=self.device)
@@ -92,6 +93,7 @@ class LSHSparseAttnServer:
         # -- three passes over the KV cache, no transposed / centred intermediates
         avg_k, self.hash_code_buffer = self.attn_server.fill_offload(
             layer_idx, request_id, key_cache, value_cache, seq_len, s, l, hasher=self.hasher)
+        self._filled[(layer_idx, request_id)] = True
         self.avg_k[layer_idx][request_id] = avg_k
         # sink + local tokens -> the static window, centred with the same avg_k (:126-153): a few dozen rows
         if s + l > 0:
@@ -108,7 +110,10 @@ class LSHSparseAttnServer:
         'counting' uses the device counting sort (LSH.fastfill)."""
         codes = self.hash_code_buffer
         if self.table_build == "counting":
-            self.lsh_retriever.fastfill(layer_idx, request_id, codes)
+            # the store of (layer, request) was filled first (fill() above, as models/attnserver.py:174 precedes :178):
+            # the sort packs the key norms into the table words in the same pass
+            self.lsh_retriever.fastfill(layer_idx, request_id, codes,
+                                        self.attn_server if self._filled.get((layer_idx, request_id)) else None)
         else:
             sorted_values, sorted_indices = codes.sort(dim=-1)
             self.lsh_retriever.fill(layer_idx, request_id, sorted_values.contiguous(),
@@ -244,6 +249,7 @@ class LSHSparseAttnServer:
         self.kv_last_page_len.zero_()
         self._window_rows = [0] * self.batch_size
         self.window_nnz.zero_()
+        self._filled = {}
         self.lsh_retriever.clear()
         self.attn_server.clear()
         self.window_server.clear()

@@ -36,9 +36,9 @@ hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, 
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
                            int32_t*, int*, hipStream_t);
 hipError_t launch_lsh_unsort(const int16_t*, const int32_t*, int, int64_t, int16_t*, int*, hipStream_t);
-hipError_t launch_lsh_subbounds(const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
-hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int, int32_t*, int32_t*, int*,
-                            hipStream_t);
+hipError_t launch_lsh_subbounds(const int32_t*, int32_t*, int, int, int, int64_t, int, hipStream_t);
+hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int, int32_t*, int32_t*, int*, const float*, int,
+                            int, int*, bool*, hipStream_t);
 hipError_t launch_lsh_retrieve(const int32_t*, const int32_t*, const int32_t*, int32_t*, int32_t*, int,
                                int, int, int, int64_t, int, const int*, hipStream_t);
 hipError_t launch_lsh_attach_norms(int32_t*, const float*, int, int, int64_t, int, int*, hipStream_t);
@@ -662,13 +662,14 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
         MP_HIP_CHECK(tok.alloc((size_t)rows * n * 2));
         MP_HIP_CHECK(hipMemsetAsync(tok.p, 0xff, (size_t)rows * n * 2, st));      // code -1: a token no id named
         MP_HIP_CHECK(launch_lsh_unsort((const int16_t*)c, (const int32_t*)i, rows, n, tok.as<int16_t>(), h->err, st));
-        MP_HIP_CHECK(launch_lsh_build(tok.as<int16_t>(), rows, n, h->NB, h->M, h->R, b, t, h->err, st));
+        MP_HIP_CHECK(launch_lsh_build(tok.as<int16_t>(), rows, n, h->NB, h->M, h->R, b, t, h->err, nullptr, h->L, 0,
+                                      nullptr, nullptr, st));
         // an id outside [0, n) is flagged by the unsort, a token missing from the id list shows up as code -1
         if (lsh_read_err(h, st, "mp_lsh_fill") != MP_OK)
             return fail(MP_ERR_DATA, "mp_lsh_fill: a bucket's ids do not ascend (unstable sort) and the ids of a row are "
                                      "not a permutation of [0, n): the rows cannot be re-sorted on device");
     }
-    MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, st));
+    MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, 0, st));
     if (!h->slots.empty())
         MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * 32, rows,
                                       h->NB, h->R, h->M, st));
@@ -676,28 +677,13 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
     return MP_OK;
 }
 
+// shared by mp_lsh_build (attn == nullptr: plain ids) and mp_lsh_build_with_norms
+static int lsh_build_entry(mp_lsh_t* h, mp_attn_t* attn, int layer_id, int request_id, const int16_t* codes, int64_t n,
+                           int mem, hipStream_t st, const char* who);
+
 int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes, int64_t n,
                  int mem, mp_stream_t stream) {
-    MP_ON_DEVICE(h);
-    int rc = lsh_check_slot(h, layer_id, request_id, n, "mp_lsh_build");
-    if (rc) return rc;
-    MP_REQUIRE(codes, MP_ERR_INVALID, "mp_lsh_build: null argument");
-    hipStream_t st = (hipStream_t)stream;
-    const int rows = h->Hkv * h->L;
-    DevBuf dc;
-    const void* c = nullptr;
-    rc = stage_in(codes, (size_t)rows * n * 2, mem, dc, &c);
-    if (rc) return rc;
-    int32_t* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB * (h->R + 1);
-    int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
-    if ((rc = lsh_set_version(h, layer_id, request_id, 0, st)) != MP_OK) return rc;   // the rows are rewritten with plain ids
-    if (n > (1 << 17) && (rc = lsh_widen(h, layer_id, request_id, st)) != MP_OK) return rc;
-    MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, h->R, b, t, h->err, st));
-    MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, st));
-    if (!h->slots.empty())
-        MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * 32, rows,
-                                      h->NB, h->R, h->M, st));
-    return lsh_read_err(h, st, "mp_lsh_build");
+    return lsh_build_entry(h, nullptr, layer_id, request_id, codes, n, mem, (hipStream_t)stream, "mp_lsh_build");
 }
 
 int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32_t* results,
@@ -1355,6 +1341,55 @@ int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream) {
     }
     *score_dev = h->score;
     return MP_OK;
+}
+
+// =================================================================== table build (with the store's norms)
+
+static int lsh_build_entry(mp_lsh_t* h, mp_attn_t* attn, int layer_id, int request_id, const int16_t* codes, int64_t n,
+                           int mem, hipStream_t st, const char* who) {
+    MP_ON_DEVICE(h);
+    int rc = lsh_check_slot(h, layer_id, request_id, n, who);
+    if (rc) return rc;
+    MP_REQUIRE(codes, MP_ERR_INVALID, std::string(who) + ": null argument");
+    const int rows = h->Hkv * h->L;
+    DevBuf dc;
+    const void* c = nullptr;
+    rc = stage_in(codes, (size_t)rows * n * 2, mem, dc, &c);
+    if (rc) return rc;
+    int32_t* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB * (h->R + 1);
+    int32_t* t = h->table[layer_id] + (size_t)request_id * rows * h->M;
+    if ((rc = lsh_set_version(h, layer_id, request_id, 0, st)) != MP_OK) return rc;   // the rows are being rewritten
+    if (n > (1 << 17) && (rc = lsh_widen(h, layer_id, request_id, st)) != MP_OK) return rc;
+    // Packed build: the store already holds this request's key norms (the reference's order: norms and K/V at
+    // models/attnserver.py:146, 174, the tables at :178-193) -> the sort writes  id | norm << 17  itself, the direct slots
+    // are built ONCE from the packed words, and the first decode of the layer finds nothing to do (round 3: a second
+    // sweep over the table + a second build of the slots, +1.4 ms per layer at cfg 1 and a first-token latency spike).
+    const float* kn = nullptr;
+    int* flag = h->pay_bad + ((size_t)layer_id * h->B + request_id) * h->Hkv;
+    uint32_t ver = 0;
+    if (attn != nullptr) {
+        MP_REQUIRE(attn->allocated && attn->device == h->device && attn->B == h->B && attn->Hkv == h->Hkv &&
+                       attn->M == h->M && layer_id < attn->layers,
+                   MP_ERR_INVALID, std::string(who) + ": the attention store disagrees on device / B / Hkv / max_length / layers");
+        ver = attn->kn_ver[layer_id][request_id];
+        if (h->idbits_of[layer_id] != 0 && ver != KN_VERSION_UNKNOWN && g_opt.decode_kn_payload.load() != 0)
+            kn = attn->kn[layer_id] + (size_t)request_id * attn->Hkv * attn->M;
+    }
+    if (kn != nullptr) MP_HIP_CHECK(hipMemsetAsync(flag, 0, (size_t)h->Hkv * 4, st));
+    bool packed = false;
+    MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, h->R, b, t, h->err, kn, h->L, 17, flag, &packed, st));
+    MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, packed ? 17 : 0, st));
+    if (!h->slots.empty())
+        MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * 32, rows,
+                                      h->NB, h->R, h->M, st));
+    if (packed && (rc = lsh_set_version(h, layer_id, request_id, ver, st)) != MP_OK) return rc;
+    return lsh_read_err(h, st, who);
+}
+
+int mp_lsh_build_with_norms(mp_lsh_t* h, mp_attn_t* attn, int layer_id, int request_id, const int16_t* codes, int64_t n,
+                            int mem, mp_stream_t stream) {
+    MP_REQUIRE(attn != nullptr, MP_ERR_INVALID, "mp_lsh_build_with_norms: null attention store");
+    return lsh_build_entry(h, attn, layer_id, request_id, codes, n, mem, (hipStream_t)stream, "mp_lsh_build_with_norms");
 }
 
 // =================================================================== fused decode step

@@ -154,7 +154,8 @@ __global__ void lsh_unsort_kernel(const int16_t* __restrict__ codes, const int32
 // (ids ascend inside a bucket).  One workgroup per (kv head, table) row, one thread per (bucket, cut): a binary
 // search over a table row that was just written (L2 hits).
 __global__ __launch_bounds__(256) void lsh_subbounds_kernel(
-    const int32_t* __restrict__ table, int32_t* __restrict__ bounds, int NB, int R, int range_len, int64_t M) {
+    const int32_t* __restrict__ table, int32_t* __restrict__ bounds, int NB, int R, int range_len, int64_t M,
+    uint32_t idmask) {                                   // the words may carry a payload above the id (packed build)
     const int64_t row = blockIdx.x;
     const int RS = R + 1;
     const int32_t* t = table + row * M;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void lsh_subbounds_kernel(
         const int target = r * range_len;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (t[mid] < target) lo = mid + 1;
+            if ((int)((uint32_t)t[mid] & idmask) < target) lo = mid + 1;
             else hi = mid;
         }
         b[bk * RS + r] = lo;
@@ -319,7 +320,12 @@ template <int TPL>   // tokens per lane and tile: T = TPL * blockDim.x
 __global__ __launch_bounds__(1024) void lsh_build_kernel(
     const int16_t* __restrict__ codes,   // [Hkv*L][n] unsorted
     int n, int NB, int nbits, int64_t M, int RS, int32_t* __restrict__ bounds, int32_t* __restrict__ table,
-    int* __restrict__ err) {
+    int* __restrict__ err,
+    // packed build (round 4): with the attention store's norms of this request (kn [Hkv][M], nullptr = plain ids) a word
+    // is written as  id | bf16 bits 14..0 of the token's norm << idbits  in the SAME pass -- what lsh_attach_norms_kernel
+    // does to a finished table (a second sweep over 472 MB at cfg 1, plus a second build of the direct slots) when the
+    // first decode finds plain ids.  bad[kv head] is set for a norm that is not a non-negative bf16 number.
+    const float* __restrict__ kn, int L, int idbits, int* __restrict__ bad) {
     extern __shared__ int s_mem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int T = TPL * blockDim.x;
@@ -397,7 +403,22 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
             }
         }
         __syncthreads();
-        for (int p = tid; p < tile_count; p += blockDim.x) dst[p + s_gdelta[s_b[p]]] = s_id[p];
+        if (kn == nullptr) {
+            for (int p = tid; p < tile_count; p += blockDim.x) dst[p + s_gdelta[s_b[p]]] = s_id[p];
+        } else {
+            const float* knr = kn + (row / L) * M;               // a tile's 8 192 norms: 32 KB, read once per table row
+            bool refused = false;
+            for (int p = tid; p < tile_count; p += blockDim.x) {
+                const int id = s_id[p];
+                uint32_t u = __float_as_uint(knr[id]);
+                if ((u & 0x8000ffffu) != 0u || (u & 0x7f800000u) == 0x7f800000u) {   // not bf16, negative, inf / nan
+                    refused = true;
+                    u = 0u;
+                }
+                dst[p + s_gdelta[s_b[p]]] = (int32_t)((uint32_t)id | ((u >> 16) << idbits));
+            }
+            if (refused) atomicOr(bad + row / L, 1);
+        }
         // the next tile's zeroing of s_cnt is ordered after this loop's LDS reads by its barrier;
         // s_id / s_b are rewritten only after two more barriers
     }
@@ -1498,9 +1519,10 @@ bool lsh_hash_only_supported(int L) { return body_lds_bytes(0, L) <= RT_LDS_DYN_
 int lsh_range_len(int64_t M, int R) { return (int)((((M + R - 1) / R) + 31) & ~(int64_t)31); }
 
 hipError_t launch_lsh_subbounds(const int32_t* table, int32_t* bounds, int rows, int NB, int R, int64_t M,
-                                hipStream_t st) {
+                                int idbits, hipStream_t st) {
     if (R <= 1) return hipSuccess;
-    hipLaunchKernelGGL(lsh_subbounds_kernel, dim3(rows), dim3(256), 0, st, table, bounds, NB, R, lsh_range_len(M, R), M);
+    hipLaunchKernelGGL(lsh_subbounds_kernel, dim3(rows), dim3(256), 0, st, table, bounds, NB, R, lsh_range_len(M, R), M,
+                       idbits ? ((1u << idbits) - 1u) : 0xffffffffu);
     return hipGetLastError();
 }
 
@@ -1542,8 +1564,11 @@ static bool build_staged_geometry(int NB, int& nw, int& tpl, size_t& lds) {
 }
 
 // bounds entries 0 and R + the table; launch_lsh_subbounds fills entries 1 .. R-1 afterwards
+// kn != nullptr: the packed build (only the staged kernels pack; *packed says whether they ran)
 hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, int64_t M, int R,
-                            int32_t* bounds, int32_t* table, int* err, hipStream_t st) {
+                            int32_t* bounds, int32_t* table, int* err, const float* kn, int L, int idbits, int* bad,
+                            bool* packed, hipStream_t st) {
+    if (packed) *packed = false;
     static DeviceOnce once;
     const hipError_t attr_err = once.run([] {
         const void* fns[] = {reinterpret_cast<const void*>(lsh_build_kernel<8>),
@@ -1567,9 +1592,10 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
 #define MP_BUILD_CASE(TPL)                                                                         \
         if (tpl == TPL)                                                                            \
             hipLaunchKernelGGL(lsh_build_kernel<TPL>, dim3(rows), dim3(64 * nw), lds, st, codes,   \
-                               (int)n, NB, nbits, M, RS, bounds, table, err);
+                               (int)n, NB, nbits, M, RS, bounds, table, err, kn, L, idbits, bad);
         MP_BUILD_CASE(8) MP_BUILD_CASE(16) MP_BUILD_CASE(32)
 #undef MP_BUILD_CASE
+        if (packed) *packed = kn != nullptr;
         return hipGetLastError();
     }
     nw = BUILD_LDS_COUNTERS / NB;

@@ -50,11 +50,18 @@ class LSH:
         L.check(L.lib().mp_lsh_fill(self._h, layer_id, request_id, L.ptr(sorted_hash_code),
                                     L.ptr(sorted_indices), n, mem, L.current_stream(sorted_hash_code, self._device)))
 
-    def fastfill(self, layer_id: int, request_id: int, hash_code: torch.Tensor) -> None:
+    def fastfill(self, layer_id: int, request_id: int, hash_code: torch.Tensor, attn_server=None) -> None:
         """Working version of LSH::fastfill (lsh.cc:93-142, unfinished in the reference): builds
-        the tables on device from UNSORTED codes int16 [Hkv,L,n]."""
+        the tables on device from UNSORTED codes int16 [Hkv,L,n].  attn_server: the SparseAttentionServer whose
+        (layer, request) slot was ALREADY filled (the reference's order, models/attnserver.py:174 before :178-193):
+        the sort then packs the key norms into the table words itself (mp_lsh_build_with_norms) and the first decode
+        of the layer has nothing left to do; same tables, same results."""
         n = hash_code.shape[-1]
         L.expect(hash_code, torch.int16, (self.Hkv, self.L, n), "hash_code")
+        if attn_server is not None:
+            L.check(L.lib().mp_lsh_build_with_norms(self._h, attn_server._h, layer_id, request_id, L.ptr(hash_code), n,
+                                                    L.mem_kind(hash_code), L.current_stream(hash_code, self._device)))
+            return
         L.check(L.lib().mp_lsh_build(self._h, layer_id, request_id, L.ptr(hash_code), n,
                                      L.mem_kind(hash_code), L.current_stream(hash_code, self._device)))
 

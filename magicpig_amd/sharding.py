@@ -127,6 +127,17 @@ def gather_outputs(local: torch.Tensor, shard: Shard, batch_size: int, num_atten
     return full
 
 
+def gather_scalars(value: int, device=None) -> list:
+    """One int64 per rank, gathered on every rank (per-rank checksums of the bench / the multi-GPU tests)."""
+    dist = _dist()
+    if dist is None:
+        return [int(value)]
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [int(p.item()) for p in parts]
+
+
 def max_over_ranks(seconds: float, device=None) -> float:
     """The bench's step time is the slowest rank's."""
     dist = _dist()

@@ -21,10 +21,15 @@ from bench import CONFIGS, synth_kv
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg1"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 data = sys.argv[3] if len(sys.argv) > 3 else "randn"
+# "graph" [layers]: the stamps of the LAST launch of a hipGraph of `layers` back-to-back launches over as many DISTINCT
+# layers (bench.py's timed region: 30 at the 8B shape) instead of eager launches over 2 layers with a synchronisation
+# in between -- variants that win under idle-machine stamps have lost in the replayed graph three times (R3-6, R3-12, R4-1)
+use_graph = len(sys.argv) > 4 and sys.argv[4] == "graph"
+glayers = int(sys.argv[5]) if len(sys.argv) > 5 else 30
 cfg = CONFIGS[name]
 B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
 dev = torch.device("cuda:0")
-NLAYER = 2
+NLAYER = glayers if use_graph else 2
 server = mp.LSHSparseAttnServer(NLAYER, H, Hkv, D, K=K, L=Lt, batch_size=B, max_length=M, dense_layers=(), device="cuda:0")
 for li in range(NLAYER):
     for b in range(B):
@@ -60,7 +65,28 @@ names = ["start", "q row in", "normalised", "own unit", "hashed", "slots issued"
          "wave counted", "pieces in", "stream done", "own words scanned", "ids staged", "gathers issued",
          "qk", "transform", "pv", "states met", "stores acked", "ticket", "end (merger)"]
 acc = []
-for r in range(reps):
+if use_graph:
+    q_static = qs[0].clone()
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for li in range(NLAYER): server.decode(q_static[li], li)
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for li in range(NLAYER): server.decode(q_static[li], li)
+    for r in range(reps):
+        q_static.copy_(qs[r])
+        graph.replay(); torch.cuda.synchronize()          # warm replay
+        stamp.zero_()
+        q_static.copy_(qs[(r + 1) % reps])
+        graph.replay(); torch.cuda.synchronize()
+        a = stamp.cpu().numpy().reshape(grid, STRIDE)[:, slots].astype(np.float64) * 0.01
+        a[a == 0] = np.nan
+        # every launch of the replay overwrote the slots it passed: keep the workgroups whose stamps are those of ONE
+        # launch (monotone), relative to the last launch's first start
+        acc.append(a - np.nanmin(a[:, 0]))
+else:
+  for r in range(reps):
     for li in range(NLAYER):
         stamp.zero_()
         server.decode(qs[r, li], li)
@@ -71,7 +97,7 @@ for r in range(reps):
 L.check(L.lib().mp_debug_set_stamp_buffer(None))
 L.set_option("stamp_stride", 0)
 a = np.array(acc)                    # [runs, grid, phases]
-print(f"{name} ({data}): grid {grid} workgroups (R = {R}); us after the first workgroup's start, median over runs of the per-launch")
+print(f"{name} ({data}{', last launch of a replayed graph of %d layers' % NLAYER if use_graph else ''}): grid {grid} workgroups (R = {R}); us after the first workgroup's start, median over runs of the per-launch")
 print(f"{'phase':>16} {'min':>7} {'median':>7} {'p90':>7} {'max':>7}   rank-0 median / other ranks median")
 BH = B * H
 for i, nm in enumerate(names):

@@ -55,6 +55,7 @@ def run(scenario: str, iters: int) -> None:
     faulthandler.enable()
     BH, M = 8, 20480                      # results: 8 x 20480 x 4 = 640 KiB (> the 256 KiB registration threshold)
     addrs = set()
+    reused = 0
     for it in range(iters):
         lsh, q, ref_res, ref_nnz = _setup(mp, torch, seed=it)
         L_.set_option("host_register", 1)
@@ -79,6 +80,7 @@ def run(scenario: str, iters: int) -> None:
             resB = torch.full((BH, M), -7, dtype=torch.int32)       # very likely X's address again
             nnzB = torch.zeros((BH,), dtype=torch.int32)
             same = resB.data_ptr() in addrs
+            reused += int(same)
             lshB.batch_retrieve(0, qB, resB, nnzB)
             try:
                 _check(resB, nnzB, refB, refzB, f"stale it {it} (address reused: {same})")
@@ -98,7 +100,9 @@ def run(scenario: str, iters: int) -> None:
             raise SystemExit(f"unknown scenario {scenario}")
         L_.set_option("host_register", 0)
         if it % 20 == 0:
-            print(f"[{scenario}] iteration {it} ok ({len(addrs)} distinct result addresses so far)", flush=True)
+            print(f"[{scenario}] iteration {it} ok ({len(addrs)} distinct result addresses so far"
+                  + (f", stale address handed out again {reused} times" if scenario == "stale" else "") + ")",
+                  flush=True)
     print(f"[{scenario}] {iters} iterations ok, {len(addrs)} distinct result addresses", flush=True)
 
 
@@ -116,7 +120,9 @@ def main() -> None:
         print(f"==== scenario {sc}: {' '.join(cmd)}", flush=True)
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
-            tail = (r.stdout[-3000:] + "\n---- stderr ----\n" + r.stderr[-3000:])
+            keep = [ln for ln in r.stdout.splitlines() if not ln.startswith(("[Thread ", "[New Thread", "[New process"))]
+            err = [ln for ln in r.stderr.splitlines() if "Cannot get amd_mem_obj" not in ln]
+            tail = "\n".join(keep[-40:]) + "\n---- stderr (without the pageable-pointer lookups) ----\n" + "\n".join(err[-40:])
             print(f"==== scenario {sc}: exit code {r.returncode}\n{tail}", flush=True)
         except subprocess.TimeoutExpired:
             print(f"==== scenario {sc}: TIMEOUT", flush=True)

@@ -184,6 +184,42 @@ def test_captured_decodes_follow_the_state_of_their_replay(mp):
     server.collect_nnz = True
 
 
+@pytest.mark.parametrize("B,H,Hkv,K,Lt,data", [(1, 32, 8, 8, 75, "randn"), (2, 8, 2, 10, 40, "clustered"),
+                                               (1, 8, 1, 11, 30, "randn")])
+def test_packed_build_writes_what_the_lazy_packing_writes(mp, B, H, Hkv, K, Lt, data):
+    """mp_lsh_build_with_norms (LSH.fastfill(..., attn_server=store), what LSHSparseAttnServer.build_table does after
+    fill()): the counting sort packs the store's norms into the table words in the same pass.  Bounds, table words
+    and decode results are those of the plain build followed by the first decode's lazy packing, bit for bit, and the
+    first decode of the layer launches no packing kernel (the words do not change)."""
+    n, M, D = 6000, 6144, 128
+    lazy, (keys, kns, vals, W, qb) = _server(mp, B, H, Hkv, n, M, D, K, Lt, 41, data)      # tables first, then the store
+    eager = mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=Lt, batch_size=B, num_sink_tokens=0, num_local_tokens=0,
+                                   max_length=M, dense_layers=(), hash_func=bf16_t(W, "cuda"))
+    for b in range(B):                                                                    # the reference's order
+        eager.attn_server.fill(0, b, bf16_t(keys[b], "cuda"), bf16_t(vals[b], "cuda"), torch.from_numpy(kns[b]).cuda())
+        codes = eager.hasher.keys(bf16_t(keys[b], "cuda"))
+        eager.lsh_retriever.fastfill(0, b, codes, attn_server=eager.attn_server)
+    assert _packed(eager, n=n) and not _packed(lazy, n=n)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    qs = [torch.randn((B, H, 1, D), device="cuda", generator=gen).to(torch.bfloat16) for _ in range(3)]
+    before = eager.lsh_retriever.get_tables(0, raw=True)[1].clone()
+    for q in qs:
+        a, b_ = _decode(eager, q), _decode(lazy, q)
+        assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]) and torch.equal(a[2], b_[2])
+    eb, et = eager.lsh_retriever.get_tables(0, raw=True)
+    lb, lt = lazy.lsh_retriever.get_tables(0, raw=True)
+    assert torch.equal(et, before)                       # the first decode found nothing to pack
+    assert torch.equal(eb, lb) and torch.equal(et, lt)   # and the lazy path arrived at the same words
+    # a norm that cannot ride along (not a bf16 number) is refused by the packed build exactly as by the lazy packing
+    odd = torch.from_numpy(kns[0]).cuda() * 1.00390625 + 1e-3
+    for srv in (eager, lazy):
+        srv.attn_server.fill(0, 0, bf16_t(keys[0], "cuda"), bf16_t(vals[0], "cuda"), odd)
+    eager.lsh_retriever.fastfill(0, 0, eager.hasher.keys(bf16_t(keys[0], "cuda")), attn_server=eager.attn_server)
+    a, b_ = _decode(eager, qs[0]), _decode(lazy, qs[0])
+    assert torch.equal(a[0], b_[0]) and torch.equal(a[2], b_[2])
+    assert not _packed(eager, slice(0, Hkv), n)
+
+
 def test_norms_written_outside_a_fill_are_never_read_from_stale_table_words(mp):
     """mp_attn_append* and the writable get_key_norm() view change norms without a fill.  An append marks
     the layer's norms "changed outside a fill" on the device, in stream order -- also inside a replayed graph: the decode
