@@ -135,7 +135,8 @@ def parse():
     ap.add_argument("--lib", default=None,
                     help="A/B: path of an alternative build of libmagicpig_hip.so (the product reads no environment)")
     ap.add_argument("--cluster", type=int, default=0,
-                    help="A/B: workgroups per query head of the decode kernel (1, 2, 4, 8; default: by B*H and CUs)")
+                    help="A/B: workgroups per query head of the decode kernel (1, 2, 4, 8, 16, 32; default: by B*H, CUs and "
+                         "the tokens per member)")
     ap.add_argument("--no-direct-slots", action="store_true", help="A/B: sub-bounds + ids instead of direct piece slots")
     ap.add_argument("--split-hash", type=int, default=-1, choices=[-1, 0, 1],
                     help="A/B: hyperplanes split over the workgroups of a head's cluster (0 never, 1 always; default: auto)")

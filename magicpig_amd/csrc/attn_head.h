@@ -139,9 +139,7 @@ __device__ __forceinline__ AhState ah_state_init(int lane, int lpr) {
 // token - kn_t0 (lsh_decode_kernel scatters them there from the table entries' payload when a token is hit the second
 // time): a token's norm is then a 2-byte LDS read instead of a random 4-byte HBM access -- one line request in five of
 // the gather, which is bound by the requests a CU can keep in flight (EXPERIMENTS.md R3-10).
-// OWN: the list belongs to the calling WAVE alone (lsh_decode_kernel: the ids a wave popped from its own words of the
-// collision bitmap): it folds slices 0, 1, 2, ... of it by itself instead of every NW-th slice of a shared list.
-template <int D, int NW, bool DENSE, int SLICE, bool OWN = false, typename IDS>   // NW: upper bound of the workgroup's waves
+template <int D, int NW, bool DENSE, int SLICE, typename IDS>   // NW: upper bound of the workgroup's waves
 __device__ __forceinline__ void attn_head_fold(
     AhState& st,
     const uint16_t* __restrict__ kv_g,   // kv rows of this head's kv group: [M][2][D]
@@ -157,17 +155,17 @@ __device__ __forceinline__ void attn_head_fold(
     constexpr int UPS = SLICE / RPL;     // load steps per slice
     constexpr int DUP = LPR / UPS;       // lanes that end up with the same token's score
     static_assert(UPS >= 4 && UPS % 4 == 0 && DUP >= 2, "ids are fetched four at a time");
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int r = lane / LPR, c = lane % LPR;
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
-    // row addresses = ONE uniform base (a scalar register pair) + a 32-bit byte offset per row: a token's K | V rows are
-    // 4 D bytes, max_length <= 2^22 tokens, so every offset of a KV group is below 2^32 -- half the address registers
-    // and none of the 64-bit multiply-adds of a pointer per row (the 32-token step holds 64 registers of rows in flight
-    // under the 128 a lane of a 1 024-thread workgroup has)
+    // row addresses = ONE uniform base (a scalar register pair) + a 32-bit byte offset per row (round 4): a token's K | V
+    // rows are 4 D bytes, max_length <= 2^22 tokens, so every offset of a KV group is below 2^32 -- half the address
+    // registers and none of the 64-bit multiply-adds of a pointer per row (A/B, same box: cfg 3 31.25 -> 30.4 us per layer,
+    // cfg 2 33.9 -> 33.7, cfg 1 19.3 -> 19.2; EXPERIMENTS.md R4-2)
     const char* kvb = reinterpret_cast<const char*>(kv_g);
     const uint32_t coff = (uint32_t)c * 16u;
 
-    for (int k = OWN ? 0 : wave;; k += OWN ? 1 : nw) {
+    for (int k = wave;; k += nw) {
         const int64_t s = (int64_t)slice0 + (int64_t)slice_stride * k;
         if (j0 + s * SLICE >= nz) break;
         const int jb = j0 + (int)s * SLICE;
@@ -204,10 +202,11 @@ __device__ __forceinline__ void attn_head_fold(
         // a DRAM page, are requested back to back (splitting them cost 2 % at cfg 2).
         // the key norm FIRST in both forms: the transform needs it right behind the K rows; as the youngest load of a
         // full-size step it held the transform back until every V row was in (cfg 2 on clustered keys: 45.6 -> 43.3 us)
-        // (a norm that sits in LDS is read BEHIND the row loads: in front of them its ds_read and the wait at the join of
-        // the uniform branch stood between the ids and the first row request of every step -- EXPERIMENTS.md R3-15)
         float kn_my = 1.f;
-        if (!DENSE && kn_lds == nullptr) kn_my = kn_g[id_my];
+        if (!DENSE) {
+            if (kn_lds != nullptr) kn_my = bf16_bits_to_f32(kn_lds[id_my - kn_t0]);
+            else kn_my = kn_g[id_my];
+        }
         uint32_t ro[UPS];
 #pragma unroll
         for (int u = 0; u < UPS; ++u) ro[u] = (uint32_t)idc[u] * (uint32_t)(4 * D) + coff;
@@ -224,14 +223,8 @@ __device__ __forceinline__ void attn_head_fold(
                 kreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kvb + ro[u]));
                 vreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kvb + ro[u] + 2 * D));
             }
-#ifndef MP_NO_GATHER_FENCE
-            // every row load of the step is in flight before the first dot product: without the fence the scheduler
-            // sinks the K loads between the dot chains, two at a time (four dependent round trips per step; R3-15)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
-        if (!DENSE && kn_lds != nullptr) kn_my = bf16_bits_to_f32(kn_lds[id_my - kn_t0]);
-        if (!DENSE && k == (OWN ? 0 : wave)) MP_STAMP(stamp, 34);
+        if (!DENSE && k == wave) MP_STAMP(stamp, 34);
 
         // ---- q . K partials, reduce-scatter over the row group while more than one value is left, then all-reduce
         float part[UPS];
@@ -261,7 +254,7 @@ __device__ __forceinline__ void attn_head_fold(
             }
         }
         const float sc = part[0];                            // = q . K[id_my] on the DUP lanes of slot_my
-        if (!DENSE && k == (OWN ? 0 : wave)) MP_STAMP(stamp, 35);
+        if (!DENSE && k == wave) MP_STAMP(stamp, 35);
 
         // ---- importance-sampling transform (transform_kernel, sparse_attention.cc:164-184): importance_logit
         float z = -INFINITY;
@@ -276,7 +269,7 @@ __device__ __forceinline__ void attn_head_fold(
         const float m_w = wave_max(z);
         const float p_my = valid_my ? __expf(z - m_w) : 0.f;    // slice non-empty => m_w finite
         const float l_w = wave_sum((c % DUP) ? 0.f : p_my);
-        if (!DENSE && k == (OWN ? 0 : wave)) MP_STAMP(stamp, 36);
+        if (!DENSE && k == wave) MP_STAMP(stamp, 36);
 
         // ---- P . V
         float acc[8];
@@ -296,7 +289,7 @@ __device__ __forceinline__ void attn_head_fold(
         rs_step_h<4, 16>(acc, lane, doff);
         if (LPR == 8) rs_step_h<2, 8>(acc, lane, doff);
         st.d0 = c * 8 + doff;
-        if (!DENSE && k == (OWN ? 0 : wave)) MP_STAMP(stamp, 37);
+        if (!DENSE && k == wave) MP_STAMP(stamp, 37);
 
         // ---- fold the slice into the wave's running state
         const float m_new = fmaxf(st.m, m_w);
@@ -320,10 +313,7 @@ template <int D, int NW, bool FULL = false>
 __device__ __forceinline__ void attn_head_merge(const AhState& st, float* s_merge, float& m_out,
                                                 float& Z_out, float& o0_out, float& o1_out) {
     constexpr int VPL = D / 64;          // 2 (D = 128) or 1 (D = 64)
-    // (the wave index as a SCALAR: as a vector register it was the one value of the decode kernel that spilled, and its
-    // scratch reload stood in front of this merge)
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6),
-              nw = FULL ? NW : (int)(blockDim.x >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = FULL ? NW : (int)(blockDim.x >> 6);
     float* mine = s_merge + wave * (D + 2);
     mine[st.d0] = st.o0;
     if (D / 8 == 16) mine[st.d0 + 1] = st.o1;

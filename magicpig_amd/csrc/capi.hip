@@ -27,12 +27,13 @@ bool lsh_decode_supported(int64_t M, int L, int D, int R);
 bool xcd_round_robin_verified();
 hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, const uint16_t*, const float*, int,
                              int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
-                             float*, float2*, int*, int*, int*, uint16_t*, float*, float2*, const int32_t*, float*, int*,
+                             float*, float2*, int*, int*, uint16_t*, float*, float2*, const int32_t*, float*, int*,
                              int, int, bool, const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t,
                              bool, unsigned long long*, unsigned int*, int, int, int, const int*, const int*, const unsigned int*,
                              const unsigned int*, hipStream_t);
 hipError_t set_stamp_stride(int);
 hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
+int lsh_slot_log2(int64_t M, int NB, int R);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
                            int32_t*, int*, hipStream_t);
 hipError_t launch_lsh_unsort(const int16_t*, const int32_t*, int, int64_t, int16_t*, int*, hipStream_t);
@@ -89,7 +90,7 @@ int fail(int code, const std::string& msg) {
 // ---- debug / A-B options (mp_debug_set_option): process-wide, read at call time
 struct DebugOptions {
     std::atomic<int> decode_two_launch{0};   // 1: hash+retrieve launch, then attention launch
-    std::atomic<int> decode_cluster{0};      // 0 = auto, else workgroups per head (clamped to [1, min(8, slices)])
+    std::atomic<int> decode_cluster{0};      // 0 = auto, else workgroups per head (clamped to [1, min(32, slices)])
     std::atomic<int> decode_agent_scope{0};  // 1: cluster hand-off through memory even when the XCD placement was observed
     std::atomic<int> decode_mfma_hash{0};    // 1: query SimHash by the MFMA kernel in a launch of its own, then the decode
     std::atomic<int> decode_split_hash{-1};  // -1 = auto, 0 = never, 1 = always (clusters on one XCD), 2 = split but nobody publishes (test)
@@ -240,7 +241,7 @@ struct HostMap {
 };
 
 constexpr int FILL_BLOCKS = 1024;   // row blocks of mp_attn_fill_offload's column sums
-constexpr int MAX_CLUSTER = 32;     // workgroups per query head of the one-launch decode, at most
+constexpr int MAX_CLUSTER = MP_CLUSTER_MAX;   // workgroups per query head of the one-launch decode, at most
 
 static int alloc_zero(void** p, size_t bytes) {
     MP_HIP_CHECK(hipMalloc(p, bytes ? bytes : 1));
@@ -279,7 +280,8 @@ struct mp_lsh {
     int range_len = 0;             // tokens per range (multiple of 32)
     std::vector<int32_t*> bounds;  // per layer [B*Hkv][L][NB][R+1]
     std::vector<int32_t*> table;   // per layer [B*Hkv][L][M]
-    std::vector<int32_t*> slots;   // per layer [B*Hkv][L][NB][R][32] direct piece slots, or empty (R = 1 / long pieces)
+    std::vector<int32_t*> slots;   // per layer [B*Hkv][L][NB][R][slot_words] direct piece slots, or empty (R = 1 / long pieces)
+    int slot_words = 32;           // words per slot: 32, 16 or 8 by the mean piece length (lsh_slot_log2)
     unsigned long long* xw = nullptr;   // [BH][xwords] split hash: (launch sequence << 32 | 32 sign bits) (R > 1)
     unsigned int* xseq = nullptr;  // [BH] split hash: sequence number of the next launch
     int xwords = 0;
@@ -312,9 +314,8 @@ struct mp_attn {
     float2* part_ml = nullptr;     // [max_slices]
     float2* head_mz = nullptr;     // [BH] (max logit, Z) of the last call
     int* head_cnt = nullptr;       // [BH] arrival tickets of the in-launch merge (zero between calls)
-    int* part_cnt = nullptr;       // [BH][8] selected tokens of every cluster member in the last one-launch decode
-    int* wave_cnt = nullptr;       // [BH][MAX_CLUSTER][16] selected tokens of every wave of every member in the last one-launch
-                                   // decode (owned here, not by the lsh handle: get_score compacts the score rows with it later)
+    int* part_cnt = nullptr;       // [BH][MAX_CLUSTER] selected tokens of every cluster member in the last one-launch decode (owned
+                                   // here, not by the lsh handle: get_score compacts the score rows with it later)
     int* err = nullptr;            // device-side validation flag (append past max_length)
     double* colsum = nullptr;      // [FILL_BLOCKS][Hkv*D] scratch of mp_attn_fill_offload
     Stage small, big;              // host-buffer mode: (q | qn | nnz | offsets | out | mve) and the packed index rows
@@ -324,8 +325,8 @@ struct mp_attn {
     const int32_t* lastz = nullptr;// device nnz of the last call (for get_score): last_nnz or the
                                    // caller's own device buffer (valid until it changes)
     int score_state = 0;           // 0 none, 1 logits, 2 probabilities
-    const int* seg_cnt = nullptr;  // score rows are in 16 R segments (decode kernel: one per wave of every member): the
-    int seg_R = 1;                 // per-wave counts; compacted on demand by mp_attn_get_score
+    const int* seg_cnt = nullptr;  // score rows are in R segments (decode kernel, R > 1): per-member counts,
+    int seg_R = 1;                 // compacted on demand by mp_attn_get_score
     int grid = 8;                  // workgroups per head of the partial kernel (grid.x)
     bool head_kernel = false;      // one workgroup per head (attn_head_kernel) instead of split-KV
     bool xcd_rr = false;           // block b -> XCD b % 8 observed on this device (xcd_round_robin_verified)
@@ -508,16 +509,17 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
     // holding the piece's length, position and first 30 ids.  Worth their memory (groups x L x 2^K x R x 128 B per layer:
     // 1.26 GB at cfg 1) where a head is split over several workgroups AND a piece rarely overflows a slot:
     // mean piece length max_length / (2^K R) <= 12.5 ids (P[Poisson(12.5) > 31] = 2e-6).
+    h->slot_words = 1 << lsh_slot_log2(h->M, h->NB, h->R);               // 32, 16 or 8 words per slot (lsh.hip)
     bool direct = h->R > 1 && (double)h->M <= 12.5 * (double)h->NB * h->R &&
-                  (double)L * h->NB * h->R * 32.0 < 2147483648.0;     // 32-bit slot offsets inside a group
-    const size_t slot_bytes = groups * L * h->NB * (size_t)h->R * 128;
+                  (double)L * h->NB * h->R * (double)h->slot_words < 2147483648.0;     // 32-bit slot offsets inside a group
+    const size_t slot_bytes = groups * L * h->NB * (size_t)h->R * h->slot_words * 4;
     if (direct) {   // an accelerator, not a requirement: never take more than a third of what is free for it
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)slot_bytes * num_layers > (double)free_b / 3.0)
             direct = false;
     }
     if (const int o = g_opt.decode_direct.load(); o >= 0)                                  // A/B switch, read at alloc
-        direct = h->R > 1 && o != 0 && (double)L * h->NB * h->R * 32.0 < 2147483648.0;
+        direct = h->R > 1 && o != 0 && (double)L * h->NB * h->R * (double)h->slot_words < 2147483648.0;
     int rc = MP_OK;
     for (int i = 0; i < num_layers && rc == MP_OK; ++i) {
         void* b = nullptr; void* t = nullptr; void* sl = nullptr;
@@ -559,21 +561,24 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
     return MP_OK;
 }
 
-// Workgroups per query head of the one-launch decode (= token ranges of the tables): spread a head over
-// several CUs while there are idle ones.  Measured: 16 and 32 members lose more in the hand-off and in L2
-// plane traffic than they gain.
+// Workgroups per query head of the one-launch decode (= token ranges of the tables): spread a head over several CUs
+// while there are idle ones.  Up to 8 members: whenever B*H <= CUs / 8.  16 and 32 (round 4: cfg 4's 8 query heads per
+// GPU used 64 of the 256 CUs): only while a member still owns >= 4 096 tokens -- with fewer the chain of a member is
+// latency, not bytes, and more members only lengthen the hand-off (cfg 0's 4 288 tokens stay at 8).
 static int decode_cluster_size(int BH, int64_t M) {
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
         cus = prop.multiProcessorCount;
     int cluster = cus / (BH > 0 ? BH : 1);
-    if (const int o = g_opt.decode_cluster.load(); o >= 1) cluster = o;      // A/B switch, read at alloc
-    if (cluster > 8) cluster = 8;
+    const int forced = g_opt.decode_cluster.load();                          // A/B switch, read at alloc
+    if (forced >= 1) cluster = forced;
+    if (cluster > MAX_CLUSTER) cluster = MAX_CLUSTER;
     const int64_t slices = (M + 63) / 64;
     if (cluster > slices) cluster = (int)slices;
     int r = 1;
     while (2 * r <= cluster) r *= 2;
+    while (forced < 1 && r > 8 && M / r < 4096) r /= 2;
     return r;
 }
 
@@ -621,7 +626,7 @@ static int lsh_widen(mp_lsh_t* h, int layer_id, int except_request, hipStream_t 
         MP_HIP_CHECK(launch_lsh_attach_norms(t, nullptr, h->Hkv, h->L, h->M, 17, flag, st));
         if (!h->slots.empty()) {
             int32_t* b = h->bounds[layer_id] + (size_t)r * rows * h->NB * (h->R + 1);
-            MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)r * rows * h->NB * h->R * 32, rows, h->NB,
+            MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)r * rows * h->NB * h->R * h->slot_words, rows, h->NB,
                                           h->R, h->M, st));
         }
         int rc = lsh_set_version(h, layer_id, r, 0, st);
@@ -671,7 +676,7 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
     }
     MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, 0, st));
     if (!h->slots.empty())
-        MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * 32, rows,
+        MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * h->slot_words, rows,
                                       h->NB, h->R, h->M, st));
     if (mem == MP_MEM_HOST) MP_HIP_CHECK(hipStreamSynchronize(st));
     return MP_OK;
@@ -780,7 +785,7 @@ int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream) {
         MP_HIP_CHECK(hipMemsetAsync(h->bounds[i], 0, groups * h->L * h->NB * (size_t)(h->R + 1) * 4, st));
         MP_HIP_CHECK(hipMemsetAsync(h->table[i], 0, groups * h->L * (size_t)h->M * 4, st));
         if (!h->slots.empty())
-            MP_HIP_CHECK(hipMemsetAsync(h->slots[i], 0, groups * h->L * h->NB * (size_t)h->R * 128, st));
+            MP_HIP_CHECK(hipMemsetAsync(h->slots[i], 0, groups * h->L * h->NB * (size_t)h->R * h->slot_words * 4, st));
     }
     for (auto& v : h->att_ver) std::fill(v.begin(), v.end(), 0);
     MP_HIP_CHECK(hipMemsetAsync(h->att_ver_dev, 0, (size_t)h->layers * h->B * h->Hkv * 4, st));
@@ -802,7 +807,7 @@ static int lsh_attach_norms(mp_lsh_t* h, int layer_id, int request_id, const flo
     MP_HIP_CHECK(launch_lsh_attach_norms(t, kn, h->Hkv, h->L, h->M, 17, flag, st));
     if (!h->slots.empty()) {                            // the direct slots copy table words: rebuild them
         int32_t* b = h->bounds[layer_id] + (size_t)request_id * rows * h->NB * (h->R + 1);
-        MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * 32, rows,
+        MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * h->slot_words, rows,
                                       h->NB, h->R, h->M, st));
     }
     return MP_OK;
@@ -890,10 +895,10 @@ static void attn_free(mp_attn_t* h) {
     for (auto p : h->kn) if (p) (void)hipFree(p);
     h->kv.clear();
     h->kn.clear();
-    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt, h->err, h->colsum, h->part_cnt, h->kn_ver_dev, h->wave_cnt};
+    void* ptrs[] = {h->score, h->part_o, h->part_ml, h->head_mz, h->last_nnz, h->head_cnt, h->err, h->colsum, h->part_cnt, h->kn_ver_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->score = nullptr; h->part_o = nullptr; h->part_ml = nullptr; h->head_mz = nullptr;
-    h->last_nnz = nullptr; h->head_cnt = nullptr; h->err = nullptr; h->colsum = nullptr; h->part_cnt = nullptr; h->kn_ver_dev = nullptr; h->wave_cnt = nullptr;
+    h->last_nnz = nullptr; h->head_cnt = nullptr; h->err = nullptr; h->colsum = nullptr; h->part_cnt = nullptr; h->kn_ver_dev = nullptr;
     if (h->ind_rows) (void)hipFree(h->ind_rows);
     h->ind_rows = nullptr;
     h->small.release();
@@ -943,8 +948,7 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
     if (rc == MP_OK) rc = alloc_zero((void**)&h->last_nnz, BH * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->head_cnt, BH * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->err, 4);
-    if (rc == MP_OK) rc = alloc_zero((void**)&h->part_cnt, BH * 8 * 4);
-    if (rc == MP_OK) rc = alloc_zero((void**)&h->wave_cnt, BH * (size_t)MAX_CLUSTER * 16 * 4);
+    if (rc == MP_OK) rc = alloc_zero((void**)&h->part_cnt, BH * (size_t)MAX_CLUSTER * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->kn_ver_dev, (size_t)num_layers * groups * 4);
     if (rc == MP_OK) {   // every slot's norms (zeros) get a version no table can carry yet
         const uint32_t v = next_kn_version();
@@ -1330,7 +1334,7 @@ int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream) {
     MP_REQUIRE(score_dev, MP_ERR_INVALID, "mp_attn_get_score: null argument");
     hipStream_t st = (hipStream_t)stream;
     if (h->score_state == 1) {
-        if (h->seg_cnt != nullptr) {                   // one-launch decode: per-wave segments -> one list
+        if (h->seg_cnt != nullptr && h->seg_R > 1) {   // one-launch decode: R per-member segments -> one list
             MP_HIP_CHECK(launch_lsh_compact(reinterpret_cast<uint32_t*>(h->score), h->seg_cnt, h->B * h->H,
                                             h->seg_R, h->M, st));
             h->seg_cnt = nullptr;
@@ -1380,7 +1384,7 @@ static int lsh_build_entry(mp_lsh_t* h, mp_attn_t* attn, int layer_id, int reque
     MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, h->R, b, t, h->err, kn, h->L, 17, flag, &packed, st));
     MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, packed ? 17 : 0, st));
     if (!h->slots.empty())
-        MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * 32, rows,
+        MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * h->slot_words, rows,
                                       h->NB, h->R, h->M, st));
     if (packed && (rc = lsh_set_version(h, layer_id, request_id, ver, st)) != MP_OK) return rc;
     return lsh_read_err(h, st, who);
@@ -1458,7 +1462,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
         MP_HIP_CHECK(launch_lsh_decode(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk, s->wnorm, s->D,
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
-                                       attn->part_cnt, attn->wave_cnt, attn->head_cnt, output, max_value_expsum, attn->head_mz,
+                                       attn->part_cnt, attn->head_cnt, output, max_value_expsum, attn->head_mz,
                                        lsh->slots.empty() ? nullptr : lsh->slots[layer_id], attn->score, attn->err, attn_slices_per_head(attn->M), lsh->R,
                                        attn->xcd_rr && g_opt.decode_agent_scope.load() == 0,
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
@@ -1467,7 +1471,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
                                        attn->kn_ver_dev + goff, st));
         attn->lastz = lsh->nnz;
         attn->score_state = 1;
-        attn->seg_cnt = attn->wave_cnt;
+        attn->seg_cnt = lsh->R > 1 ? attn->part_cnt : nullptr;
         attn->seg_R = lsh->R;
     } else {
         // two launches: (hash + retrieve), then attention (models/attnserver.py:264-299, :300)

@@ -10,6 +10,7 @@
 namespace mp {
 
 constexpr int WAVE = 64;
+#define MP_CLUSTER_MAX 32   // workgroups per query head of the one-launch decode, at most (one XCD's 32 CUs)
 
 // ---------------------------------------------------------------- error plumbing (host)
 void set_error(const std::string& msg);

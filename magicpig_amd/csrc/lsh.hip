@@ -88,8 +88,7 @@ constexpr int RT_WAVES = RT_THREADS / 64;
 constexpr int RT_GROUP = 12;               // buckets in flight per wave per round (x 2 chunks of 64 ids)
 constexpr int RT_TAIL_CAP = 2048;          // pooled chunk descriptors for ids beyond 128 per bucket
 constexpr int RT_TAIL_UNROLL = 8;
-constexpr int DIRECT_IDS = 30;             // ids held by a 128-byte direct slot (behind the piece's length and position)
-constexpr int DIRECT_MORE = 96;            // ids of a longer piece its half-wave fetches itself before the chunk pool
+constexpr int CLUSTER_MAX = MP_CLUSTER_MAX; // workgroups per query head of the decode kernel, at most (common.h)
 
 // ---------------------------------------------------------------- LSH::fill
 // grid = Hkv*L rows of one request; one workgroup per (kv head, table) row.  RS = R + 1 entries per
@@ -173,8 +172,8 @@ __global__ __launch_bounds__(256) void lsh_subbounds_kernel(
     }
 }
 
-// direct piece slots [rows][NB][R][32] (R > 1): word 0 = length of the piece (bucket, range), word 1 = its position
-// in the table row, words 2 .. 31 = its first 30 ids.  The decode kernel reads a piece with ONE 128-byte access
+// direct piece slots [rows][NB][R][SW] (R > 1; SW = 32, 16 or 8 words by the mean piece length, lsh_slot_log2): word 0 =
+// length of the piece (bucket, range), word 1 = its position in the table row, words 2 .. SW - 1 = its first SW - 2 ids.  The decode kernel reads a piece with ONE 128-byte access
 // straight from the query's code, without the sub-bounds round trip in front of it; the position lets it fetch the
 // rest of a longer piece with the next access.  Half a wave writes a slot.
 // (Measured and rejected, round 3: the layout [group][R][L][NB][32], in which the slots a cluster member reads are one
@@ -182,16 +181,18 @@ __global__ __launch_bounds__(256) void lsh_subbounds_kernel(
 // randn / clustered / cfg 4 against 19.4 / 22.1 / 21.0 with this one.  Address translation is not what the phase waits for.)
 __global__ __launch_bounds__(256) void lsh_slots_kernel(const int32_t* __restrict__ table,
                                                         const int32_t* __restrict__ bounds,
-                                                        int32_t* __restrict__ slots, int NB, int R, int64_t M) {
+                                                        int32_t* __restrict__ slots, int NB, int R, int64_t M, int swl) {
     const int64_t row = blockIdx.y;                      // (kv head, table) row of this request
     const int RS = R + 1;
+    const int SW = 1 << swl;                             // words per slot: 32, 16 or 8 (lsh_slot_log2)
     const int32_t* t = table + row * M;
     const int32_t* b = bounds + row * NB * RS;
-    int32_t* s = slots + row * NB * R * 32;
-    const int sl = threadIdx.x & 31;
-    constexpr int U = 4;                                 // pieces in flight per half-wave
+    int32_t* s = slots + row * NB * R * SW;
+    const int sl = threadIdx.x & (SW - 1);
+    const int gpb = 256 >> swl;                          // groups of SW lanes per block: one group writes a slot
+    constexpr int U = 4;                                 // pieces in flight per group
     const int total = NB * R;
-    for (int p0 = (blockIdx.x * 8 + (threadIdx.x >> 5)) * U; p0 < total; p0 += gridDim.x * 8 * U) {
+    for (int p0 = (blockIdx.x * gpb + (threadIdx.x >> swl)) * U; p0 < total; p0 += gridDim.x * gpb * U) {
         int lo[U], hi[U], v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void lsh_slots_kernel(const int32_t* __restric
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (p0 + u < total) s[(int64_t)(p0 + u) * 32 + sl] = v[u];
+            if (p0 + u < total) s[(int64_t)(p0 + u) * SW + sl] = v[u];
     }
 }
 
@@ -521,13 +522,13 @@ struct AttnArgs {
     const float* kn;         // [B*Hkv][M]
     float* part_o;           // [BH][maxs][D]
     float2* part_ml;         // [BH][maxs]
-    int* part_cnt;           // [BH][8] selected tokens of every member (R > 1), bits 0..23; bits 24..27 its XCC_ID
-    int* wave_cnt;           // [BH][R][16] selected tokens of every wave of every member: the segments of the score rows
+    int* part_cnt;           // [BH][CLUSTER_MAX] selected tokens of every member (R > 1), bits 0..23; bits 24..27 its XCC_ID
     int* head_cnt;           // [BH] arrival tickets, zero between launches
     uint16_t* out;           // [BH][D] bf16
     float* mve;              // [2][BH]
     float2* head_mz;         // [BH]
-    const int32_t* slots;    // [B*Hkv][L][NB][R][32] direct piece slots (R > 1, short pieces) or nullptr
+    const int32_t* slots;    // [B*Hkv][L][NB][R][2^slot_log2] direct piece slots (R > 1, short pieces) or nullptr
+    int slot_log2;           // words per slot, log2 (5, 4 or 3: lsh_slot_log2)
     float* score;            // [BH][M] (nullable); member r's logits start at column r * range_len
     int* err;                // device flag: bit 4 = a cluster member ran on another XCD than observed
     int BH, BHp, maxs, cap, cluster_log2;   // BHp: heads per rank in the grid (BH padded to 8 when R > 1); cap: ids of the LDS stage (multiple of AH_SLICE)
@@ -863,27 +864,46 @@ __device__ __forceinline__ void lsh_head_body(
         // ids is finished by its half-wave with one more access (below); the slots exist only where the mean piece
         // is <= 12.5 ids.  (256-byte slots holding 63 ids need no second access and measured slower: 23.8 against
         // 22.9 us per layer at cfg 1, 28.6 against 27.3 at cfg 4 -- twice the bytes of random 128-byte reads.)
-        const int half = lane >> 5, sl = lane & 31;
-        const int32_t* sg = slots + ((int64_t)g * L * NB * R + rank) * 32;
-        // DG = 6 covers 192 tables in one round (cfg 1: L = 150); with more tables (cfg 4: L = 300) a second
-        // round would be a second dependent round trip, so the wide form keeps 10 loads = 320 pieces in flight
-        auto direct_pass = [&](auto dg_tag) {
+        // A slot is SW = 32, 16 or 8 words (aa.slot_log2; chosen at alloc from the mean piece length M / (2^K R)): its
+        // first two words are the piece's length and position, the rest its first SW - 2 ids.  A GROUP of SW lanes reads a
+        // slot, so one load instruction fetches 64 / SW slots: with clusters of 16 / 32 workgroups per head (cfg 4: mean
+        // piece 4 / 2 ids, L = 300) a wave's 19 tables are 5 / 3 loads of 64- / 32-byte slots instead of 10 of 128 bytes.
+        auto direct_pass = [&](auto dg_tag, auto sw_tag) {
         constexpr int DG = decltype(dg_tag)::value;
-        for (int l0 = 0; l0 < L; l0 += RT_WAVES * 2 * DG) {
+        constexpr int SWL = decltype(sw_tag)::value;                    // log2 of the slot width in words
+        constexpr int SW = 1 << SWL, GPW = 64 / SW;                     // groups (= slots) per load instruction
+        constexpr int SLOT_IDS = SW - 2, SLOT_MORE = 3 * SW;            // ids in the slot / fetched by the group itself behind it
+        const int grp = lane >> SWL, sl = lane & (SW - 1);
+        const int32_t* sg = slots + ((int64_t)g * L * NB * R + rank) * SW;
+        // the value lane (group start + k) holds, k = 0 (length) or 1 (position), for every lane of the group
+        auto group_word = [&](int32_t v, auto k_tag) -> int {
+            constexpr int KK = decltype(k_tag)::value;
+            if constexpr (SW == 32) {
+                const int a0 = __builtin_amdgcn_readlane(v, KK), a1 = __builtin_amdgcn_readlane(v, 32 + KK);
+                return grp ? a1 : a0;
+            } else if constexpr (SW == 16) {                            // a group is one DPP row
+                return __builtin_amdgcn_update_dpp(0, v, 0x150 + KK, 0xf, 0xf, false);            // row_newbcast:KK
+            } else {                                                    // two groups per DPP row
+                const int lo = __builtin_amdgcn_update_dpp(0, v, 0x150 + KK, 0xf, 0xf, false);
+                const int hi = __builtin_amdgcn_update_dpp(0, v, 0x150 + 8 + KK, 0xf, 0xf, false);
+                return (lane & 8) ? hi : lo;
+            }
+        };
+        for (int l0 = 0; l0 < L; l0 += RT_WAVES * GPW * DG) {
             int32_t v[DG];
             int cd[DG];
             uint32_t at[DG];
             // three straight-line rounds -- codes (two LDS words + one funnel shift each), slot offsets (shifts only:
-            // NB = 2^K, R = 2^clog, 32-word slots; the host keeps a group's slots under 2^31 words), loads -- and the
+            // NB = 2^K, R = 2^clog, 2^SWL-word slots; the host keeps a group's slots under 2^31 words), loads -- and the
             // stores of the codes after them.  As one loop body per piece (a branch around the second LDS word, 64-bit
             // multiplies, a branch around the store) the compiler emitted six dependent LDS round trips in front of
             // the loads: 1.5 us between "sign bits in LDS" and "loads issued" (scripts/phase_times.py), now 0.3.
 #pragma unroll
             for (int b = 0; b < DG; ++b) {
-                const int l = l0 + (b * RT_WAVES + wave) * 2 + half;
+                const int l = l0 + (b * RT_WAVES + wave) * GPW + grp;
                 const int lc = l < L ? l : L - 1;                       // loads stay unconditional
                 cd[b] = code_fast(lc);
-                at[b] = (((((uint32_t)lc << ha.K) + (uint32_t)cd[b]) << clog) << 5) + (uint32_t)sl;
+                at[b] = (((((uint32_t)lc << ha.K) + (uint32_t)cd[b]) << clog) << SWL) + (uint32_t)sl;
             }
 #pragma unroll
             for (int b = 0; b < DG; ++b) v[b] = sg[at[b]];
@@ -891,7 +911,7 @@ __device__ __forceinline__ void lsh_head_body(
             if ((HASH == 1 || HASH == 3) && lead && sl == 0) {
 #pragma unroll
                 for (int b = 0; b < DG; ++b) {
-                    const int l = l0 + (b * RT_WAVES + wave) * 2 + half;
+                    const int l = l0 + (b * RT_WAVES + wave) * GPW + grp;
                     if (l < L) ha.codes_out[h * L + l] = cd[b];
                 }
             }
@@ -899,45 +919,43 @@ __device__ __forceinline__ void lsh_head_body(
             // 128 dimensions: bucket sizes at cfg 1 run from 32 (p1) to 209 (p99) around a mean of 96) and a query lands
             // in the heavy ones more often -- 1.5 % of the probed pieces on isotropic keys, 5.9 % on the clustered
             // workload (bench.py --data clustered), i.e. two to three per wave somewhere in almost every cluster.  Its
-            // half-wave fetches up to 96 more ids itself (the slot carries the position): ONE more dependent access for
+            // group fetches up to 3 SW more ids itself (the slot carries the position): ONE more dependent access for
             // the whole wave -- the follow-up loads of ALL its long pieces are issued while the slots are still being
             // counted and are waited for together (round 2 waited for each long piece's loads on the spot: a wave
             // with three long pieces paid three dependent round trips, and the launch waits for its slowest wave).
-            // What is longer still (> 126 ids, skewed data) goes to the chunk pool.
+            // What is longer still (skewed data) goes to the chunk pool.
             int32_t e0[DG], e1[DG], e2[DG];
             int r1s[DG];
             uint32_t more = 0u, wide = 0u;                                  // wave-uniform bit masks over b
 #pragma unroll
             for (int b = 0; b < DG; ++b) {
-                const int l = l0 + (b * RT_WAVES + wave) * 2 + half;
-                const int c0 = __builtin_amdgcn_readlane(v[b], 0), c1 = __builtin_amdgcn_readlane(v[b], 32);
-                const int p0 = __builtin_amdgcn_readlane(v[b], 1), p1 = __builtin_amdgcn_readlane(v[b], 33);
-                const int pl = half ? c1 : c0;                          // length of the piece
-                const int pp = half ? p1 : p0;                          // its position in the table row
+                const int l = l0 + (b * RT_WAVES + wave) * GPW + grp;
+                const int pl = group_word(v[b], std::integral_constant<int, 0>{});   // length of the piece
+                const int pp = group_word(v[b], std::integral_constant<int, 1>{});   // its position in the table row
                 if (b == 0) MP_STAMP(stamp, 43);                        // the first slot has arrived
                 if (b == DG - 1) MP_STAMP(stamp, 44);                   // the last one has
                 int rest = 0;
                 if (l < L) {
-                    rest = pl - DIRECT_IDS;
+                    rest = pl - SLOT_IDS;
                     if (pp < 0 || (int64_t)pp + pl > M) rest = 0;       // never outside the row
                 }
-                const int r1 = rest < DIRECT_MORE ? rest : DIRECT_MORE;
+                const int r1 = rest < SLOT_MORE ? rest : SLOT_MORE;
                 r1s[b] = r1;
                 e0[b] = e1[b] = e2[b] = -1;
                 if (__ballot(rest > 0)) {                               // wave-uniform: the follow-up goes out NOW
                     more |= 1u << b;
                     const int lc = l < L ? l : L - 1;
                     const int32_t* row = tab + (int64_t)lc * M;
-                    const int at0 = pp + DIRECT_IDS + sl;
+                    const int at0 = pp + SLOT_IDS + sl;
                     e0[b] = row[sl < r1 ? at0 : 0];
-                    if (__ballot(r1 > 32)) {
+                    if (__ballot(r1 > SW)) {
                         wide |= 1u << b;
-                        e1[b] = row[sl + 32 < r1 ? at0 + 32 : 0];
-                        e2[b] = row[sl + 64 < r1 ? at0 + 64 : 0];
+                        e1[b] = row[sl + SW < r1 ? at0 + SW : 0];
+                        e2[b] = row[sl + 2 * SW < r1 ? at0 + 2 * SW : 0];
                     }
-                    if (sl == 0 && rest > DIRECT_MORE) {                // skewed data: the chunk pool takes the rest
-                        s_start[l] = pp + DIRECT_IDS + DIRECT_MORE;
-                        s_len[l] = rest - DIRECT_MORE;
+                    if (sl == 0 && rest > SLOT_MORE) {                  // skewed data: the chunk pool takes the rest
+                        s_start[l] = pp + SLOT_IDS + SLOT_MORE;
+                        s_len[l] = rest - SLOT_MORE;
                         atomicAdd(&s_tmp[30], 1);
                     }
                 }
@@ -949,16 +967,20 @@ __device__ __forceinline__ void lsh_head_body(
                     if (more & (1u << b)) {
                         apply(sl < r1s[b] ? e0[b] : -1);
                         if (wide & (1u << b)) {
-                            apply(sl + 32 < r1s[b] ? e1[b] : -1);
-                            apply(sl + 64 < r1s[b] ? e2[b] : -1);
+                            apply(sl + SW < r1s[b] ? e1[b] : -1);
+                            apply(sl + 2 * SW < r1s[b] ? e2[b] : -1);
                         }
                     }
                 }
             }
         }
         };
-        if (L > RT_WAVES * 2 * 6) direct_pass(std::integral_constant<int, 10>{});
-        else direct_pass(std::integral_constant<int, 6>{});
+        // loads in flight per wave: enough to cover L tables in ONE round where it fits (a second round is a second
+        // dependent round trip): 128-byte slots 6 (L <= 192) or 10; 64-byte slots 5 (L <= 320); 32-byte slots 3 (L <= 384)
+        if (aa.slot_log2 == 3) direct_pass(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
+        else if (aa.slot_log2 == 4) direct_pass(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+        else if (L > RT_WAVES * 2 * 6) direct_pass(std::integral_constant<int, 10>{}, std::integral_constant<int, 5>{});
+        else direct_pass(std::integral_constant<int, 6>{}, std::integral_constant<int, 5>{});
         MP_STAMP(stamp, 45);                                            // this wave's pieces counted
         __syncthreads();
         MP_STAMP(stamp, 17);
@@ -1088,144 +1110,85 @@ __device__ __forceinline__ void lsh_head_body(
     if (!(AD > 0 && HASH != 0 && slots != nullptr && ntail == 0)) __syncthreads();
     MP_STAMP(stamp, 19);
 
-    if (AD == 0) {
-        // ---- stand-alone retrieve: sweep B with contiguous words per thread, block-wide exclusive scan, ascending
-        // emission of the head's list
-        int cnt = 0;
-        int32_t* out = results + h * M;
-        const int nsw = words;
-        const int wpt = (nsw + RT_THREADS - 1) / RT_THREADS;
-        const int w0 = tid * wpt;
-        for (int k = 0; k < wpt; ++k)
-            if (w0 + k < nsw) cnt += __popc(bmB[w0 + k]);
-        int total;
-        int off = block_excl_scan(cnt, s_tmp, total);
-        MP_STAMP(stamp, 20);
-        for (int k = 0; k < wpt; ++k) {
-            if (w0 + k >= nsw) break;
-            uint32_t bits = bmB[w0 + k];
-            const int base = (int)T0 + ((w0 + k) << 5);
-            while (bits) {
-                const int p = __ffs((int)bits) - 1;
-                bits &= bits - 1;
-                out[off++] = base + p;
-            }
+    // sweep B: contiguous words per thread, block-wide exclusive scan, ascending emission
+    int cnt = 0;
+    // the stand-alone retrieve writes the head's list; a decode member writes ITS list at column t0 of the
+    // head's row (a by-product: get_score's order, the spill path below), nnz is summed at the hand-off
+    int32_t* out = results + h * M + t0;
+    const int nsw = words;
+    const int wpt = (nsw + RT_THREADS - 1) / RT_THREADS;
+    const int w0 = tid * wpt;
+    for (int k = 0; k < wpt; ++k)
+        if (w0 + k < nsw) cnt += __popc(bmB[w0 + k]);
+    int total;
+    int off = block_excl_scan(cnt, s_tmp, total);
+    MP_STAMP(stamp, 20);
+    // AD: the member's ids stay in LDS; a list longer than the stage (cap ids) is read back from HBM
+    const bool spill = AD > 0 && total > aa.cap;
+    for (int k = 0; k < wpt; ++k) {
+        if (w0 + k >= nsw) break;
+        uint32_t bits = bmB[w0 + k];
+        const int base = (int)T0 + ((w0 + k) << 5);
+        while (bits) {
+            const int p = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            out[off] = base + p;
+            if (AD > 0 && off < aa.cap) s_ids[off] = base + p;
+            ++off;
         }
-        if (tid == 0) nnz[h] = total;
-        MP_STAMP(stamp, 21);
+    }
+    if (tid == 0 && (AD == 0 || clog == 0)) nnz[h] = total;
+    MP_STAMP(stamp, 21);
+    if (AD == 0) {
         MP_STAMP_FLUSH(stamp);
         return;
     }
 
     // ------------------------------------------------------------ fused sparse attention of head h
-    // Every WAVE gathers straight from its own words of bitmap B (round 4).  Wave w owns words [w * wpw, (w + 1) * wpw)
-    // of the member's range (cfg 1: 24 words = 768 tokens, ~12 selected): its lanes read the words, a DPP prefix sum
-    // gives every id its place in a wave-private piece of the LDS stage, and the wave requests the K / V rows of its
-    // ids at once -- no block-wide scan, no emission to HBM and no workgroup barrier between "counted" and the first
-    // row request (1.6 us of the dependent chain until round 3).  The mapping wave -> tokens is fixed, the waves'
-    // states are merged in wave order: results stay deterministic.  Logits (get_score) land in the wave's segment of
-    // the head's score row (column t0 + 32 * w * wpw); the per-wave counts go to wave_cnt, which get_score's
-    // compaction and the hand-off's count (nnz) read.
     constexpr int ADD = AD > 0 ? AD : 64;
     uint16_t* out_h = aa.out + h * ADD;
     int wlen = 0;
     if (WIN && aa.win_kv != nullptr) {
-        wlen = __builtin_amdgcn_readfirstlane(aa.win_len[h]);
+        wlen = aa.win_len[h];
         wlen = wlen < 0 ? 0 : (wlen > aa.win_M ? (int)aa.win_M : wlen);
     }
+    if (clog == 0 && total == 0 && wlen == 0) {
+        attn_head_empty<ADD>(out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
+        MP_STAMP_FLUSH(stamp);
+        return;
+    }
+    __syncthreads();                        // s_ids complete; the spilled list drained (vmcnt) and visible in L2
+    MP_STAMP(stamp, 33);
+    // two instantiations of the sparse fold: the LDS path carries no global load ahead of its gathers
     float m, Z, o0, o1;
     const u32x4 qv = *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADD / 8)) * 4);
+    float* score_h = aa.score ? aa.score + h * M + t0 : nullptr;
     const uint16_t* kv_g = aa.kv + g * M * 2 * ADD;
     const float* kn_g = aa.kn + g * M;
-    constexpr int SHORT = (ADD == 128) ? 16 : AH_SLICE;      // 16-token steps exist for head_dim 128 only
-    const int wpw = (words + RT_WAVES - 1) / RT_WAVES;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar: everything derived from it stays in SGPRs
-    const int wlo = wave_u * wpw < words ? wave_u * wpw : words;
-    const int whi = wlo + wpw < words ? wlo + wpw : words;
-    const int capw = aa.cap / RT_WAVES;                      // ids of the wave's piece of the stage (256 = 8 full words)
-    int32_t* mylist = s_ids + wave_u * capw;
-    float* score_w = aa.score ? aa.score + h * M + t0 + ((int64_t)wlo << 5) : nullptr;
+    auto ids_lds = [&](int j) { return *reinterpret_cast<const u32x4*>(s_ids + j); };
+    auto ids_hbm = [&](int j) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        for (int e = 0; e < 4; ++e)
+            v[e] = ((uint32_t)(j + e) < tlen) ? (uint32_t)__builtin_nontemporal_load(out + j + e) : 0u;
+        return v;
+    };
+    // lists that one round of 16-token steps covers (a member's ~190 ids at cfg 1) take those: twice the waves,
+    // half the rows per wave (head_dim 128; at 64 a 16-token step would be two load instructions).  Measured and
+    // rejected: 16-token steps for the last partial round of a long list (cfg 2: 641 ids = one round of 32-token
+    // steps + 129 ids) -- 37.2 us per layer against 35.6 with HBM saturated.
+    constexpr int SHORT = (ADD == 128) ? 16 : AH_SLICE;
+    const bool short_list = SHORT < AH_SLICE && total <= SHORT * RT_WAVES && !spill;
     AhState st = ah_state_init(lane, ADD / 8);
     const uint16_t* kn_lds = pay ? s_kn : nullptr;
-    const float qn_h = s_rn[1];
-    auto ids_own = [&](int j) { return *reinterpret_cast<const u32x4*>(mylist + j); };
-    // Rounds of (stage, fold); with a sampled selection (a few per cent of the tokens) ONE round covers the wave's words.
-    // A round stages whole 64-word chunks while they fit the wave's piece of the stage; a chunk that alone holds more
-    // than 256 ids (dense selections: more than an eighth of 2 048 tokens) is taken in groups of 8 words (<= 256 ids).
-    int done = 0;                                             // wave-uniform: ids folded so far
-    int c0 = wlo, sg = 0;                                     // next chunk, first 8-lane group of it not yet staged
-    for (;;) {
-        int run = 0;                                          // ids staged in this round
-        while (c0 < whi) {
-            const int wi = c0 + lane;
-            uint32_t bits = (wi < whi && (lane >> 3) >= sg) ? bmB[wi] : 0u;
-            int cnt = __popc(bits);
-            int incl = wave_incl_scan(cnt);
-            int tot = __builtin_amdgcn_readlane(incl, 63);
-            MP_STAMP(stamp, 20);                              // this wave's words of bitmap B read and prefix-summed
-            int ngrp = 8 - sg;                                // groups of this chunk staged by this pass
-            if (run + tot > capw) {
-                if (run > 0) break;                           // fold what is staged first
-                // an empty stage and still too many: the leading groups that fit (at least one: 8 words <= 256 ids)
-                // (the running count at the end of every group; nondecreasing, and zero in front of group sg)
-                int last = sg, taken = 0;
-#define MP_GROUP_END(gq, ln)                                                         \
-                {                                                                     \
-                    const int e = __builtin_amdgcn_readlane(incl, ln);                \
-                    if (gq >= sg && e <= capw) {                                      \
-                        last = gq;                                                    \
-                        taken = e;                                                    \
-                    }                                                                 \
-                }
-                MP_GROUP_END(0, 7) MP_GROUP_END(1, 15) MP_GROUP_END(2, 23) MP_GROUP_END(3, 31)
-                MP_GROUP_END(4, 39) MP_GROUP_END(5, 47) MP_GROUP_END(6, 55) MP_GROUP_END(7, 63)
-#undef MP_GROUP_END
-                ngrp = last - sg + 1;
-                if ((lane >> 3) > last) bits = 0u;
-                cnt = __popc(bits);
-                tot = taken;
-            }
-            const int base = (int)T0 + (wi << 5);
-            int off = run + incl - cnt;
-            while (bits) {
-                const int p = __ffs((int)bits) - 1;
-                bits &= bits - 1;
-                mylist[off++] = base + p;
-            }
-            run += tot;
-            sg += ngrp;
-            if (sg >= 8) {
-                sg = 0;
-                c0 += 64;
-            } else {
-                break;                                        // a partial chunk fills the round
-            }
-        }
-        if (run == 0) {
-            if (c0 >= whi) break;                             // nothing left
-            continue;                                         // (a partial chunk whose leading groups were empty)
-        }
-        // the wave's own LDS writes, read back by other lanes of the same wave: program order is enough for the
-        // hardware (one wave's LDS accesses execute in order), the fences keep the compiler from moving them
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        MP_STAMP(stamp, 33);                                  // the wave's ids are staged
-        float* sc = score_w ? score_w + done : nullptr;
-        // a wave's ~12 ids at cfg 1 are ONE 16-token step (8 row loads in flight); longer lists take 32-token steps.
-        // (The two forms in mutually exclusive branches: a 16-token step for the rest of a longer list, behind the
-        // 32-token loop, kept both forms' constants and addresses live at once and spilled 9-16 vector registers.)
-        if (SHORT < AH_SLICE && run <= SHORT)
-            attn_head_fold<ADD, RT_WAVES, false, SHORT, true>(st, kv_g, kn_g, qv, qn_h, run, M, ha.K, L, 0, 1, ids_own,
-                                                              sc, stamp, 0, kn_lds, (int)T0);
-        else
-            attn_head_fold<ADD, RT_WAVES, false, AH_SLICE, true>(st, kv_g, kn_g, qv, qn_h, run, M, ha.K, L, 0, 1, ids_own,
-                                                                 sc, stamp, 0, kn_lds, (int)T0);
-        done += run;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the stage is rewritten only after these reads
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (lane == 0) s_tmp[wave_u] = done;    // read by wave 0 behind the barrier of attn_head_merge
+    if (short_list)
+        attn_head_fold<ADD, RT_WAVES, false, SHORT>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1, ids_lds,
+                                                    score_h, stamp, 0, kn_lds, (int)T0);
+    else if (!spill)
+        attn_head_fold<ADD, RT_WAVES, false, AH_SLICE>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
+                                                       ids_lds, score_h, stamp, 0, kn_lds, (int)T0);
+    else
+        attn_head_fold<ADD, RT_WAVES, false, AH_SLICE>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
+                                                       ids_hbm, score_h, stamp, 0, kn_lds, (int)T0);
     if (WIN && wlen > 0) {                  // the static window: dense slices rank, rank + R, ... (k runs from
                                             // `wave` again, so the waves that got no sparse slice are served first)
         auto none = [](int) { return u32x4{0u, 0u, 0u, 0u}; };
@@ -1237,13 +1200,8 @@ __device__ __forceinline__ void lsh_head_body(
     // from here on WAVE 0 alone holds the workgroup's state: one wave needs no workgroup barrier to order its
     // own stores, ticket and loads, and the other fifteen are done
     if (wave != 0) return;
-    // the waves' counts: one LDS read, one store for get_score's compaction, a DPP sum for nnz / the hand-off
-    const int cnt_w = lane < RT_WAVES ? s_tmp[lane] : 0;
-    if (lane < RT_WAVES && aa.wave_cnt != nullptr) aa.wave_cnt[((h << clog) + rank) * RT_WAVES + lane] = cnt_w;
-    const int total = __builtin_amdgcn_readlane(wave_incl_scan(cnt_w), 63);
     if (clog == 0) {
-        attn_head_finalize<ADD>(m, Z, o0, o1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);   // Z = 0: out = 0, LSE = -inf
-        if (lane == 0) nnz[h] = total;
+        attn_head_finalize<ADD>(m, Z, o0, o1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
         MP_STAMP(stamp, 39);
         MP_STAMP_FLUSH(stamp);
         return;
@@ -1265,18 +1223,18 @@ __device__ __forceinline__ void lsh_head_body(
     constexpr int VPL = ADD / 64;
     const int nmem = 1 << clog;
     const int64_t pre = h * aa.maxs;
-    float mr[8], zr[8], oa[8], ob[8];
-    int cr[8];
     int ticket = 0;
+    uint32_t my_xcc = 0;
     if (aa.same_xcd) {
         // every member publishes the XCD it ran on next to its count; the merger compares them with its own
-        const uint32_t my_xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]
+        my_xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]
         constexpr int kSc0 = 1;   // aux bit 0 = sc0 on gfx940+
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
             aa.part_o + pre * ADD, 0, (int)(aa.maxs * ADD * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<float*>(aa.part_ml + pre), 0, (int)(aa.maxs * 8), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(aa.part_cnt + h * 8, 0, 32, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(aa.part_cnt + h * CLUSTER_MAX, 0,
+                                                                            CLUSTER_MAX * 4, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), ro, (rank * ADD + lane * VPL) * 4, 0, kSc0);
         if (VPL == 2)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1), ro, (rank * ADD + lane * 2 + 1) * 4, 0, kSc0);
@@ -1300,32 +1258,6 @@ __device__ __forceinline__ void lsh_head_body(
             // split hash: every member is past the exchange -- the next launch gets a new sequence number
             if (aa.xseq != nullptr) __hip_atomic_fetch_add(aa.xseq + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            mr[u] = -INFINITY;
-            zr[u] = 0.f;
-            oa[u] = 0.f;
-            ob[u] = 0.f;
-            cr[u] = 0;
-            if (u < nmem) {
-                mr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, u * 8, 0, kSc0));
-                zr[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, u * 8 + 4, 0, kSc0));
-                oa[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (u * ADD + lane * VPL) * 4, 0, kSc0));
-                if (VPL == 2)
-                    ob[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (u * ADD + lane * 2 + 1) * 4, 0, kSc0));
-                cr[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rc, u * 4, 0, kSc0);
-            }
-        }
-        // (checked AFTER all loads are in flight: a use inside the loop made every member's loads wait for the
-        // previous member's -- eight dependent L2 round trips, ~1 us of the merger's 2)
-        bool misplaced = false;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            // a member on another XCD (a placement the host did not observe): its partial may be stale in this L2
-            if (u < nmem) misplaced = misplaced || ((uint32_t)cr[u] >> 24) != my_xcc;
-            cr[u] &= 0xffffff;
-        }
-        if (lane == 0 && misplaced) atomicOr(aa.err, 4);
     } else {
         __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + lane * VPL),
                            __float_as_uint(o0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1336,7 +1268,7 @@ __device__ __forceinline__ void lsh_head_body(
             __hip_atomic_store(reinterpret_cast<unsigned long long*>(aa.part_ml + pre + rank),
                                (unsigned long long)__float_as_uint(m) | ((unsigned long long)__float_as_uint(Z) << 32),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(aa.part_cnt + h * 8 + rank, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(aa.part_cnt + h * CLUSTER_MAX + rank, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
@@ -1348,47 +1280,82 @@ __device__ __forceinline__ void lsh_head_body(
             return;
         }
         if (lane == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the last arriver merges the R records in rank order (bit-identical whoever merges).  Lane u < R reads member
+    // u's (m, Z, count) -- one round of loads for any R up to 32 -- and every lane reads its two elements of all R
+    // partial outputs with ONE 8-byte load per member; everything is requested before anything is used (a use inside
+    // the loading loop made every member's loads wait for the previous member's: R dependent L2 round trips).  The
+    // scales exp(m_u - max) are computed once, by lane u, and broadcast with v_readlane.
+    float mm = -INFINITY, ZZ = 0.f, q0 = 0.f, q1 = 0.f;
+    int csum = 0;
+    auto merge_records = [&](auto n_tag) {
+        constexpr int NM = decltype(n_tag)::value;                    // 8, 16 or 32 >= nmem: loads past nmem re-read member 0
+        const int lu = lane < nmem ? lane : 0;
+        float m_u, z_u;
+        int c_u;
+        float oa[NM], ob[NM];
+        if (aa.same_xcd) {
+            constexpr int kSc0 = 1;
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+                aa.part_o + pre * ADD, 0, (int)(aa.maxs * ADD * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<float*>(aa.part_ml + pre), 0, (int)(aa.maxs * 8), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(aa.part_cnt + h * CLUSTER_MAX, 0,
+                                                                                CLUSTER_MAX * 4, 0x00020000);
+            m_u = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, lu * 8, 0, kSc0));
+            z_u = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, lu * 8 + 4, 0, kSc0));
+            c_u = (int)__builtin_amdgcn_raw_buffer_load_b32(rc, lu * 4, 0, kSc0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            mr[u] = -INFINITY;
-            zr[u] = 0.f;
-            oa[u] = 0.f;
-            ob[u] = 0.f;
-            cr[u] = 0;
-            if (u < nmem) {
-                const unsigned long long pk = __hip_atomic_load(
-                    reinterpret_cast<unsigned long long*>(aa.part_ml + pre + u), __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT);
-                mr[u] = __uint_as_float((uint32_t)pk);
-                zr[u] = __uint_as_float((uint32_t)(pk >> 32));
+            for (int u = 0; u < NM; ++u) {
+                const int uu = u < nmem ? u : 0;
+                oa[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (uu * ADD + lane * VPL) * 4, 0, kSc0));
+                ob[u] = VPL == 2 ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (uu * ADD + lane * 2 + 1) * 4, 0, kSc0))
+                                 : 0.f;
+            }
+        } else {
+            const unsigned long long pk = __hip_atomic_load(
+                reinterpret_cast<unsigned long long*>(aa.part_ml + pre + lu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m_u = __uint_as_float((uint32_t)pk);
+            z_u = __uint_as_float((uint32_t)(pk >> 32));
+            c_u = __hip_atomic_load(aa.part_cnt + h * CLUSTER_MAX + lu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < NM; ++u) {
+                const int uu = u < nmem ? u : 0;
                 oa[u] = __uint_as_float(__hip_atomic_load(
-                    reinterpret_cast<unsigned int*>(aa.part_o + (pre + u) * ADD + lane * VPL), __ATOMIC_RELAXED,
+                    reinterpret_cast<unsigned int*>(aa.part_o + (pre + uu) * ADD + lane * VPL), __ATOMIC_RELAXED,
                     __HIP_MEMORY_SCOPE_AGENT));
-                if (VPL == 2)
-                    ob[u] = __uint_as_float(__hip_atomic_load(
-                        reinterpret_cast<unsigned int*>(aa.part_o + (pre + u) * ADD + lane * 2 + 1), __ATOMIC_RELAXED,
-                        __HIP_MEMORY_SCOPE_AGENT));
-                cr[u] = __hip_atomic_load(aa.part_cnt + h * 8 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ob[u] = VPL == 2 ? __uint_as_float(__hip_atomic_load(
+                                       reinterpret_cast<unsigned int*>(aa.part_o + (pre + uu) * ADD + lane * 2 + 1),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                 : 0.f;
             }
         }
-    }
-    float mm = -INFINITY;
-    int csum = 0;
+        if (lane >= nmem) {
+            m_u = -INFINITY;
+            z_u = 0.f;
+            c_u = 0;
+        }
+        // a member on another XCD (a placement the host did not observe): its partial may be stale in this L2
+        if (aa.same_xcd) {
+            const bool off = lane < nmem && ((uint32_t)c_u >> 24) != my_xcc;
+            if (__ballot(off) != 0ull && lane == 0) atomicOr(aa.err, 4);
+        }
+        c_u &= 0xffffff;
+        mm = wave_max(m_u);
+        const float e_u = (m_u != -INFINITY) ? __expf(m_u - mm) : 0.f;   // a member without tokens: weight 0
+        const float ez_u = e_u * z_u;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        mm = fmaxf(mm, mr[u]);
-        csum += cr[u];
-    }
-    float ZZ = 0.f, q0 = 0.f, q1 = 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        if (u < nmem && mr[u] != -INFINITY) {
-            const float e = __expf(mr[u] - mm);
-            ZZ = fmaf(e, zr[u], ZZ);
+        for (int u = 0; u < NM; ++u) {
+            const float e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_u), u));     // 0 past nmem
+            ZZ += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ez_u), u));
+            csum += __builtin_amdgcn_readlane(c_u, u);
             q0 = fmaf(e, oa[u], q0);
             q1 = fmaf(e, ob[u], q1);
         }
-    }
+    };
+    if (nmem <= 8) merge_records(std::integral_constant<int, 8>{});
+    else if (nmem <= 16) merge_records(std::integral_constant<int, 16>{});
+    else merge_records(std::integral_constant<int, 32>{});
     attn_head_finalize<ADD>(mm, ZZ, q0, q1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);   // ZZ = 0: no member had a token
     if (lane == 0) nnz[h] = csum;
     MP_STAMP(stamp, 39);
@@ -1420,20 +1387,19 @@ __global__ __launch_bounds__(RT_THREADS, 4) void lsh_decode_kernel(
                                      idbits, ha, aa, stamp);
 }
 
-// The decode kernel leaves the logits of wave w of member r at column r * range_len + w * wave_tokens of the head's
-// score row (wave_cnt[h][r][w] of them); this moves the 16 R segments of every row down into one contiguous list
-// (get_score's `ind` order: ascending token ids).  One workgroup per head; a segment only ever moves to lower
-// addresses, chunk by chunk (read, barrier, write, barrier).
+// The decode kernel leaves member r's selected ids / logits at column r * range_len of the head's row; this
+// moves the R segments of every row down into one contiguous list (get_score's `ind` order).  One workgroup
+// per head; a segment only ever moves to lower addresses, chunk by chunk (read, barrier, write, barrier).
 __global__ __launch_bounds__(1024) void lsh_compact_segments_kernel(uint32_t* __restrict__ rows,
-                                                                   const int* __restrict__ wave_cnt, int R,
-                                                                   int range_len, int wave_tokens, int64_t M) {
+                                                                   const int* __restrict__ part_cnt, int R,
+                                                                   int range_len, int64_t M) {
     const int64_t h = blockIdx.x;
     uint32_t* row = rows + h * M;
-    int off = 0;
-    for (int seg = 0; seg < R * RT_WAVES; ++seg) {
-        const int cnt = wave_cnt[h * R * RT_WAVES + seg];
-        const int64_t src = (int64_t)(seg / RT_WAVES) * range_len + (int64_t)(seg % RT_WAVES) * wave_tokens;
-        if (cnt > 0 && off != src) {
+    int off = part_cnt[h * CLUSTER_MAX] & 0xffffff;   // bits 24+ : the XCD a member reported (same-XCD hand-off)
+    for (int r = 1; r < R; ++r) {
+        const int cnt = part_cnt[h * CLUSTER_MAX + r] & 0xffffff;
+        const int64_t src = (int64_t)r * range_len;
+        if (off != src) {
             for (int base = 0; base < cnt; base += blockDim.x) {
                 const int j = base + threadIdx.x;
                 const uint32_t v = (j < cnt) ? row[src + j] : 0u;
@@ -1526,12 +1492,21 @@ hipError_t launch_lsh_subbounds(const int32_t* table, int32_t* bounds, int rows,
     return hipGetLastError();
 }
 
+// words per direct slot (log2) for a head split over R token ranges: 128-byte slots (30 ids) while the mean piece
+// M / (NB R) is above 5 ids, 64-byte slots (14 ids) above 2.5, 32-byte slots (6 ids) below -- a slot should hold a piece
+// of ~2.5x the mean (SimHash buckets are wider than Poisson: p99 of a probed piece at cfg 1 is 2.3x its mean)
+int lsh_slot_log2(int64_t M, int NB, int R) {
+    const double mean = (double)M / ((double)NB * (double)R);
+    return mean > 5.0 ? 5 : (mean > 2.5 ? 4 : 3);
+}
+
 hipError_t launch_lsh_slots(const int32_t* table, const int32_t* bounds, int32_t* slots, int rows, int NB, int R,
                             int64_t M, hipStream_t st) {
     if (R <= 1 || slots == nullptr) return hipSuccess;
     int gx = (NB * R + 31) / 32;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(lsh_slots_kernel, dim3(gx, rows), dim3(256), 0, st, table, bounds, slots, NB, R, M);
+    hipLaunchKernelGGL(lsh_slots_kernel, dim3(gx, rows), dim3(256), 0, st, table, bounds, slots, NB, R, M,
+                       lsh_slot_log2(M, NB, R));
     return hipGetLastError();
 }
 
@@ -1757,7 +1732,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                              const uint16_t* Wk, const float* wnorm, int D, int K, int KLpad,
                              int32_t* codes_out, float* qnorm_out, int32_t* results, int32_t* nnz,
                              const uint16_t* kv, const float* kn, float* part_o, float2* part_ml, int* part_cnt,
-                             int* wave_cnt, int* head_cnt, uint16_t* out, float* mve, float2* head_mz, const int32_t* slots,
+                             int* head_cnt, uint16_t* out, float* mve, float2* head_mz, const int32_t* slots,
                              float* score, int* err, int maxs, int R, bool same_xcd, const uint16_t* win_kv,
                              const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
                              bool codes_given, unsigned long long* xw, unsigned int* xseq, int xwords, int xmode,
@@ -1770,7 +1745,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     if (e != hipSuccess) return e;
     int clog = 0;
     while ((1 << clog) < R) ++clog;
-    if ((1 << clog) != R || R > 8) return hipErrorInvalidValue;
+    if ((1 << clog) != R || R > CLUSTER_MAX) return hipErrorInvalidValue;
     const int BHp = clog > 0 ? (BH + 7) & ~7 : BH;
     const bool sx = same_xcd && clog > 0 && xcd_round_robin_verified();
     HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
@@ -1778,7 +1753,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     // cluster share an XCD (sx) and every unit of 64 planes finds a wave (K*L <= 1024 R)
     const bool split_hash = xmode != 0 && sx && xw != nullptr && xseq != nullptr && !codes_given &&
                             ((K * L + 63) / 64) <= (RT_WAVES << clog) && 2 * ((K * L + 63) / 64) <= xwords;
-    AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, wave_cnt, head_cnt, out, mve, head_mz, slots, score, err, BH, BHp, maxs,
+    AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, slots, lsh_slot_log2(M, NB, R), score, err, BH, BHp, maxs,
                    DECODE_ID_CAP, clog, sx ? 1 : 0, split_hash ? xw : nullptr, split_hash ? xseq : nullptr, xwords, xmode, nullptr, idbits_dev, nullptr, nullptr,
                    win_kv, win_len, win_M};
     const dim3 grid((unsigned)BHp << clog);
@@ -1819,12 +1794,10 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     return hipErrorInvalidValue;
 }
 
-// tokens a wave of a decode workgroup owns (the last waves of a range may own fewer, or none)
-int lsh_wave_tokens(int64_t M, int R) { return ((lsh_range_len(M, R) / 32 + RT_WAVES - 1) / RT_WAVES) * 32; }
-
-hipError_t launch_lsh_compact(uint32_t* rows, const int* wave_cnt, int BH, int R, int64_t M, hipStream_t st) {
-    hipLaunchKernelGGL(lsh_compact_segments_kernel, dim3(BH), dim3(1024), 0, st, rows, wave_cnt, R,
-                       lsh_range_len(M, R), lsh_wave_tokens(M, R), M);
+hipError_t launch_lsh_compact(uint32_t* rows, const int* part_cnt, int BH, int R, int64_t M, hipStream_t st) {
+    if (R <= 1) return hipSuccess;
+    hipLaunchKernelGGL(lsh_compact_segments_kernel, dim3(BH), dim3(1024), 0, st, rows, part_cnt, R,
+                       lsh_range_len(M, R), M);
     return hipGetLastError();
 }
 

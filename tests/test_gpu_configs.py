@@ -447,9 +447,12 @@ def test_full_size_fused_decode_on_non_isotropic_keys(mp, cfg, data):
 
 # ------------------------------------------------------------------ BASELINE cfg 4 (per-GPU share) at full size
 
-def test_cfg4_full_size_fused_decode_properties(mp):
+@pytest.mark.parametrize("cluster", [32, 16, 8])
+def test_cfg4_full_size_fused_decode_properties(mp, cluster):
     """BASELINE cfg 4's per-GPU share (Llama-3.1-70B, TP = 8: H = 8, Hkv = 1, P = 131 072 -> n = 131 004,
-    M = 131 264, K = 11, L = 300: NB = 2048, U = 52 units of the split hash over 8 members, the wide direct pass),
+    M = 131 264, K = 11, L = 300: NB = 2048, U = 52 units of the split hash over the members, the wide direct pass),
+    with clusters of 32 (the default since round 4: all 256 CUs, 32-byte direct slots), 16 (64-byte slots) and 8
+    (round 3: 64 of 256 CUs, 128-byte slots) workgroups per query head,
     one layer, through size-independent properties: (1) the one-launch entry equals hash -> batch_retrieve ->
     attention_wrapper on the same stores (codes and nnz bit for bit, outputs up to summation order); (2) the selected
     sets are exactly {tokens colliding in >= 2 tables}, recounted densely from the stored key codes; (3) V -> 2 V
@@ -467,8 +470,15 @@ def test_cfg4_full_size_fused_decode_properties(mp):
     kc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
     vc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
     q = torch.randn((B, H, 1, D), device=dev, generator=gen)
-    mk = lambda: mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, max_length=M, dense_layers=(),  # noqa: E731
-                                        hash_func=W, generation_buffer=8)
+    def mk():
+        if cluster != 32:                       # 32 is what the library picks for this shape on its own
+            L_.set_option("decode_cluster", cluster)
+        try:
+            return mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, max_length=M, dense_layers=(),
+                                          hash_func=W, generation_buffer=8)
+        finally:
+            L_.set_option("decode_cluster", 0)
+
     server = mk()
     server.fill(0, 0, kc, vc, P)
     kcodes = server.hash_code_buffer.clone()                                     # int16 [Hkv, L, n]
@@ -478,7 +488,7 @@ def test_cfg4_full_size_fused_decode_properties(mp):
     j = torch.randint(0, n, (H,), device=dev, generator=gen)
     q[0, ::2, 0] = 0.5 * q[0, ::2, 0] + 3.0 * kcen[0, 0, j[::2]].float()
     q = q.to(torch.bfloat16)
-    assert server.lsh_retriever.R == 8
+    assert server.lsh_retriever.R == cluster
     out, lse = server.decode(q, 0)
     out, lse, nz1 = out.clone().reshape(BH, D), lse.clone().reshape(-1), server.nnz.clone()
     server.attn_server.check()

@@ -798,23 +798,31 @@ def test_fused_decode_unusual_shapes_equal_two_kernel_path(mp, B, H, Hkv, D, K, 
 
 
 @pytest.mark.parametrize("direct", [1, 0])
-@pytest.mark.parametrize("K,L,n,M", [(4, 30, 6000, 6144),      # 16 buckets: every piece overflows its 31-id slot
-                                     (6, 75, 6000, 6144),      # mean piece 12 ids: a mix of both
-                                     (10, 150, 20000, 20480)]) # mean piece 2.5 ids: slots only
-def test_fused_decode_direct_slots_and_overflow(mp, K, L, n, M, direct):
-    """R = 8 workgroups per head with the direct piece slots forced on (also where pieces are far longer than a
-    slot: the rest of such a piece comes through the sub-bounds + chunk pool) and forced off (sub-bounds only),
-    against hash -> batch_retrieve -> attention_wrapper on the same stores: same nnz, same ids, outputs equal up
-    to summation order."""
+@pytest.mark.parametrize("K,L,n,M,cluster", [
+    (4, 30, 6000, 6144, 8),        # 16 buckets: every piece overflows its 30-id slot
+    (6, 75, 6000, 6144, 8),        # mean piece 12 ids: a mix of both
+    (10, 150, 20000, 20480, 8),    # mean piece 2.5 ids: 32-byte slots (6 ids)
+    (6, 75, 6000, 6144, 16),       # 16 workgroups per head: mean piece 6 ids in 128-byte slots
+    (7, 300, 6000, 6144, 16),      # mean piece 3: 64-byte slots (14 ids), L = 300 in one round of five loads per wave
+    (4, 30, 6000, 6144, 32),       # 32 workgroups per head, 16 buckets: 12-id pieces overflow the chunk pool's way in
+    (8, 150, 20000, 20480, 32),    # mean piece 2.5 ids: 32-byte slots, 32 members
+    (11, 300, 20000, 20480, 32)])  # cfg 4's K and L: 52 hash units over 32 members, mean piece 0.3 ids
+def test_fused_decode_direct_slots_and_overflow(mp, K, L, n, M, cluster, direct):
+    """R = 8 / 16 / 32 workgroups per head with the direct piece slots (128, 64 or 32 bytes by the mean piece length)
+    forced on (also where pieces are far longer than a slot: the rest of such a piece comes through the sub-bounds +
+    chunk pool) and forced off (sub-bounds only), against hash -> batch_retrieve -> attention_wrapper on the same
+    stores: same nnz, same ids, outputs equal up to summation order."""
     import magicpig_amd._lib as L_
 
     B, H, Hkv, D = 1, 8, 2, 128
     L_.set_option("decode_direct", direct)
+    L_.set_option("decode_cluster", cluster)
     try:
         server, _ = _fused_server(mp, B, H, Hkv, n, M, D, K, L, 3000 + K)
     finally:
         L_.set_option("decode_direct", -1)
-    assert server.lsh_retriever.R == 8
+        L_.set_option("decode_cluster", 0)
+    assert server.lsh_retriever.R == cluster
     BH = B * H
     gen = torch.Generator(device="cuda").manual_seed(K * L + direct)
     for it in range(3):
