@@ -74,6 +74,8 @@ hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, 
 bool lsh_hash_only_supported(int L);
 hipError_t launch_attn_ticket_check(int*, int, int*, hipStream_t);
 hipError_t launch_relay(const void*, void*, size_t, hipStream_t);
+hipError_t launch_export_rows(const int32_t*, const int32_t*, int32_t*, int32_t*, unsigned long long*, int, int64_t,
+                              hipStream_t);
 hipError_t launch_host_rows(const int32_t*, const int32_t*, int32_t*, int64_t, int, const void*, void*, size_t, int,
                             hipStream_t);
 
@@ -285,8 +287,19 @@ struct mp_lsh {
     unsigned long long* xw = nullptr;   // [BH][xwords] split hash: (launch sequence << 32 | 32 sign bits) (R > 1)
     unsigned int* xseq = nullptr;  // [BH] split hash: sequence number of the next launch
     int xwords = 0;
-    Stage small, big;              // host-buffer mode: (codes | nnz | offsets) and the packed result rows
+    Stage small, big;              // host-buffer mode: (codes | nnz | offsets | row checksums) and the packed result rows
     HostMap hostmap;               // host-buffer mode: caller buffers the kernels use in place
+    // host-buffer mode: what the last MP_MEM_HOST batch_retrieve handed to its caller -- the caller's pointers, the counts
+    // and a position-weighted checksum of every row -- while `results` / `nnz` (HBM) still hold the same rows.  The
+    // attention entry of the paired store recognises the `ind` / `nnz` it is given by them and reads the HBM copy instead
+    // of uploading the rows it was just handed (models/attnserver.py:299-300 passes results_lsh_cpu straight on).
+    struct HostRetrieve {
+        bool valid = false;
+        const void* results = nullptr;
+        const void* nnz = nullptr;
+        std::vector<int32_t> nnzv;
+        std::vector<unsigned long long> sums;
+    } host_ret;
     int32_t* last_query = nullptr; // [BH][L] staging copy of host-side query codes
     const int32_t* lastq = nullptr;// device codes of the last retrieve (for get_mask): last_query,
                                    // `codes`, or the caller's own device buffer (valid until it changes)
@@ -332,6 +345,23 @@ struct mp_attn {
     bool xcd_rr = false;           // block b -> XCD b % 8 observed on this device (xcd_round_robin_verified)
     int cus = 256;
 };
+
+// the lsh handle whose last MP_MEM_HOST batch_retrieve is still described by its host_ret (nullptr: none); written
+// by that handle's calls, read by the attention entry.  Handles are not thread-safe (as the reference's objects);
+// the mutex only keeps a destroy on another thread from racing the lookup.
+static std::mutex g_host_ret_mu;
+static mp_lsh_t* g_host_ret_lsh = nullptr;
+static void host_ret_forget(mp_lsh_t* h) {
+    std::lock_guard<std::mutex> lock(g_host_ret_mu);
+    if (h) h->host_ret.valid = false;
+    if (g_host_ret_lsh == h) g_host_ret_lsh = nullptr;
+}
+// position-weighted checksum of the first n entries of a row: what export_rows_kernel computes on the device
+static unsigned long long host_row_sum(const int32_t* row, int64_t n) {
+    unsigned long long s = 0ull;
+    for (int64_t j = 0; j < n; ++j) s += (unsigned long long)(uint32_t)(row[j] + 1) * (unsigned long long)(j + 1);
+    return s;
+}
 
 extern "C" {
 
@@ -456,6 +486,7 @@ int mp_lsh_create(mp_lsh_t** out) {
 }
 
 static void lsh_free(mp_lsh_t* h) {
+    host_ret_forget(h);
     for (auto p : h->bounds) if (p) (void)hipFree(p);
     for (auto p : h->table) if (p) (void)hipFree(p);
     for (auto p : h->slots) if (p) (void)hipFree(p);
@@ -710,13 +741,15 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     // host callers (models/attnserver.py:299 passes CPU tensors).  Zero copy: the kernel reads the codes from the handle's
     // pinned block and writes the ids straight into the caller's `results` rows (mapped once, HostMap) and the counts
     // into the pinned block: ONE launch, ONE synchronisation, no copy engine.
-    int rc = h->small.reserve(qb + (size_t)(2 * BH + 1) * 4);
+    host_ret_forget(h);                                   // the step buffers are about to be rewritten
+    const size_t o_codes = (size_t)(2 * BH + 1) * 4, o_sums = (o_codes + qb + 7) & ~(size_t)7;
+    int rc = h->small.reserve(o_sums + (size_t)BH * 8);
     if (rc) return rc;
     if (g_opt.host_zero_copy.load() != 0 && h->small.hd != nullptr) {
         const size_t rbytes = (size_t)BH * h->M * 4;
         void* res_dev = h->hostmap.resolve(results, rbytes, g_opt.host_register.load() != 0);
         bool mirror = false;
-        if (res_dev == nullptr) {                 // pageable `results`: the kernel writes the handle's pinned mirror
+        if (res_dev == nullptr) {                 // pageable `results`: the rows go to the handle's pinned mirror
             rc = h->big.reserve(rbytes, true);
             if (rc) return rc;
             res_dev = h->big.hd;
@@ -725,14 +758,17 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
         if (res_dev != nullptr) {
             char* hp = reinterpret_cast<char*>(h->small.hp);
             char* hd = reinterpret_cast<char*>(h->small.hd);
-            const size_t o_codes = (size_t)(2 * BH + 1) * 4;
             memcpy(hp + o_codes, query, qb);
             h->lastq = reinterpret_cast<const int32_t*>(hd + o_codes);      // (get_mask reads them again)
             h->last_layer = layer_id;
+            // the retrieve writes its rows and counts to HBM (the handle's step buffers); a second launch brings the live
+            // entries, the counts and a checksum per row across PCIe with coalesced stores: ONE synchronisation
             MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id],
-                                             reinterpret_cast<const int32_t*>(hd + o_codes),
-                                             reinterpret_cast<int32_t*>(res_dev), reinterpret_cast<int32_t*>(hd), BH,
+                                             reinterpret_cast<const int32_t*>(hd + o_codes), h->results, h->nnz, BH,
                                              h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, st));
+            MP_HIP_CHECK(launch_export_rows(h->results, h->nnz, reinterpret_cast<int32_t*>(res_dev),
+                                            reinterpret_cast<int32_t*>(hd), reinterpret_cast<unsigned long long*>(hd + o_sums),
+                                            BH, h->M, st));
             MP_HIP_CHECK(hipStreamSynchronize(st));
             memcpy(nnz, hp, (size_t)BH * 4);
             if (mirror) {                         // only the first nnz[h] entries of a row mean anything
@@ -742,6 +778,16 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
                     z = z < 0 ? 0 : (z > h->M ? h->M : z);
                     if (z > 0) memcpy(results + (size_t)i * h->M, rows + (size_t)i * h->M, (size_t)z * 4);
                 }
+            }
+            {   // remember what was handed out: the attention entry of the paired store may be given these very rows
+                std::lock_guard<std::mutex> lock(g_host_ret_mu);
+                h->host_ret.results = results;
+                h->host_ret.nnz = nnz;
+                h->host_ret.nnzv.assign(nnz, nnz + BH);
+                const unsigned long long* sums = reinterpret_cast<const unsigned long long*>(hp + o_sums);
+                h->host_ret.sums.assign(sums, sums + BH);
+                h->host_ret.valid = true;
+                g_host_ret_lsh = h;
             }
             return MP_OK;
         }
@@ -1164,6 +1210,43 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
     }
     offs[BH] = (int32_t)total;
     MP_REQUIRE(total <= (size_t)INT32_MAX, MP_ERR_UNSUPPORTED, std::string(who) + ": more than 2^31 index entries in one call");
+    // The rows a paired LSH handle has just handed out (round 4).  The reference's caller passes the `results` /
+    // `nnz` of batch_retrieve straight on as `ind` / `nnz` (models/attnserver.py:299-300); the handle that produced them
+    // still holds the same rows in HBM.  They are recognised by the caller's pointers, the counts and a position-weighted
+    // checksum of every live row computed on both sides -- a caller that edited `ind` in between is served its edit
+    // through the upload below -- and then only (q | qn) cross PCIe: no index upload, no second copy of the rows.
+    if (!dense && g_opt.host_zero_copy.load() != 0 && h->small.hd != nullptr) {
+        mp_lsh_t* l = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_host_ret_mu);
+            l = g_host_ret_lsh;
+            if (l != nullptr && !(l->host_ret.valid && l->allocated && l->device == h->device && l->B * l->H == BH &&
+                                  l->M == h->M && l->host_ret.results == ind && l->host_ret.nnz == nnz &&
+                                  memcmp(l->host_ret.nnzv.data(), nnz, (size_t)BH * 4) == 0))
+                l = nullptr;
+        }
+        if (l != nullptr) {
+            for (int i = 0; i < BH && l != nullptr; ++i) {
+                int64_t z = nnz[i];
+                z = z < 0 ? 0 : (z > h->M ? h->M : z);
+                if (host_row_sum(ind + (size_t)i * h->M, z) != l->host_ret.sums[i]) l = nullptr;
+            }
+        }
+        if (l != nullptr) {
+            char* hd = reinterpret_cast<char*>(h->small.hd);
+            MP_HIP_CHECK(launch_relay(hd, dp, o_nnz, st));                   // (q | qn)
+            // the counts outlive the lsh handle's next call (get_score reads them later)
+            MP_HIP_CHECK(hipMemcpyAsync(h->last_nnz, l->nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));
+            rc = attn_run(h, layer_id, false, K, L, reinterpret_cast<uint16_t*>(hd + o_out),
+                          reinterpret_cast<float*>(hd + o_mve), dp + o_q, query_dtype,
+                          reinterpret_cast<const float*>(dp + o_qn), l->results, h->last_nnz, st);
+            if (rc) return rc;
+            MP_HIP_CHECK(hipStreamSynchronize(st));
+            memcpy(output, hp + o_out, (size_t)BH * h->D * 2);
+            memcpy(mve, hp + o_mve, (size_t)2 * BH * 4);
+            return MP_OK;
+        }
+    }
     // Zero copy: ONE launch brings (q | qn | nnz) and the first nnz[h] entries of every index row into HBM with
     // coalesced reads over PCIe -- straight from the caller's rows where they are pinned (or registered on request,
     // HostMap), else from the handle's pinned block, into which the host packs the live entries -- and the attention
@@ -1415,6 +1498,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
     MP_REQUIRE(layer_id >= 0 && layer_id < lsh->layers && layer_id < attn->layers, MP_ERR_INVALID,
                w + ": layer_id out of range");
     const int BH = lsh->B * lsh->H;
+    host_ret_forget(lsh);                                  // the fused entry rewrites the handle's step buffers
     lsh->lastq = lsh->codes;
     lsh->last_layer = layer_id;
     const bool two_launch = g_opt.decode_two_launch.load() != 0;                // A/B switch

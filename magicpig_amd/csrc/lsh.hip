@@ -1281,19 +1281,25 @@ __device__ __forceinline__ void lsh_head_body(
         }
         if (lane == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ---- the last arriver merges the R records in rank order (bit-identical whoever merges).  Lane u < R reads member
-    // u's (m, Z, count) -- one round of loads for any R up to 32 -- and every lane reads its two elements of all R
-    // partial outputs with ONE 8-byte load per member; everything is requested before anything is used (a use inside
-    // the loading loop made every member's loads wait for the previous member's: R dependent L2 round trips).  The
-    // scales exp(m_u - max) are computed once, by lane u, and broadcast with v_readlane.
-    float mm = -INFINITY, ZZ = 0.f, q0 = 0.f, q1 = 0.f;
+    // ---- the last arriver merges the R records (bit-identical whoever merges: the order below is fixed).  Lane u < R
+    // reads member u's (m, Z, count): one round of loads for any R up to 32, scales exp(m_u - max) computed once, by lane
+    // u.  The partial outputs: the wave's two halves take the two halves of the members, and a lane reads 16 bytes -- four
+    // elements of o -- per member of its half: R / 2 load instructions for the whole merge (round 3: two 4-byte loads per
+    // member and lane, 16 at R = 8; 64 at R = 32), all requested before anything is used.  The halves meet with one
+    // cross-half add; lanes 0 .. D/4-1 hold four consecutive elements of the head's output each.
+    float mm = -INFINITY, ZZ = 0.f;
+    float q4[4] = {0.f, 0.f, 0.f, 0.f};
     int csum = 0;
+    constexpr int QL = ADD / 4;                                       // lanes of a half that hold elements (32 or 16)
+    const int half = lane >> 5, ql = lane & 31;
     auto merge_records = [&](auto n_tag) {
-        constexpr int NM = decltype(n_tag)::value;                    // 8, 16 or 32 >= nmem: loads past nmem re-read member 0
+        constexpr int NM = decltype(n_tag)::value;                    // 2 .. 32 >= nmem, a power of two
+        constexpr int NH = NM / 2;                                    // members per half
         const int lu = lane < nmem ? lane : 0;
         float m_u, z_u;
         int c_u;
-        float oa[NM], ob[NM];
+        u32x4 ov[NH];
+        const int qc = ql < QL ? ql : 0;                              // (head_dim 64: lanes 16 .. 31 of a half re-read piece 0)
         if (aa.same_xcd) {
             constexpr int kSc0 = 1;
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
@@ -1306,11 +1312,10 @@ __device__ __forceinline__ void lsh_head_body(
             z_u = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, lu * 8 + 4, 0, kSc0));
             c_u = (int)__builtin_amdgcn_raw_buffer_load_b32(rc, lu * 4, 0, kSc0);
 #pragma unroll
-            for (int u = 0; u < NM; ++u) {
+            for (int i = 0; i < NH; ++i) {
+                const int u = half * NH + i;
                 const int uu = u < nmem ? u : 0;
-                oa[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (uu * ADD + lane * VPL) * 4, 0, kSc0));
-                ob[u] = VPL == 2 ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (uu * ADD + lane * 2 + 1) * 4, 0, kSc0))
-                                 : 0.f;
+                ov[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, (uu * ADD + qc * 4) * 4, 0, kSc0);
             }
         } else {
             const unsigned long long pk = __hip_atomic_load(
@@ -1319,15 +1324,13 @@ __device__ __forceinline__ void lsh_head_body(
             z_u = __uint_as_float((uint32_t)(pk >> 32));
             c_u = __hip_atomic_load(aa.part_cnt + h * CLUSTER_MAX + lu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int u = 0; u < NM; ++u) {
+            for (int i = 0; i < NH; ++i) {
+                const int u = half * NH + i;
                 const int uu = u < nmem ? u : 0;
-                oa[u] = __uint_as_float(__hip_atomic_load(
-                    reinterpret_cast<unsigned int*>(aa.part_o + (pre + uu) * ADD + lane * VPL), __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT));
-                ob[u] = VPL == 2 ? __uint_as_float(__hip_atomic_load(
-                                       reinterpret_cast<unsigned int*>(aa.part_o + (pre + uu) * ADD + lane * 2 + 1),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                                 : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    ov[i][e] = __hip_atomic_load(reinterpret_cast<unsigned int*>(aa.part_o + (pre + uu) * ADD + qc * 4 + e),
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (lane >= nmem) {
@@ -1342,21 +1345,45 @@ __device__ __forceinline__ void lsh_head_body(
         }
         c_u &= 0xffffff;
         mm = wave_max(m_u);
-        const float e_u = (m_u != -INFINITY) ? __expf(m_u - mm) : 0.f;   // a member without tokens: weight 0
-        const float ez_u = e_u * z_u;
+        const float e_u = (m_u != -INFINITY) ? __expf(m_u - mm) : 0.f;   // a member without tokens (or past nmem): weight 0
+        ZZ = wave_sum(e_u * z_u);
+        csum = __builtin_amdgcn_readlane(wave_incl_scan(c_u), 63);
 #pragma unroll
-        for (int u = 0; u < NM; ++u) {
-            const float e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_u), u));     // 0 past nmem
-            ZZ += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ez_u), u));
-            csum += __builtin_amdgcn_readlane(c_u, u);
-            q0 = fmaf(e, oa[u], q0);
-            q1 = fmaf(e, ob[u], q1);
+        for (int i = 0; i < NH; ++i) {
+            const float e_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_u), i));
+            const float e_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_u), NH + i));
+            const float e = half ? e_hi : e_lo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q4[k] = fmaf(e, __uint_as_float(ov[i][k]), q4[k]);
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q4[k] += __shfl_xor(q4[k], 32);      // the two halves' members meet
     };
-    if (nmem <= 8) merge_records(std::integral_constant<int, 8>{});
+    if (nmem <= 2) merge_records(std::integral_constant<int, 2>{});
+    else if (nmem <= 4) merge_records(std::integral_constant<int, 4>{});
+    else if (nmem <= 8) merge_records(std::integral_constant<int, 8>{});
     else if (nmem <= 16) merge_records(std::integral_constant<int, 16>{});
     else merge_records(std::integral_constant<int, 32>{});
-    attn_head_finalize<ADD>(mm, ZZ, q0, q1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);   // ZZ = 0: no member had a token
+    // out = o / Z as bf16 (RNE), max_value_expsum as attn_head_finalize (sparse_attention.cc:238-239); ZZ = 0: no
+    // member had a token -> out = 0, LSE = -inf
+    {
+        const bool none = !(ZZ > 0.f);
+        if (lane < QL) {
+            uint16_t ob[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ob[k] = none ? (uint16_t)0 : f32_to_bf16_rne(q4[k] / ZZ);
+            uint2 pk;
+            pk.x = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16);
+            pk.y = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
+            reinterpret_cast<uint2*>(out_h)[lane] = pk;
+        }
+        if (lane == 0) {
+            const float mv = none ? -INFINITY : mm * 1.4426950408889634f;
+            aa.mve[h] = mv;
+            aa.mve[aa.BH + h] = none ? -INFINITY : log2f(ZZ) + mv;
+            aa.head_mz[h] = make_float2(none ? -INFINITY : mm, none ? 0.f : ZZ);
+        }
+    }
     if (lane == 0) nnz[h] = csum;
     MP_STAMP(stamp, 39);
     MP_STAMP_FLUSH(stamp);

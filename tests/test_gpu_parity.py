@@ -314,6 +314,20 @@ def test_host_buffer_modes_agree(mp, mode, pinned):
             srv.attention_wrapper(0, K, L, h_out, h_mve, h_q, h_qn, h_res, h_nnz)
             assert torch.equal(h_out, d_out.cpu()) and torch.equal(h_mve, d_mve.cpu())
             assert torch.equal(srv.get_score().reshape(BH, M), d_probs)
+            # The attention entry recognises the rows batch_retrieve has just handed out (same pointers, counts and row
+            # checksums) and reads their HBM copy instead of uploading them.  A caller that EDITS `ind` in place between
+            # the two calls must be served its edit: one id of the longest row is replaced by a token that was not selected.
+            r = int(torch.argmax(h_nnz))
+            z = int(h_nnz[r])
+            assert z >= 2
+            other = next(t for t in range(n) if t not in set(h_res[r, :z].tolist()))
+            h_res[r, z // 2] = other
+            e_res = d_res.clone()
+            e_res[r, z // 2] = other
+            srv.attention_wrapper(0, K, L, d_out, d_mve, q, qn, e_res, d_nnz)
+            srv.attention_wrapper(0, K, L, h_out, h_mve, h_q, h_qn, h_res, h_nnz)
+            assert torch.equal(h_out, d_out.cpu()) and torch.equal(h_mve, d_mve.cpu())
+            assert not torch.equal(srv.get_score().reshape(BH, M)[r, :z], d_probs[r, :z])
         del lsh, srv                                    # (handles first: they unregister what they registered)
     finally:
         L_.set_option("host_zero_copy", 1)
