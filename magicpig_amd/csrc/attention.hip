@@ -816,40 +816,27 @@ hipError_t launch_host_rows(const int32_t* ind_host, const int32_t* nnz_host, in
                        (int)((small_bytes + 15) / 16));
     return hipGetLastError();
 }
-// host-buffer mode of batch_retrieve (round 4): the retrieve kernel writes its rows to HBM; this brings the first nnz[h]
-// entries of every row to the caller's rows as the device sees them (pinned / registered memory, or the handle's pinned
-// mirror) with coalesced stores over PCIe -- the retrieve kernel's own 4-byte stores, scattered by its popcount sweep,
-// were one PCIe write each -- and leaves nnz[h] and a position-weighted checksum of the row next to them: the attention
-// entry recognises by it that the `ind` rows it is handed ARE these rows (capi.hip: HostRetrieve) and reads the HBM copy.
-// Entries behind nnz[h] are not touched (the reference leaves them stale, lsh.cc:272-283).
-__global__ __launch_bounds__(1024) void export_rows_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ nnz,
-                                                           int32_t* __restrict__ dst_rows, int32_t* __restrict__ dst_nnz,
-                                                           unsigned long long* __restrict__ dst_sum, int64_t M) {
-    __shared__ unsigned long long s_part[16];
-    const int h = blockIdx.x;
-    const int z = nnz[h];
-    const int64_t n = z < 0 ? 0 : ((int64_t)z > M ? M : (int64_t)z);
-    const int32_t* src = rows + (int64_t)h * M;
-    int32_t* dst = dst_rows + (int64_t)h * M;
-    unsigned long long s = 0ull;
-    for (int64_t j = threadIdx.x; j < n; j += blockDim.x) {
-        const int32_t v = src[j];
-        dst[j] = v;
-        s += (unsigned long long)(uint32_t)(v + 1) * (unsigned long long)(j + 1);
-    }
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0ull;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_part[w];
-        dst_nnz[h] = z;
-        dst_sum[h] = t;
-    }
+// relay_kernel plus a second, 4-byte-granular segment (device to device): one launch for the attention entry's small
+// arguments (q | qn: pinned -> HBM) and the counts of the rows it recognised (the lsh handle's step buffer -> the store's own)
+__global__ __launch_bounds__(1024) void relay2_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16,
+                                                      const int32_t* __restrict__ src2, int32_t* __restrict__ dst2, int n4) {
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) dst2[i] = src2[i];
 }
-hipError_t launch_export_rows(const int32_t* rows, const int32_t* nnz, int32_t* dst_rows, int32_t* dst_nnz,
-                              unsigned long long* dst_sum, int BH, int64_t M, hipStream_t st) {
-    hipLaunchKernelGGL(export_rows_kernel, dim3(BH), dim3(1024), 0, st, rows, nnz, dst_rows, dst_nnz, dst_sum, M);
+hipError_t launch_relay2(const void* src, void* dst, size_t bytes, const int32_t* src2, int32_t* dst2, int n4,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(relay2_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const uint4*>(src),
+                       reinterpret_cast<uint4*>(dst), (int)((bytes + 15) / 16), src2, dst2, n4);
+    return hipGetLastError();
+}
+
+// host-buffer mode: "everything before me on this stream is done" as a word in pinned memory (capi.hip: host_wait)
+__global__ void host_flag_kernel(volatile unsigned int* flag, unsigned int value) {
+    *flag = value;
+    __threadfence_system();
+}
+hipError_t launch_host_flag(unsigned int* flag_dev, unsigned int value, hipStream_t st) {
+    hipLaunchKernelGGL(host_flag_kernel, dim3(1), dim3(1), 0, st, flag_dev, value);
     return hipGetLastError();
 }
 

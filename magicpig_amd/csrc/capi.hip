@@ -41,7 +41,7 @@ hipError_t launch_lsh_subbounds(const int32_t*, int32_t*, int, int, int, int64_t
 hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int, int32_t*, int32_t*, int*, const float*, int,
                             int, int*, bool*, hipStream_t);
 hipError_t launch_lsh_retrieve(const int32_t*, const int32_t*, const int32_t*, int32_t*, int32_t*, int,
-                               int, int, int, int64_t, int, const int*, hipStream_t);
+                               int, int, int, int64_t, int, const int*, int32_t*, uint32_t*, hipStream_t);
 hipError_t launch_lsh_attach_norms(int32_t*, const float*, int, int, int64_t, int, int*, hipStream_t);
 hipError_t launch_lsh_hash_retrieve(const int32_t*, const int32_t*, const uint16_t*, const uint16_t*,
                                     const float*, int, int, int, int32_t*, float*, int32_t*, int32_t*,
@@ -74,8 +74,8 @@ hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, 
 bool lsh_hash_only_supported(int L);
 hipError_t launch_attn_ticket_check(int*, int, int*, hipStream_t);
 hipError_t launch_relay(const void*, void*, size_t, hipStream_t);
-hipError_t launch_export_rows(const int32_t*, const int32_t*, int32_t*, int32_t*, unsigned long long*, int, int64_t,
-                              hipStream_t);
+hipError_t launch_relay2(const void*, void*, size_t, const int32_t*, int32_t*, int, hipStream_t);
+hipError_t launch_host_flag(unsigned int*, unsigned int, hipStream_t);
 hipError_t launch_host_rows(const int32_t*, const int32_t*, int32_t*, int64_t, int, const void*, void*, size_t, int,
                             hipStream_t);
 
@@ -103,6 +103,8 @@ struct DebugOptions {
     std::atomic<int> decode_kn_payload{1};   // 1: use the key norms attached to the table entries (where attached), 0: one HBM access per token
     std::atomic<int> host_zero_copy{1};      // MP_MEM_HOST calls: 1 = kernels work on pinned memory in place (the caller's, or the handle's mirror), 0 = staged copies
     std::atomic<int> host_register{0};       // 1 = a large PAGEABLE caller buffer is registered (hipHostRegister) once and used in place
+    std::atomic<int> host_flag_wait{0};      // MP_MEM_HOST calls: 1 = wait for the stream by spinning on a word a one-thread kernel
+                                             // writes to pinned memory instead of hipStreamSynchronize (A/B, EXPERIMENTS.md R4-5)
 };
 static DebugOptions g_opt;
 
@@ -120,6 +122,7 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "decode_kn_payload")) return &g_opt.decode_kn_payload;
     if (!strcmp(name, "host_zero_copy")) return &g_opt.host_zero_copy;
     if (!strcmp(name, "host_register")) return &g_opt.host_register;
+    if (!strcmp(name, "host_flag_wait")) return &g_opt.host_flag_wait;
     return nullptr;
 }
 
@@ -196,6 +199,48 @@ struct Stage {
         if (dp) (void)hipFree(dp);
         hp = dp = hd = nullptr;
         cap = 0;
+    }
+};
+
+// Host-buffer mode: waiting for the stream.  hipStreamSynchronize costs ~10 us from the kernel's end to the caller's next
+// instruction; the `host_flag_wait` option instead has a one-thread kernel write a sequence number to a pinned word behind
+// the call's launches and spins on it (PCIe posted writes of one device arrive in order: what the launches wrote to pinned
+// memory is there when the word is).  Falls back to the synchronisation after 5 ms.
+struct HostFlag {
+    unsigned int* hp = nullptr;   // pinned word
+    unsigned int* hd = nullptr;   // as the device sees it
+    unsigned int seq = 0;
+    int wait(hipStream_t st, bool spin) {
+        if (spin && hp == nullptr) {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess) {
+                hp = reinterpret_cast<unsigned int*>(p);
+                *hp = 0u;
+                void* d = nullptr;
+                if (hipHostGetDevicePointer(&d, p, 0) == hipSuccess) hd = reinterpret_cast<unsigned int*>(d);
+            }
+            if (hd == nullptr) (void)hipGetLastError();
+        }
+        if (spin && hd != nullptr) {
+            const unsigned int want = ++seq;
+            if (launch_host_flag(hd, want, st) == hipSuccess) {
+                volatile unsigned int* f = hp;
+                for (long it = 0; it < 5000000L; ++it) {          // ~5 ms
+                    if (*f == want) return MP_OK;
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        MP_HIP_CHECK(hipStreamSynchronize(st));
+        return MP_OK;
+    }
+    void release() {
+        if (hp) (void)hipHostFree(hp);
+        hp = hd = nullptr;
     }
 };
 
@@ -289,6 +334,7 @@ struct mp_lsh {
     int xwords = 0;
     Stage small, big;              // host-buffer mode: (codes | nnz | offsets | row checksums) and the packed result rows
     HostMap hostmap;               // host-buffer mode: caller buffers the kernels use in place
+    HostFlag hostflag;             // host-buffer mode: completion word (host_flag_wait)
     // host-buffer mode: what the last MP_MEM_HOST batch_retrieve handed to its caller -- the caller's pointers, the counts
     // and a position-weighted checksum of every row -- while `results` / `nnz` (HBM) still hold the same rows.  The
     // attention entry of the paired store recognises the `ind` / `nnz` it is given by them and reads the HBM copy instead
@@ -298,7 +344,7 @@ struct mp_lsh {
         const void* results = nullptr;
         const void* nnz = nullptr;
         std::vector<int32_t> nnzv;
-        std::vector<unsigned long long> sums;
+        std::vector<uint32_t> sums;        // [BH][2]: sum of (id + 1), sum of (id + 1) (position + 1), mod 2^32
     } host_ret;
     int32_t* last_query = nullptr; // [BH][L] staging copy of host-side query codes
     const int32_t* lastq = nullptr;// device codes of the last retrieve (for get_mask): last_query,
@@ -333,6 +379,7 @@ struct mp_attn {
     double* colsum = nullptr;      // [FILL_BLOCKS][Hkv*D] scratch of mp_attn_fill_offload
     Stage small, big;              // host-buffer mode: (q | qn | nnz | offsets | out | mve) and the packed index rows
     HostMap hostmap;               // host-buffer mode: caller buffers the kernels use in place
+    HostFlag hostflag;             // host-buffer mode: completion word (host_flag_wait)
     int32_t* ind_rows = nullptr;   // host-buffer mode: [BH][M] device copy of `ind`
     int32_t* last_nnz = nullptr;   // [BH] staging copy of host-side nnz
     const int32_t* lastz = nullptr;// device nnz of the last call (for get_score): last_nnz or the
@@ -356,11 +403,34 @@ static void host_ret_forget(mp_lsh_t* h) {
     if (h) h->host_ret.valid = false;
     if (g_host_ret_lsh == h) g_host_ret_lsh = nullptr;
 }
-// position-weighted checksum of the first n entries of a row: what export_rows_kernel computes on the device
-static unsigned long long host_row_sum(const int32_t* row, int64_t n) {
-    unsigned long long s = 0ull;
-    for (int64_t j = 0; j < n; ++j) s += (unsigned long long)(uint32_t)(row[j] + 1) * (unsigned long long)(j + 1);
-    return s;
+// position-weighted checksum of the first n entries of a row, two u32 sums with wrap-around -- what the retrieve kernel
+// leaves per row (lsh.hip: rowsum).  32-bit lanes on purpose: the loop vectorises (vpmulld), ~1 us for cfg 1's 49 K ids.
+#if defined(__x86_64__)
+__attribute__((target("avx2")))
+static void host_row_sum_avx2(const int32_t* row, int64_t n, uint32_t* s1, uint32_t* s2) {
+    uint32_t a = 0u, b = 0u;
+    for (int64_t j = 0; j < n; ++j) {
+        const uint32_t v = (uint32_t)row[j] + 1u;
+        a += v;
+        b += v * (uint32_t)(j + 1);
+    }
+    *s1 = a;
+    *s2 = b;
+}
+#endif
+static void host_row_sum(const int32_t* row, int64_t n, uint32_t* s1, uint32_t* s2) {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return host_row_sum_avx2(row, n, s1, s2);
+#endif
+    uint32_t a = 0u, b = 0u;
+    for (int64_t j = 0; j < n; ++j) {
+        const uint32_t v = (uint32_t)row[j] + 1u;
+        a += v;
+        b += v * (uint32_t)(j + 1);
+    }
+    *s1 = a;
+    *s2 = b;
 }
 
 extern "C" {
@@ -500,6 +570,7 @@ static void lsh_free(mp_lsh_t* h) {
     h->small.release();
     h->big.release();
     h->hostmap.release();
+    h->hostflag.release();
     h->allocated = false;
 }
 
@@ -594,8 +665,10 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
 
 // Workgroups per query head of the one-launch decode (= token ranges of the tables): spread a head over several CUs
 // while there are idle ones.  Up to 8 members: whenever B*H <= CUs / 8.  16 and 32 (round 4: cfg 4's 8 query heads per
-// GPU used 64 of the 256 CUs): only while a member still owns >= 4 096 tokens -- with fewer the chain of a member is
-// latency, not bytes, and more members only lengthen the hand-off (cfg 0's 4 288 tokens stay at 8).
+// GPU used 64 of the 256 CUs): only while a member still owns >= 8 192 tokens -- with fewer the chain of a member is
+// latency, not bytes, and more members only lengthen the hand-off.  Measured at cfg 4 (131 264 tokens, EXPERIMENTS.md
+// R4-3): 8 members 20.7 us per layer, 16 members 17.0, 32 members 17.7 (the ticket of 32 arrivals and the merge of 32
+// records cost what the shorter gather saves) -> 16; cfg 0's 4 288 tokens stay at 8.
 static int decode_cluster_size(int BH, int64_t M) {
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
@@ -609,7 +682,7 @@ static int decode_cluster_size(int BH, int64_t M) {
     if (cluster > slices) cluster = (int)slices;
     int r = 1;
     while (2 * r <= cluster) r *= 2;
-    while (forced < 1 && r > 8 && M / r < 4096) r /= 2;
+    while (forced < 1 && r > 8 && M / r < 8192) r /= 2;
     return r;
 }
 
@@ -735,7 +808,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
         h->lastq = query;
         h->last_layer = layer_id;
         MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], query, results,
-                                         nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, st));
+                                         nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, nullptr, nullptr, st));
         return MP_OK;
     }
     // host callers (models/attnserver.py:299 passes CPU tensors).  Zero copy: the kernel reads the codes from the handle's
@@ -761,15 +834,16 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
             memcpy(hp + o_codes, query, qb);
             h->lastq = reinterpret_cast<const int32_t*>(hd + o_codes);      // (get_mask reads them again)
             h->last_layer = layer_id;
-            // the retrieve writes its rows and counts to HBM (the handle's step buffers); a second launch brings the live
-            // entries, the counts and a checksum per row across PCIe with coalesced stores: ONE synchronisation
+            // ONE launch, ONE synchronisation, no copy engine: the kernel reads the codes from the pinned block, writes
+            // the ids straight into the caller's rows (pinned / registered) or the pinned mirror and the counts into the
+            // pinned block -- and leaves a second copy of the rows in HBM (the handle's step buffer) with a checksum
+            // per row, so that the attention entry of the paired store need not upload what it is handed next
             MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id],
-                                             reinterpret_cast<const int32_t*>(hd + o_codes), h->results, h->nnz, BH,
-                                             h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, st));
-            MP_HIP_CHECK(launch_export_rows(h->results, h->nnz, reinterpret_cast<int32_t*>(res_dev),
-                                            reinterpret_cast<int32_t*>(hd), reinterpret_cast<unsigned long long*>(hd + o_sums),
-                                            BH, h->M, st));
-            MP_HIP_CHECK(hipStreamSynchronize(st));
+                                             reinterpret_cast<const int32_t*>(hd + o_codes),
+                                             reinterpret_cast<int32_t*>(res_dev), reinterpret_cast<int32_t*>(hd), BH,
+                                             h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, h->results,
+                                             reinterpret_cast<uint32_t*>(hd + o_sums), st));
+            if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) return rc;
             memcpy(nnz, hp, (size_t)BH * 4);
             if (mirror) {                         // only the first nnz[h] entries of a row mean anything
                 const int32_t* rows = reinterpret_cast<const int32_t*>(h->big.hp);
@@ -784,8 +858,8 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
                 h->host_ret.results = results;
                 h->host_ret.nnz = nnz;
                 h->host_ret.nnzv.assign(nnz, nnz + BH);
-                const unsigned long long* sums = reinterpret_cast<const unsigned long long*>(hp + o_sums);
-                h->host_ret.sums.assign(sums, sums + BH);
+                const uint32_t* sums = reinterpret_cast<const uint32_t*>(hp + o_sums);
+                h->host_ret.sums.assign(sums, sums + 2 * (size_t)BH);
                 h->host_ret.valid = true;
                 g_host_ret_lsh = h;
             }
@@ -798,7 +872,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     h->lastq = h->last_query;
     h->last_layer = layer_id;
     MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], h->last_query,
-                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, st));
+                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, nullptr, nullptr, st));
     int32_t* d_offs = reinterpret_cast<int32_t*>(h->small.dp) + BH;           // dp: [nnz BH | offs BH + 1]
     MP_HIP_CHECK(launch_ragged_offsets(h->nnz, BH, h->M, d_offs, st));
     MP_HIP_CHECK(hipMemcpyAsync(h->small.dp, h->nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));
@@ -950,6 +1024,7 @@ static void attn_free(mp_attn_t* h) {
     h->small.release();
     h->big.release();
     h->hostmap.release();
+    h->hostflag.release();
     h->allocated = false;
 }
 
@@ -1229,19 +1304,21 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
             for (int i = 0; i < BH && l != nullptr; ++i) {
                 int64_t z = nnz[i];
                 z = z < 0 ? 0 : (z > h->M ? h->M : z);
-                if (host_row_sum(ind + (size_t)i * h->M, z) != l->host_ret.sums[i]) l = nullptr;
+                uint32_t s1, s2;
+                host_row_sum(ind + (size_t)i * h->M, z, &s1, &s2);
+                if (s1 != l->host_ret.sums[2 * i] || s2 != l->host_ret.sums[2 * i + 1]) l = nullptr;
             }
         }
         if (l != nullptr) {
             char* hd = reinterpret_cast<char*>(h->small.hd);
-            MP_HIP_CHECK(launch_relay(hd, dp, o_nnz, st));                   // (q | qn)
-            // the counts outlive the lsh handle's next call (get_score reads them later)
-            MP_HIP_CHECK(hipMemcpyAsync(h->last_nnz, l->nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));
+            // ONE launch for (q | qn) pinned -> HBM and the counts, which must outlive the lsh handle's next call
+            // (get_score reads them later): lsh step buffer -> this store's own
+            MP_HIP_CHECK(launch_relay2(hd, dp, o_nnz, reinterpret_cast<const int32_t*>(hd + o_nnz), h->last_nnz, BH, st));
             rc = attn_run(h, layer_id, false, K, L, reinterpret_cast<uint16_t*>(hd + o_out),
                           reinterpret_cast<float*>(hd + o_mve), dp + o_q, query_dtype,
                           reinterpret_cast<const float*>(dp + o_qn), l->results, h->last_nnz, st);
             if (rc) return rc;
-            MP_HIP_CHECK(hipStreamSynchronize(st));
+            if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) return rc;
             memcpy(output, hp + o_out, (size_t)BH * h->D * 2);
             memcpy(mve, hp + o_mve, (size_t)2 * BH * 4);
             return MP_OK;
@@ -1290,7 +1367,7 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
                           reinterpret_cast<const float*>(dp + o_qn), dense ? nullptr : h->ind_rows,
                           reinterpret_cast<const int32_t*>(dp + o_nnz), st);
             if (rc) return rc;
-            MP_HIP_CHECK(hipStreamSynchronize(st));
+            if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) return rc;
             memcpy(output, hp + o_out, (size_t)BH * h->D * 2);
             memcpy(mve, hp + o_mve, (size_t)2 * BH * 4);
             return MP_OK;                                         // (lastz = dp + o_nnz: valid until the next host call)

@@ -192,6 +192,17 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
+// wave-wide sum of u32 values with wrap-around (checksums): the same DPP ladder on unsigned arithmetic
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Exclusive prefix sum over the block's threads; `total` gets the block sum.
 // s_tmp: LDS scratch of >= blockDim.x/64 + 1 ints.  Contains two __syncthreads().
 __device__ __forceinline__ int block_excl_scan(int v, int* s_tmp, int& total) {

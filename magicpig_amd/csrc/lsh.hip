@@ -549,6 +549,10 @@ struct AttnArgs {
     const uint16_t* win_kv;  // [B*Hkv][win_M][2][D] or nullptr
     const int32_t* win_len;  // [BH]
     int64_t win_M;
+    // stand-alone retrieve, host-buffer mode (capi.hip: HostRetrieve): a second copy of the emitted rows in HBM and a
+    // position-weighted checksum (two u32 sums) per row, by which the attention entry recognises the rows it is handed
+    int32_t* rows2;          // [BH][M] or nullptr
+    uint32_t* rowsum;        // [BH][2] or nullptr
 };
 
 // HASH: 0 = the codes are given (`query`), 1 = fused SimHash prologue, 3 = the same with the planes split over the
@@ -1125,6 +1129,8 @@ __device__ __forceinline__ void lsh_head_body(
     MP_STAMP(stamp, 20);
     // AD: the member's ids stay in LDS; a list longer than the stage (cap ids) is read back from HBM
     const bool spill = AD > 0 && total > aa.cap;
+    uint32_t cs1 = 0u, cs2 = 0u;            // stand-alone retrieve: checksum of this thread's entries (host-buffer mode)
+    int32_t* out2 = (AD == 0 && aa.rows2 != nullptr) ? aa.rows2 + h * M : nullptr;
     for (int k = 0; k < wpt; ++k) {
         if (w0 + k >= nsw) break;
         uint32_t bits = bmB[w0 + k];
@@ -1134,12 +1140,30 @@ __device__ __forceinline__ void lsh_head_body(
             bits &= bits - 1;
             out[off] = base + p;
             if (AD > 0 && off < aa.cap) s_ids[off] = base + p;
+            if (AD == 0 && out2 != nullptr) {
+                out2[off] = base + p;
+                cs1 += (uint32_t)(base + p + 1);
+                cs2 += (uint32_t)(base + p + 1) * (uint32_t)(off + 1);
+            }
             ++off;
         }
     }
     if (tid == 0 && (AD == 0 || clog == 0)) nnz[h] = total;
     MP_STAMP(stamp, 21);
     if (AD == 0) {
+        if (aa.rowsum != nullptr) {         // block sum of the two u32 checksums (wrap-around arithmetic: order-free)
+            __syncthreads();                // (s_tmp is the scan's scratch)
+            if (tid < 2) s_tmp[tid] = 0;
+            __syncthreads();
+            cs1 = wave_sum_u32(cs1);
+            cs2 = wave_sum_u32(cs2);
+            if (lane == 0) {
+                atomicAdd(reinterpret_cast<unsigned int*>(&s_tmp[0]), cs1);
+                atomicAdd(reinterpret_cast<unsigned int*>(&s_tmp[1]), cs2);
+            }
+            __syncthreads();
+            if (tid < 2) aa.rowsum[h * 2 + tid] = (uint32_t)s_tmp[tid];
+        }
         MP_STAMP_FLUSH(stamp);
         return;
     }
@@ -1281,25 +1305,21 @@ __device__ __forceinline__ void lsh_head_body(
         }
         if (lane == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ---- the last arriver merges the R records (bit-identical whoever merges: the order below is fixed).  Lane u < R
-    // reads member u's (m, Z, count): one round of loads for any R up to 32, scales exp(m_u - max) computed once, by lane
-    // u.  The partial outputs: the wave's two halves take the two halves of the members, and a lane reads 16 bytes -- four
-    // elements of o -- per member of its half: R / 2 load instructions for the whole merge (round 3: two 4-byte loads per
-    // member and lane, 16 at R = 8; 64 at R = 32), all requested before anything is used.  The halves meet with one
-    // cross-half add; lanes 0 .. D/4-1 hold four consecutive elements of the head's output each.
-    float mm = -INFINITY, ZZ = 0.f;
-    float q4[4] = {0.f, 0.f, 0.f, 0.f};
+    // ---- the last arriver merges the R records in rank order (bit-identical whoever merges).  Lane u < R reads member
+    // u's (m, Z, count) -- one round of loads for any R up to 32 -- and every lane reads its two elements of all R
+    // partial outputs; everything is requested before anything is used (a use inside the loading loop made every
+    // member's loads wait for the previous member's: R dependent L2 round trips).  The scales exp(m_u - max) are computed
+    // once, by lane u, and broadcast with v_readlane.  (Measured and rejected, round 4: the wave's two halves taking half
+    // of the members each with 16-byte loads -- R / 2 load instructions instead of 2 R -- and one cross-half add: cfg 1
+    // 19.42 against 19.27 us per layer, cfg 4 at R = 16 17.23 against 16.98; EXPERIMENTS.md R4-4.)
+    float mm = -INFINITY, ZZ = 0.f, q0 = 0.f, q1 = 0.f;
     int csum = 0;
-    constexpr int QL = ADD / 4;                                       // lanes of a half that hold elements (32 or 16)
-    const int half = lane >> 5, ql = lane & 31;
     auto merge_records = [&](auto n_tag) {
-        constexpr int NM = decltype(n_tag)::value;                    // 2 .. 32 >= nmem, a power of two
-        constexpr int NH = NM / 2;                                    // members per half
+        constexpr int NM = decltype(n_tag)::value;                    // 8, 16 or 32 >= nmem: loads past nmem re-read member 0
         const int lu = lane < nmem ? lane : 0;
         float m_u, z_u;
         int c_u;
-        u32x4 ov[NH];
-        const int qc = ql < QL ? ql : 0;                              // (head_dim 64: lanes 16 .. 31 of a half re-read piece 0)
+        float oa[NM], ob[NM];
         if (aa.same_xcd) {
             constexpr int kSc0 = 1;
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
@@ -1312,10 +1332,11 @@ __device__ __forceinline__ void lsh_head_body(
             z_u = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, lu * 8 + 4, 0, kSc0));
             c_u = (int)__builtin_amdgcn_raw_buffer_load_b32(rc, lu * 4, 0, kSc0);
 #pragma unroll
-            for (int i = 0; i < NH; ++i) {
-                const int u = half * NH + i;
+            for (int u = 0; u < NM; ++u) {
                 const int uu = u < nmem ? u : 0;
-                ov[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, (uu * ADD + qc * 4) * 4, 0, kSc0);
+                oa[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (uu * ADD + lane * VPL) * 4, 0, kSc0));
+                ob[u] = VPL == 2 ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (uu * ADD + lane * 2 + 1) * 4, 0, kSc0))
+                                 : 0.f;
             }
         } else {
             const unsigned long long pk = __hip_atomic_load(
@@ -1324,13 +1345,15 @@ __device__ __forceinline__ void lsh_head_body(
             z_u = __uint_as_float((uint32_t)(pk >> 32));
             c_u = __hip_atomic_load(aa.part_cnt + h * CLUSTER_MAX + lu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int i = 0; i < NH; ++i) {
-                const int u = half * NH + i;
+            for (int u = 0; u < NM; ++u) {
                 const int uu = u < nmem ? u : 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    ov[i][e] = __hip_atomic_load(reinterpret_cast<unsigned int*>(aa.part_o + (pre + uu) * ADD + qc * 4 + e),
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                oa[u] = __uint_as_float(__hip_atomic_load(
+                    reinterpret_cast<unsigned int*>(aa.part_o + (pre + uu) * ADD + lane * VPL), __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT));
+                ob[u] = VPL == 2 ? __uint_as_float(__hip_atomic_load(
+                                       reinterpret_cast<unsigned int*>(aa.part_o + (pre + uu) * ADD + lane * 2 + 1),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                 : 0.f;
             }
         }
         if (lane >= nmem) {
@@ -1345,45 +1368,21 @@ __device__ __forceinline__ void lsh_head_body(
         }
         c_u &= 0xffffff;
         mm = wave_max(m_u);
-        const float e_u = (m_u != -INFINITY) ? __expf(m_u - mm) : 0.f;   // a member without tokens (or past nmem): weight 0
-        ZZ = wave_sum(e_u * z_u);
-        csum = __builtin_amdgcn_readlane(wave_incl_scan(c_u), 63);
+        const float e_u = (m_u != -INFINITY) ? __expf(m_u - mm) : 0.f;   // a member without tokens: weight 0
+        const float ez_u = e_u * z_u;
 #pragma unroll
-        for (int i = 0; i < NH; ++i) {
-            const float e_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_u), i));
-            const float e_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_u), NH + i));
-            const float e = half ? e_hi : e_lo;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q4[k] = fmaf(e, __uint_as_float(ov[i][k]), q4[k]);
+        for (int u = 0; u < NM; ++u) {
+            const float e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_u), u));     // 0 past nmem
+            ZZ += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ez_u), u));
+            csum += __builtin_amdgcn_readlane(c_u, u);
+            q0 = fmaf(e, oa[u], q0);
+            q1 = fmaf(e, ob[u], q1);
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) q4[k] += __shfl_xor(q4[k], 32);      // the two halves' members meet
     };
-    if (nmem <= 2) merge_records(std::integral_constant<int, 2>{});
-    else if (nmem <= 4) merge_records(std::integral_constant<int, 4>{});
-    else if (nmem <= 8) merge_records(std::integral_constant<int, 8>{});
+    if (nmem <= 8) merge_records(std::integral_constant<int, 8>{});
     else if (nmem <= 16) merge_records(std::integral_constant<int, 16>{});
     else merge_records(std::integral_constant<int, 32>{});
-    // out = o / Z as bf16 (RNE), max_value_expsum as attn_head_finalize (sparse_attention.cc:238-239); ZZ = 0: no
-    // member had a token -> out = 0, LSE = -inf
-    {
-        const bool none = !(ZZ > 0.f);
-        if (lane < QL) {
-            uint16_t ob[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ob[k] = none ? (uint16_t)0 : f32_to_bf16_rne(q4[k] / ZZ);
-            uint2 pk;
-            pk.x = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16);
-            pk.y = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
-            reinterpret_cast<uint2*>(out_h)[lane] = pk;
-        }
-        if (lane == 0) {
-            const float mv = none ? -INFINITY : mm * 1.4426950408889634f;
-            aa.mve[h] = mv;
-            aa.mve[aa.BH + h] = none ? -INFINITY : log2f(ZZ) + mv;
-            aa.head_mz[h] = make_float2(none ? -INFINITY : mm, none ? 0.f : ZZ);
-        }
-    }
+    attn_head_finalize<ADD>(mm, ZZ, q0, q1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);   // ZZ = 0: no member had a token
     if (lane == 0) nnz[h] = csum;
     MP_STAMP(stamp, 39);
     MP_STAMP_FLUSH(stamp);
@@ -1395,8 +1394,10 @@ __global__ __launch_bounds__(RT_THREADS, 4) void lsh_retrieve_kernel(
     const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
     int G, int L, int NB, int64_t M, int R, int words, int Lpad, const int* __restrict__ idbits_dev, HashArgs ha,
-    unsigned long long* __restrict__ stamp) {
-    const AttnArgs aa = {};
+    int32_t* __restrict__ rows2, uint32_t* __restrict__ rowsum, unsigned long long* __restrict__ stamp) {
+    AttnArgs aa = {};
+    aa.rows2 = rows2;
+    aa.rowsum = rowsum;
     // the layer's id width from the device word (written in stream order by a fill that widens the layer): a launch
     // argument would be frozen in a captured graph
     const int idbits = idbits_dev ? *idbits_dev : 0;
@@ -1696,14 +1697,14 @@ static hipError_t retrieve_attr_once() {
 
 hipError_t launch_lsh_retrieve(const int32_t* bounds, const int32_t* table, const int32_t* query,
                                int32_t* results, int32_t* nnz, int BH, int G, int L, int NB,
-                               int64_t M, int R, const int* idbits, hipStream_t st) {
+                               int64_t M, int R, const int* idbits, int32_t* rows2, uint32_t* rowsum, hipStream_t st) {
     const int words = (int)((M + 31) / 32);
     const int Lpad = (L + 63) & ~63;
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
     HashArgs ha = {};
     hipLaunchKernelGGL((lsh_retrieve_kernel<0, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
-                       st, bounds, table, query, results, nnz, G, L, NB, M, R, words, Lpad, idbits, ha, g_stamp);
+                       st, bounds, table, query, results, nnz, G, L, NB, M, R, words, Lpad, idbits, ha, rows2, rowsum, g_stamp);
     return hipGetLastError();
 }
 
@@ -1722,11 +1723,11 @@ hipError_t launch_lsh_hash_retrieve(const int32_t* bounds, const int32_t* table,
     if (D >= 128)
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, R, words,
-                           Lpad, idbits, ha, g_stamp);
+                           Lpad, idbits, ha, (int32_t*)nullptr, (uint32_t*)nullptr, g_stamp);
     else
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 8>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, R, words,
-                           Lpad, idbits, ha, g_stamp);
+                           Lpad, idbits, ha, (int32_t*)nullptr, (uint32_t*)nullptr, g_stamp);
     return hipGetLastError();
 }
 
@@ -1741,11 +1742,11 @@ hipError_t launch_lsh_hash_only(const uint16_t* q, const uint16_t* Wk, const flo
     if (D >= 128)
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 16>), dim3(rows), dim3(RT_THREADS), lds, st, (const int32_t*)nullptr,
                            (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 1, L,
-                           1 << K, (int64_t)0, 1, 0, Lpad, (const int*)nullptr, ha, g_stamp);
+                           1 << K, (int64_t)0, 1, 0, Lpad, (const int*)nullptr, ha, (int32_t*)nullptr, (uint32_t*)nullptr, g_stamp);
     else
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 8>), dim3(rows), dim3(RT_THREADS), lds, st, (const int32_t*)nullptr,
                            (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 1, L,
-                           1 << K, (int64_t)0, 1, 0, Lpad, (const int*)nullptr, ha, g_stamp);
+                           1 << K, (int64_t)0, 1, 0, Lpad, (const int*)nullptr, ha, (int32_t*)nullptr, (uint32_t*)nullptr, g_stamp);
     return hipGetLastError();
 }
 

@@ -447,12 +447,12 @@ def test_full_size_fused_decode_on_non_isotropic_keys(mp, cfg, data):
 
 # ------------------------------------------------------------------ BASELINE cfg 4 (per-GPU share) at full size
 
-@pytest.mark.parametrize("cluster", [32, 16, 8])
+@pytest.mark.parametrize("cluster", [16, 32, 8])
 def test_cfg4_full_size_fused_decode_properties(mp, cluster):
     """BASELINE cfg 4's per-GPU share (Llama-3.1-70B, TP = 8: H = 8, Hkv = 1, P = 131 072 -> n = 131 004,
     M = 131 264, K = 11, L = 300: NB = 2048, U = 52 units of the split hash over the members, the wide direct pass),
-    with clusters of 32 (the default since round 4: all 256 CUs, 32-byte direct slots), 16 (64-byte slots) and 8
-    (round 3: 64 of 256 CUs, 128-byte slots) workgroups per query head,
+    with clusters of 16 (the default since round 4: 128 CUs, 64-byte direct slots), 32 (all 256 CUs, 32-byte slots) and
+    8 (round 3: 64 of 256 CUs, 128-byte slots) workgroups per query head,
     one layer, through size-independent properties: (1) the one-launch entry equals hash -> batch_retrieve ->
     attention_wrapper on the same stores (codes and nnz bit for bit, outputs up to summation order); (2) the selected
     sets are exactly {tokens colliding in >= 2 tables}, recounted densely from the stored key codes; (3) V -> 2 V
@@ -471,7 +471,7 @@ def test_cfg4_full_size_fused_decode_properties(mp, cluster):
     vc = torch.randn((P, Hkv, D), device=dev, generator=gen).to(torch.bfloat16)
     q = torch.randn((B, H, 1, D), device=dev, generator=gen)
     def mk():
-        if cluster != 32:                       # 32 is what the library picks for this shape on its own
+        if cluster != 16:                       # 16 is what the library picks for this shape on its own
             L_.set_option("decode_cluster", cluster)
         try:
             return mp.LSHSparseAttnServer(1, H, Hkv, D, K=K, L=L, batch_size=B, max_length=M, dense_layers=(),

@@ -268,7 +268,7 @@ _REGISTER = pytest.param("register", marks=pytest.mark.skipif(not os.environ.get
 
 
 @pytest.mark.parametrize("pinned", [True, False])
-@pytest.mark.parametrize("mode", ["zero_copy", _REGISTER, "staged"])
+@pytest.mark.parametrize("mode", ["zero_copy", "flag_wait", _REGISTER, "staged"])
 def test_host_buffer_modes_agree(mp, mode, pinned):
     """MP_MEM_HOST calls (the unchanged caller of models/attnserver.py:299-300) give what the device-buffer calls
     give, bit for bit, whichever way the buffers cross PCIe: kernels working on the caller's PINNED tensors in place
@@ -290,6 +290,7 @@ def test_host_buffer_modes_agree(mp, mode, pinned):
     mk = (lambda t: t.pin_memory()) if pinned else (lambda t: t)
     L_.set_option("host_zero_copy", 0 if mode == "staged" else 1)
     L_.set_option("host_register", 1 if mode == "register" else 0)
+    L_.set_option("host_flag_wait", 1 if mode == "flag_wait" else 0)     # completion word in pinned memory instead of a sync
     keep = []                                           # registered buffers must outlive the handles
     try:
         for rep in range(2):
@@ -332,6 +333,7 @@ def test_host_buffer_modes_agree(mp, mode, pinned):
     finally:
         L_.set_option("host_zero_copy", 1)
         L_.set_option("host_register", 0)
+        L_.set_option("host_flag_wait", 0)
 
 
 @pytest.mark.parametrize("name", ["lsh_small", "gqa_32h"])
