@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
@@ -119,10 +120,12 @@ def mem_kind(t: torch.Tensor) -> int:
     return MEM_DEVICE if t.is_cuda else MEM_HOST
 
 
-def ptr(t) -> C.c_void_p:
+def ptr(t):
+    """Address of a tensor's storage as ctypes takes it for a c_void_p argument (a plain int: the per-call cost of
+    this layer is part of the host-buffer mode's budget, EXPERIMENTS.md R4-5), None for an absent tensor."""
     if t is None:
-        return C.c_void_p(None)
-    return C.c_void_p(t.data_ptr())
+        return None
+    return t.data_ptr()
 
 
 def current_stream(ref: torch.Tensor | None = None, device: int | None = None) -> C.c_void_p:
@@ -130,8 +133,20 @@ def current_stream(ref: torch.Tensor | None = None, device: int | None = None) -
     `ref` when it is a CUDA tensor, else on `device` (the handle's own device), else on the current one."""
     if torch.cuda.is_available():
         dev = ref.device if (ref is not None and ref.is_cuda) else device
-        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    return C.c_void_p(None)
+        if _raw_stream is not None:
+            if dev is None:
+                idx = torch.cuda.current_device()
+            elif isinstance(dev, int):
+                idx = dev
+            else:
+                idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            return _raw_stream(idx)
+        return torch.cuda.current_stream(dev).cuda_stream
+    return None
+
+
+# torch's raw current-stream lookup (one C call; torch.cuda.current_stream builds a Stream object per call)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def current_device() -> int:
@@ -144,6 +159,11 @@ def expect(t: torch.Tensor, dtype, shape, name: str, same_numel_ok: bool = False
     EXACT shape and contiguity.  same_numel_ok is for the one argument the reference's callers pass in two
     layouts of the same memory (the query: [B*H, D] at models/attnserver.py:274, [B, H, 1, D] in
     library/sparse_attention/test.py:44)."""
+    try:      # the common case first: three attribute reads
+        if (dtype is None or t.dtype is dtype) and t.shape == shape and t.is_contiguous():
+            return t
+    except AttributeError:
+        pass
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor")
     if dtype is not None and t.dtype != dtype:
@@ -156,11 +176,41 @@ def expect(t: torch.Tensor, dtype, shape, name: str, same_numel_ok: bool = False
     return t
 
 
+class ArgCache:
+    """Per-object memo of validated arguments: a call that is handed the SAME tensor objects as the last one (the
+    reference's caller passes its persistent buffers every step, models/attnserver.py:59-66, 299-300) skips the dtype /
+    shape / contiguity checks -- ~1.4 us of torch attribute reads per tensor, 27 us per layer over batch_retrieve +
+    attention_wrapper before (EXPERIMENTS.md R4-5).  Weak references: the memo keeps no caller buffer alive."""
+    __slots__ = ("_slots",)
+
+    def __init__(self):
+        self._slots = {}
+
+    def expect(self, slot: str, t, dtype, shape, name: str, same_numel_ok: bool = False):
+        r = self._slots.get(slot)
+        if r is not None and r() is t:
+            return t
+        expect(t, dtype, shape, name, same_numel_ok)
+        try:
+            self._slots[slot] = weakref.ref(t)
+        except TypeError:
+            self._slots.pop(slot, None)
+        return t
+
+
 def same_memory(*tensors) -> int:
-    kinds = {mem_kind(t) for t in tensors if t is not None}
-    if len(kinds) != 1:
+    kind = -1
+    for t in tensors:
+        if t is None:
+            continue
+        k = MEM_DEVICE if t.is_cuda else MEM_HOST
+        if kind < 0:
+            kind = k
+        elif k != kind:
+            raise ValueError("all tensors of one call must live on the same side (all CPU or all on the GPU)")
+    if kind < 0:
         raise ValueError("all tensors of one call must live on the same side (all CPU or all on the GPU)")
-    return kinds.pop()
+    return kind
 
 
 class DeviceView:

@@ -32,6 +32,7 @@ hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, co
                              bool, unsigned long long*, unsigned int*, int, int, int, const int*, const int*, const unsigned int*,
                              const unsigned int*, hipStream_t);
 hipError_t set_stamp_stride(int);
+void set_exact_norm(int);
 hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
 int lsh_slot_log2(int64_t M, int NB, int R);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
@@ -255,11 +256,14 @@ struct HostFlag {
 struct HostMap {
     struct Reg { const char* p; size_t bytes; char* dev; };
     std::vector<Reg> regs;
+    const void* last_pageable = nullptr;   // the last pointer found to be plain pageable memory (negative results only
+                                           // are remembered: treating pinned memory as pageable is merely slower)
     void* resolve(const void* ptr, size_t bytes, bool may_register) {
         const char* p = reinterpret_cast<const char*>(ptr);
         if (may_register)
             for (const Reg& r : regs)
                 if (r.p <= p && p + bytes <= r.p + r.bytes) return r.dev + (p - r.p);
+        if (!may_register && ptr == last_pageable) return nullptr;   // (the failing lookup below costs microseconds per call)
         hipPointerAttribute_t a;
         if (hipPointerGetAttributes(&a, ptr) == hipSuccess) {
             if (a.type == hipMemoryTypeHost && a.devicePointer != nullptr) return a.devicePointer;
@@ -267,7 +271,10 @@ struct HostMap {
         } else {
             (void)hipGetLastError();                               // pageable memory: "invalid value" on older runtimes
         }
-        if (!may_register || bytes < (256u << 10)) return nullptr;
+        if (!may_register || bytes < (256u << 10)) {
+            last_pageable = ptr;
+            return nullptr;
+        }
         if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterMapped) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;
@@ -1448,6 +1455,10 @@ int mp_debug_xcd_round_robin(void) { return xcd_round_robin_verified() ? 1 : 0; 
 int mp_debug_set_option(const char* name, int value) {
     if (name && !strcmp(name, "stamp_stride")) {      // every workgroup of the decode kernel records (lsh.hip)
         MP_HIP_CHECK(set_stamp_stride(value));
+        return MP_OK;
+    }
+    if (name && !strcmp(name, "simhash_exact_norm")) {   // 1: the fused hash normalises the query row by the exact sequence always
+        set_exact_norm(value);
         return MP_OK;
     }
     std::atomic<int>* o = debug_option(name);

@@ -507,7 +507,11 @@ struct HashArgs {
     int32_t* codes_out;      // [BH][L]
     float* qnorm_out;        // [BH]
     int D, K, KLpad;
+    int exact_norm;          // 1: the query row is normalised by the exact (f64) sequence always (A/B, tests)
 };
+
+static int g_exact_norm = 0;   // mp_debug_set_option("simhash_exact_norm"): read at launch
+void set_exact_norm(int v) { g_exact_norm = v; }
 
 // AD > 0 (with HASH) appends the sparse attention of the head to the same launch (attn_head.h): the
 // selected ids never leave the workgroup's LDS.  A head is served by a CLUSTER of R = 1, 2, 4 or 8
@@ -655,6 +659,7 @@ __device__ __forceinline__ void lsh_head_body(
         pay = (ib != 0) & (bad == 0) & (av == kv);
         idmask = idbits ? ((1u << idbits) - 1u) : 0xffffffffu;
     }
+    bool bits_exchanged = false;                                 // uniform: the split hash delivered every sign word
     if (HASH == 2) {   // the hash ran as its own launch: only the raw query row (for q.k) and ||q|| are fetched here
         const int per = ha.D >> 6;
         if (wave == 0) {
@@ -700,23 +705,64 @@ __device__ __forceinline__ void lsh_head_body(
         if (wave == 0) {
             const uint16_t e[4] = {(uint16_t)(e01 & 0xffffu), (uint16_t)(e01 >> 16),
                                    (uint16_t)(e23 & 0xffffu), (uint16_t)(e23 >> 16)};
-            double ss = 0.0;
+            // The definition (what torch computes on bf16 tensors, pinned by the qhash_* fixtures): nrm = f32 sqrt of the
+            // f32-rounded EXACT sum of squares, nb = bf16(nrm), element = bf16(IEEE f32 quotient).  The exact sequence -- f64
+            // squares, an f64 wave sum, an f64 sqrt, two IEEE divisions -- is ~130 dependent instructions on the one wave
+            // everybody waits for (~0.5 us).  Round 4: a FAST form first -- f32 sum (squares of bf16 numbers are exact in
+            // f32; <= 7 roundings), v_sqrt_f32 (1 ulp), v_rcp_f32 + multiply (<= 2.5 ulp from the IEEE quotient) -- which
+            // gives the same bf16 numbers unless a value lies within a few f32 ulps of a bf16 rounding boundary (low 16 bits
+            // at 0x8000): there, and only there (0.1 % of the rows for the norm, 3 % for some element), the wave takes the
+            // exact sequence.  Both tests are wave-uniform; the guards (32 / 16 ulps) are several times the error bounds.
+            float xf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {                      // elements past `per` are zero
-                const double v = (double)bf16_bits_to_f32(e[i]);
-                ss += v * v;                                   // exact, order-free
-            }
+            for (int i = 0; i < 4; ++i) xf[i] = bf16_bits_to_f32(e[i]);   // elements past `per` are zero
             MP_STAMP(stamp, 28);                               // the query row has arrived
-            ss = wave_sum(ss);
-            const float nrm = (float)sqrt((double)(float)ss);   // (__fsqrt_rn measured no faster here, and not bit-identical)
-            const float nb = bf16_bits_to_f32(f32_to_bf16_rne(nrm));
+            float nrm, nb;
+            bool fast = ha.exact_norm == 0;
+            if (fast) {
+                float sf = fmaf(xf[3], xf[3], fmaf(xf[2], xf[2], fmaf(xf[1], xf[1], xf[0] * xf[0])));
+                sf = wave_sum(sf);
+                float s1 = __builtin_amdgcn_sqrtf(sf);
+                s1 = fmaf(fmaf(-s1, s1, sf), 0.5f * __builtin_amdgcn_rcpf(s1), s1);   // one Newton step: within ~1 ulp of sqrt(sf)
+                const uint32_t low = __float_as_uint(s1) & 0xffffu;
+                const bool edge = (low >= 0x8000u - 32u && low <= 0x8000u + 32u) || !(sf > 1e-30f && sf < 1e30f);
+                fast = !edge;                                  // uniform: sf is the same on every lane
+                nrm = s1;
+            }
+            if (!fast) {
+                double ss = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ss += (double)xf[i] * (double)xf[i];   // exact, order-free
+                ss = wave_sum(ss);
+                nrm = (float)sqrt((double)(float)ss);          // (__fsqrt_rn measured no faster here, and not bit-identical)
+            }
+            nb = bf16_bits_to_f32(f32_to_bf16_rne(nrm));
             if (lane == 0 && lead && ha.qnorm_out != nullptr) ha.qnorm_out[h] = nrm;
             uint16_t* dst = reinterpret_cast<uint16_t*>(s_q) + lane * per;
             uint16_t* raw = reinterpret_cast<uint16_t*>(s_qraw) + lane * per;
+            float tq[4];
+            bool amb = false;
+            if (fast) {
+                const float rc = __builtin_amdgcn_rcpf(nb);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    tq[i] = xf[i] * rc;
+                    const uint32_t tb = __float_as_uint(tq[i]);
+                    const uint32_t lo16 = tb & 0xffffu;
+                    // near a rounding boundary, or so small that the reciprocal form may flush where the quotient does not
+                    amb = amb || (i < per && xf[i] != 0.f &&
+                                  ((lo16 >= 0x8000u - 16u && lo16 <= 0x8000u + 16u) || (tb & 0x7f800000u) < (32u << 23)));
+                }
+                fast = __ballot(amb) == 0ull;                  // uniform
+            }
+            if (!fast) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tq[i] = __fdiv_rn(xf[i], nb);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < per) {
-                    dst[i] = f32_to_bf16_rne(__fdiv_rn(bf16_bits_to_f32(e[i]), nb));
+                    dst[i] = f32_to_bf16_rne(tq[i]);
                     if (AD > 0) raw[i] = e[i];
                 }
             // ||nq|| <= ||q||/nb * (1 + 2^-8): every element is rounded to bf16 once (guard bound)
@@ -761,7 +807,7 @@ __device__ __forceinline__ void lsh_head_body(
                 near = fabsf(acc) <= (1.0f / 65536.0f) * rn * wn;    // 2^-16 guard band (simhash.hip SH_EPS)
             }
         };
-        bool have_bits = false;
+        bool have_bits = false;                                  // (every workgroup barrier below orders LDS only)
         if (split) {
             // ---- this wave's unit (if it has one), published as two 64-bit words (sequence << 32 | 32 sign bits):
             // a word proves by itself that it belongs to THIS launch, so there is no counter, no acknowledgement and
@@ -799,6 +845,7 @@ __device__ __forceinline__ void lsh_head_body(
             __syncthreads();
             MP_STAMP(stamp, 24);                                     // every word of the head is there (or timed out)
             have_bits = s_tmp[29] != 0;                              // uniform
+            bits_exchanged = have_bits;
             if (!have_bits) load_planes(tid);                        // on its own after all: pass 0's chunks
         }
         if (!have_bits)
@@ -827,7 +874,9 @@ __device__ __forceinline__ void lsh_head_body(
             MP_STAMP(stamp, 23 + (c0 >> 10));
         }
     }
-    __syncthreads();
+    // (split hash, every word arrived: the barrier behind the exchange already ordered the sign bits -- and the one behind
+    // the normalisation the zero-filled bitmaps -- in front of everything below; one barrier less on the chain)
+    if (!bits_exchanged) __syncthreads();
     MP_STAMP(stamp, 27);
     const uint32_t T0 = (uint32_t)t0;                                   // M <= 2^22 (mp_lsh_alloc)
     auto apply = [&](int32_t t) {
@@ -1719,7 +1768,7 @@ hipError_t launch_lsh_hash_retrieve(const int32_t* bounds, const int32_t* table,
     const int Lpad = (L + 63) & ~63;
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
-    HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
+    HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad, g_exact_norm};
     if (D >= 128)
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, R, words,
@@ -1737,7 +1786,7 @@ hipError_t launch_lsh_hash_only(const uint16_t* q, const uint16_t* Wk, const flo
     const int Lpad = (L + 63) & ~63;
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
-    HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
+    HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad, g_exact_norm};
     const size_t lds = body_lds_bytes(0, L);
     if (D >= 128)
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 16>), dim3(rows), dim3(RT_THREADS), lds, st, (const int32_t*)nullptr,
@@ -1776,7 +1825,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     if ((1 << clog) != R || R > CLUSTER_MAX) return hipErrorInvalidValue;
     const int BHp = clog > 0 ? (BH + 7) & ~7 : BH;
     const bool sx = same_xcd && clog > 0 && xcd_round_robin_verified();
-    HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad};
+    HashArgs ha = {q, Wk, wnorm, codes_out, qnorm_out, D, K, KLpad, g_exact_norm};
     // planes split over the cluster + exchange of the sign bits through the XCD's L2: only where the members of a
     // cluster share an XCD (sx) and every unit of 64 planes finds a wave (K*L <= 1024 R)
     const bool split_hash = xmode != 0 && sx && xw != nullptr && xseq != nullptr && !codes_given &&

@@ -38,12 +38,14 @@ class SimHash:
         q2 = q.reshape(-1, self.D)
         L.expect(q2, torch.bfloat16, None, "q")
         R = q2.shape[0]
-        if codes is None:
+        if codes is None:           # (a tensor made here needs no checking)
             codes = torch.empty((R, self.L), dtype=torch.int32, device=q.device)
+        else:
+            L.expect(codes, torch.int32, (R, self.L), "codes")
         if qnorm is None:
             qnorm = torch.empty((R,), dtype=torch.float32, device=q.device)
-        L.expect(codes, torch.int32, (R, self.L), "codes")
-        L.expect(qnorm, torch.float32, (R,), "qnorm")
+        else:
+            L.expect(qnorm, torch.float32, (R,), "qnorm")
         mem = L.same_memory(q2, codes, qnorm)
         L.check(L.lib().mp_simhash_query(self._h, L.ptr(q2), R, L.ptr(codes), L.ptr(qnorm), mem,
                                          L.current_stream(q2, self._device)))

@@ -25,7 +25,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def _setup(mp, torch, K=6, L=20, H=8, Hkv=2, B=1, n=20000, M=20480, seed=1):
+# MP_STRESS_BIG=1 (environment): 64 heads x 300 000 rows, so that a `results` buffer is 77 MB -- above glibc's dynamic mmap threshold
+# (at most 32 MiB): freeing it really unmaps it.  With the small shape a freed buffer stays in the heap, its pages never
+# leave the process and a stale registration keeps pointing at live memory (round 4, first hunt: nothing failed).
+BIG = bool(os.environ.get("MP_STRESS_BIG"))
+M_ROWS = 300000 if BIG else 20480          # (the collision bitmaps of max_length tokens must fit the LDS: <= ~600 K)
+HEADS = 64 if BIG else 8                    # BIG: results = 64 x 300 000 x 4 = 76.8 MB
+
+
+def _setup(mp, torch, K=6, L=20, H=HEADS, Hkv=2, B=1, n=20000, M=M_ROWS, seed=1):
     gen = torch.Generator().manual_seed(seed)
     lsh = mp.LSH()
     lsh.alloc(K, L, 1, H, Hkv, B, M)
@@ -53,7 +61,7 @@ def run(scenario: str, iters: int) -> None:
     import magicpig_amd._lib as L_
 
     faulthandler.enable()
-    BH, M = 8, 20480                      # results: 8 x 20480 x 4 = 640 KiB (> the 256 KiB registration threshold)
+    BH, M = HEADS, M_ROWS                 # results: 8 x 20480 x 4 = 640 KiB (> the 256 KiB registration threshold); BIG: 77 MB
     addrs = set()
     reused = 0
     for it in range(iters):
@@ -91,7 +99,7 @@ def run(scenario: str, iters: int) -> None:
             del lsh
         elif scenario == "resize":
             big = torch.full((2 * BH, M), -7, dtype=torch.int32)
-            lsh2, q2, r2, z2 = _setup(mp, torch, H=16, Hkv=4, seed=500 + it)
+            lsh2, q2, r2, z2 = _setup(mp, torch, H=2 * HEADS, Hkv=4, seed=500 + it)
             nn2 = torch.zeros((2 * BH,), dtype=torch.int32)
             lsh2.batch_retrieve(0, q2, big, nn2)
             _check(big, nn2, r2, z2, f"resize it {it}")
@@ -113,7 +121,7 @@ def main() -> None:
         run(scenario, iters)
         return
     env = dict(os.environ, AMD_LOG_LEVEL=os.environ.get("AMD_LOG_LEVEL", "1"))
-    for sc in ("live", "resize", "free_first", "stale"):
+    for sc in (os.environ.get("MP_STRESS_SCENARIOS", "live,resize,free_first,stale")).split(","):
         cmd = [sys.executable, os.path.abspath(__file__), sc, str(iters)]
         if os.environ.get("MP_STRESS_GDB") and os.path.exists("/opt/rocm/bin/rocgdb"):
             cmd = ["/opt/rocm/bin/rocgdb", "-batch", "-ex", "run", "-ex", "bt", "-ex", "info threads", "--args"] + cmd

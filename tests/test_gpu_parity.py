@@ -95,6 +95,45 @@ def test_query_simhash_guard_band_covers_mfma_error(mp):
     assert worst < 2.0 ** -16 / 8, worst       # >= 8x margin under the guard band (measured: 2^-24.1)
 
 
+@pytest.mark.parametrize("D", [128, 64])
+def test_fast_query_normalisation_never_changes_a_code(mp, D):
+    """The fused query hash normalises the row by a fast f32 form (f32 sum, v_sqrt_f32, reciprocal multiply) and takes
+    the exact sequence (f64 sum and sqrt, IEEE divisions: the definition, pinned by the qhash_* fixtures) only where a
+    value sits within a few ulps of a bf16 rounding boundary.  Over 64 K random rows at five scales -- ~0.1 % of them on
+    the norm's fallback, ~3 % on the quotients' -- the codes equal those of the exact sequence forced for every row
+    (`simhash_exact_norm`), and 4 K of them the oracle's; ||q|| agrees to 5e-7."""
+    import magicpig_amd._lib as L_
+
+    K, L = 10, 150
+    gen = torch.Generator(device="cuda").manual_seed(900 + D)
+    W = torch.randn((D, K * L), device="cuda", generator=gen).to(torch.bfloat16)
+    sh = mp.SimHash(W, K, L)
+    rows = 64 * 200
+    try:
+        for si, scale in enumerate((1.0, 1e-3, 37.0, 2.0 ** -20, 2.0 ** 12)):
+            q = (torch.randn((rows, D), device="cuda", generator=gen) * scale).to(torch.bfloat16)
+            fast_c, fast_n, ex_c, ex_n = [], [], [], []
+            for r0 in range(0, rows, 64):                      # <= 64 rows per call: the fused (vector-pipe) hash
+                L_.set_option("simhash_exact_norm", 0)
+                c, n = sh.query(q[r0:r0 + 64])
+                fast_c.append(c.clone()); fast_n.append(n.clone())
+                L_.set_option("simhash_exact_norm", 1)
+                c, n = sh.query(q[r0:r0 + 64])
+                ex_c.append(c.clone()); ex_n.append(n.clone())
+            fc, ec = torch.cat(fast_c), torch.cat(ex_c)
+            assert torch.equal(fc, ec), (scale, int((fc != ec).any(-1).sum()))
+            fn, en = torch.cat(fast_n), torch.cat(ex_n)
+            assert torch.allclose(fn, en, rtol=5e-7, atol=0.0)
+            if si < 2:
+                qb = q[:2048].cpu().view(torch.int16).numpy().view(np.uint16)
+                Wb = W.cpu().view(torch.int16).numpy().view(np.uint16)
+                oc, oqn = oracle.simhash_query(qb, Wb, K, L)
+                assert np.array_equal(fc[:2048].cpu().numpy(), oc)
+                assert np.allclose(fn[:2048].cpu().numpy(), oqn, rtol=5e-7)
+    finally:
+        L_.set_option("simhash_exact_norm", 0)
+
+
 def test_simhash_exact_sign_when_every_dot_product_is_tiny(mp):
     """Forces the rare branch (HIP guide rule 26): every hyperplane is built exactly or almost exactly
     orthogonal to one of the (normalised) queries, so a quarter of all dot products sit inside the
