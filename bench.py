@@ -112,8 +112,6 @@ def parse():
     ap.add_argument("--no-clustered-leg", action="store_true",
                     help="skip the second workload of the default run (clustered keys + heavy-hitter queries, the README's "
                          "~2 %% sampling rate), reported as value_clustered next to the headline value")
-    ap.add_argument("--host-register-leg", action="store_true",
-                    help="host-buffer leg: also time the opt-in host_register mode (hipHostRegister of `results`)")
     ap.add_argument("--cpu-steps", type=int, default=8192,
                     help="decode steps of ONE sparse layer timed on the host cores per thread placement (medians): "
                          "~5 s of CPU work at cfg 1, ~20 s at cfg 2")
@@ -282,7 +280,7 @@ def run_cpu_baseline(cfg, server, qs, steps, H, Hkv):
 
 # ---------------------------------------------------------------------------- host-buffer mode leg
 
-def host_mode_leg(server, cfg, qs, H, reps=40, register_leg=False):
+def host_mode_leg(server, cfg, qs, H, reps=40):
     """Per-layer cost of the UNCHANGED caller: the decode lines of models/attnserver.py:264-303 -- q hash on the GPU,
     codes + query copied to pinned CPU tensors, batch_retrieve and attention_wrapper on CPU tensors (`results` and
     `nnz` pageable, the rest pinned, exactly as :59-66), output + LSE copied back -- eager, synchronised per layer.
@@ -321,23 +319,12 @@ def host_mode_leg(server, cfg, qs, H, reps=40, register_leg=False):
         return (time.perf_counter() - t0) / reps * 1e6
 
     us = timed()
-    # the same with the pageable `results` registered once and used in place (these buffers outlive the handles).  On
-    # request only (--host-register-leg): hipHostRegister aborted inside the ROCm runtime in two test-suite runs of
-    # round 3 (EXPERIMENTS.md R3-9), and an abort here would cost the whole bench line; profiles/r03g_bench_*.json
-    # carry the figure (151-158 us per layer at cfg 1).
-    us_reg = None
-    if register_leg:
-        L.set_option("host_register", 1)
-        try:
-            us_reg = timed()
-        finally:
-            L.set_option("host_register", 0)
     host_layer(qs[(reps - 1) % NQ, 0])
     server.collect_nnz = True
     server.decode(qs[(reps - 1) % NQ, 0], 0)
     torch.cuda.synchronize()
     same = bool(torch.equal(server.nnz.cpu(), nnz)) and float((server.output.float().cpu() - output.float()).abs().max()) < 2e-2
-    return {"us_per_layer": us, "us_per_layer_host_register": us_reg, "matches_device_entry": same, "reps": reps,
+    return {"us_per_layer": us, "matches_device_entry": same, "reps": reps,
             "what": "models/attnserver.py:264-303 unchanged: GPU q-hash, pinned codes/query/output, pageable results/nnz, "
                     "batch_retrieve + attention_wrapper on CPU tensors, eager + synchronised per layer"}
 
@@ -706,7 +693,7 @@ def main():
 
     if rank == 0 and world == 1 and shard is None and not args.no_host_mode:
         try:
-            out["host_mode"] = host_mode_leg(server, cfg, qs, H, register_leg=args.host_register_leg)
+            out["host_mode"] = host_mode_leg(server, cfg, qs, H)
         except Exception as e:
             out["host_mode"] = {"us_per_layer": None, "what": f"failed: {e!r}"[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -15,7 +15,7 @@
  *   - `mem` says where caller buffers live: MP_MEM_HOST buffers (the reference's CPU-tensor callers,
  *     models/attnserver.py:59-66) are used IN PLACE by the kernels where they are pinned; for a
  *     pageable buffer the kernels work on a pinned mirror owned by the handle and the host copies the
- *     live entries across (or, on request, the buffer is registered once: "host_register");
+ *     live entries across (the library never registers a caller's memory);
  *     MP_MEM_DEVICE buffers are used in place (fast path: codes, results and nnz never leave HBM);
  *   - `stream` is a hipStream_t (NULL = default stream); work is enqueued asynchronously for
  *     MP_MEM_DEVICE arguments, synchronously completed for MP_MEM_HOST arguments;
@@ -229,17 +229,21 @@ int mp_debug_xcd_round_robin(void);
  *                        publishes (test: every workgroup takes the fallback)
  *   "decode_kn_payload"  1 = the decode entries pack the key norms into the table entries and use them (default, while
  *                        the layer's ids fit 17 bits), 0 = one HBM access per selected token
- *   "decode_direct"      -1 = auto, 0 = never, 1 = always (where R > 1): keep 128-byte direct slots (length, position + first
- *                        30 ids) for every (table, bucket, token range) piece; read by mp_lsh_alloc
+ *   "decode_direct"      -1 = auto, 0 = never, 1 = always (where R > 1): keep direct slots (length, position + the first
+ *                        ids: 128, 64 or 32 bytes by the mean piece length) for every (table, bucket, token range)
+ *                        piece; read by mp_lsh_alloc
  *   "attn_head_kernel"   -1 = auto, 0 = split-KV kernel with the in-launch ticket merge, 1 = one workgroup per head
  *   "attn_gx"            0 = auto, n = split-KV workgroups per head
  *   "attn_dense_grouped" 1 = mp_attn_full reads K/V once per kv group (default), 0 = once per query head
  *   "host_zero_copy"     1 = MP_MEM_HOST calls let the kernels work on pinned memory in place -- the caller's pinned
  *                        buffers, or the handle's pinned mirror of a pageable one (default); 0 = staged copies through
  *                        the copy engine (the fallback, kept under test)
- *   "host_register"      1 = a large PAGEABLE caller buffer (results_lsh_cpu, models/attnserver.py:60) is registered
- *                        (hipHostRegister) once per (pointer, size) and used in place until the handle is destroyed --
- *                        only for callers whose buffers live as long as the handle; 0 (default) = pinned mirror */
+ *   "host_flag_wait"     1 = MP_MEM_HOST calls wait for their launches by spinning on a word a one-thread kernel writes
+ *                        to pinned memory instead of hipStreamSynchronize (A/B; measured no gain over the whole layer)
+ *   "simhash_exact_norm" 1 = the fused query hash normalises the row by the exact f64 sequence always (A/B, tests);
+ *                        0 (default) = a fast f32 form with the exact sequence as its fallback: identical codes
+ *   "decode_cluster"     0 = auto, else workgroups per query head of the one-launch decode (1 .. 32); read by mp_lsh_alloc
+ * (the `host_register` option of rounds 2-3 -- hipHostRegister of a caller's pageable buffer -- was removed in round 4) */
 int mp_debug_set_option(const char* name, int value);
 int mp_debug_get_option(const char* name, int* value);
 

@@ -103,7 +103,6 @@ struct DebugOptions {
     std::atomic<int> attn_dense_grouped{1};  // full_attention: 1 = K/V read once per kv group, 0 = once per query head
     std::atomic<int> decode_kn_payload{1};   // 1: use the key norms attached to the table entries (where attached), 0: one HBM access per token
     std::atomic<int> host_zero_copy{1};      // MP_MEM_HOST calls: 1 = kernels work on pinned memory in place (the caller's, or the handle's mirror), 0 = staged copies
-    std::atomic<int> host_register{0};       // 1 = a large PAGEABLE caller buffer is registered (hipHostRegister) once and used in place
     std::atomic<int> host_flag_wait{0};      // MP_MEM_HOST calls: 1 = wait for the stream by spinning on a word a one-thread kernel
                                              // writes to pinned memory instead of hipStreamSynchronize (A/B, EXPERIMENTS.md R4-5)
 };
@@ -122,7 +121,6 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "attn_dense_grouped")) return &g_opt.attn_dense_grouped;
     if (!strcmp(name, "decode_kn_payload")) return &g_opt.decode_kn_payload;
     if (!strcmp(name, "host_zero_copy")) return &g_opt.host_zero_copy;
-    if (!strcmp(name, "host_register")) return &g_opt.host_register;
     if (!strcmp(name, "host_flag_wait")) return &g_opt.host_flag_wait;
     return nullptr;
 }
@@ -247,23 +245,18 @@ struct HostFlag {
 
 // Host-buffer mode without copies: the address at which a KERNEL can read / write a caller's host buffer in place.
 // The reference's callers hold pinned tensors (models/attnserver.py:59-66: hipHostMalloc through torch's pin_memory):
-// those are mapped already.  A PAGEABLE buffer (results_lsh_cpu and nnz, :59-60) is not touched by default: the
-// kernels work on a pinned mirror owned by the handle and the host copies the live entries across (a registration
-// outlives the buffer it was made for -- a caller that frees and re-allocates would be served the old pages).  With the
-// `host_register` option a large pageable buffer is registered ONCE per (pointer, size) and used in place until the
-// handle is freed: for callers whose buffers live as long as the handle, as the reference's server object's do.
-// nullptr = not mappable.
+// those are mapped already.  A PAGEABLE buffer (results_lsh_cpu and nnz, :59-60) is never touched by a kernel: the kernels
+// work on a pinned mirror owned by the handle and the host copies the live entries across.  (Rounds 2-3 could also
+// REGISTER a pageable buffer -- hipHostRegister, the opt-in `host_register` mode; the full GPU suite aborted twice inside
+// the ROCm runtime with it, and round 4's hunt -- scripts/experiments/stress_host_register.py: registrations that outlive,
+// or are outlived by, their buffers, heap-resident and really unmapped ones, 150 iterations each, under rocgdb -- reproduced
+// neither the aborts nor a wrong result.  A mode whose failure cannot be explained does not ship: removed, EXPERIMENTS.md
+// R4-6.)  nullptr = not mapped.
 struct HostMap {
-    struct Reg { const char* p; size_t bytes; char* dev; };
-    std::vector<Reg> regs;
     const void* last_pageable = nullptr;   // the last pointer found to be plain pageable memory (negative results only
                                            // are remembered: treating pinned memory as pageable is merely slower)
-    void* resolve(const void* ptr, size_t bytes, bool may_register) {
-        const char* p = reinterpret_cast<const char*>(ptr);
-        if (may_register)
-            for (const Reg& r : regs)
-                if (r.p <= p && p + bytes <= r.p + r.bytes) return r.dev + (p - r.p);
-        if (!may_register && ptr == last_pageable) return nullptr;   // (the failing lookup below costs microseconds per call)
+    void* resolve(const void* ptr, size_t /*bytes*/) {
+        if (ptr == last_pageable) return nullptr;   // (the failing lookup below costs microseconds per call)
         hipPointerAttribute_t a;
         if (hipPointerGetAttributes(&a, ptr) == hipSuccess) {
             if (a.type == hipMemoryTypeHost && a.devicePointer != nullptr) return a.devicePointer;
@@ -271,27 +264,10 @@ struct HostMap {
         } else {
             (void)hipGetLastError();                               // pageable memory: "invalid value" on older runtimes
         }
-        if (!may_register || bytes < (256u << 10)) {
-            last_pageable = ptr;
-            return nullptr;
-        }
-        if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterMapped) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        void* d = nullptr;
-        if (hipHostGetDevicePointer(&d, const_cast<void*>(ptr), 0) != hipSuccess || d == nullptr) {
-            (void)hipGetLastError();
-            (void)hipHostUnregister(const_cast<void*>(ptr));
-            return nullptr;
-        }
-        regs.push_back({p, bytes, reinterpret_cast<char*>(d)});
-        return d;
+        last_pageable = ptr;
+        return nullptr;
     }
-    void release() {
-        for (const Reg& r : regs) (void)hipHostUnregister(const_cast<char*>(r.p));
-        regs.clear();
-    }
+    void release() { last_pageable = nullptr; }
 };
 
 constexpr int FILL_BLOCKS = 1024;   // row blocks of mp_attn_fill_offload's column sums
@@ -827,7 +803,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     if (rc) return rc;
     if (g_opt.host_zero_copy.load() != 0 && h->small.hd != nullptr) {
         const size_t rbytes = (size_t)BH * h->M * 4;
-        void* res_dev = h->hostmap.resolve(results, rbytes, g_opt.host_register.load() != 0);
+        void* res_dev = h->hostmap.resolve(results, rbytes);
         bool mirror = false;
         if (res_dev == nullptr) {                 // pageable `results`: the rows go to the handle's pinned mirror
             rc = h->big.reserve(rbytes, true);
@@ -842,7 +818,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
             h->lastq = reinterpret_cast<const int32_t*>(hd + o_codes);      // (get_mask reads them again)
             h->last_layer = layer_id;
             // ONE launch, ONE synchronisation, no copy engine: the kernel reads the codes from the pinned block, writes
-            // the ids straight into the caller's rows (pinned / registered) or the pinned mirror and the counts into the
+            // the ids straight into the caller's rows (where they are pinned) or the pinned mirror and the counts into the
             // pinned block -- and leaves a second copy of the rows in HBM (the handle's step buffer) with a checksum
             // per row, so that the attention entry of the paired store need not upload what it is handed next
             MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id],
@@ -1332,8 +1308,8 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
         }
     }
     // Zero copy: ONE launch brings (q | qn | nnz) and the first nnz[h] entries of every index row into HBM with
-    // coalesced reads over PCIe -- straight from the caller's rows where they are pinned (or registered on request,
-    // HostMap), else from the handle's pinned block, into which the host packs the live entries -- and the attention
+    // coalesced reads over PCIe -- straight from the caller's rows where they are pinned (HostMap),
+    // else from the handle's pinned block, into which the host packs the live entries -- and the attention
     // kernel writes (out | mve) straight into the pinned block: two or three launches, ONE synchronisation, no copy engine.
     if (g_opt.host_zero_copy.load() != 0 && h->small.hd != nullptr) {
         char* hd = reinterpret_cast<char*>(h->small.hd);
@@ -1342,7 +1318,7 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
             MP_HIP_CHECK(launch_relay(hd, dp, o_offs, st));
         } else {
             if (h->ind_rows == nullptr) MP_HIP_CHECK(hipMalloc((void**)&h->ind_rows, (size_t)BH * h->M * 4));
-            const void* ind_dev = h->hostmap.resolve(ind, (size_t)BH * h->M * 4, g_opt.host_register.load() != 0);
+            const void* ind_dev = h->hostmap.resolve(ind, (size_t)BH * h->M * 4);
             if (ind_dev != nullptr) {
                 int64_t longest = 0;                                     // one PCIe round trip per thread: blocks by the longest row
                 for (int i = 0; i < BH; ++i) longest = nnz[i] > longest ? nnz[i] : longest;

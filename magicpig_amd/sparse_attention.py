@@ -165,11 +165,18 @@ class SparseAttentionServer:
                             (self.Hkv * self.M * rs, self.M * rs, rs, 2), device=torch.device("cuda", self._device))
         return t.view(torch.bfloat16)
 
-    def get_key_cache(self, layer_id: int) -> torch.Tensor:
-        return self._kv(layer_id, 0)
+    def get_key_cache(self, layer_id: int, contiguous: bool = False) -> torch.Tensor:
+        """get_key_cache, sparse_attention.cc:1213-1222: bf16 [B, Hkv, M, D].  The reference returns an alias of one
+        contiguous blob; here a token's K and V rows are interleaved in HBM, so the alias is a STRIDED view (element
+        stride 2 D between tokens: `.view(-1)` on it raises).  contiguous=True returns a contiguous COPY for callers
+        that reshape the cache (writes to the copy do not reach the store)."""
+        t = self._kv(layer_id, 0)
+        return t.contiguous() if contiguous else t
 
-    def get_value_cache(self, layer_id: int) -> torch.Tensor:
-        return self._kv(layer_id, 1)
+    def get_value_cache(self, layer_id: int, contiguous: bool = False) -> torch.Tensor:
+        """get_value_cache, sparse_attention.cc:1223-1233 (see get_key_cache)."""
+        t = self._kv(layer_id, 1)
+        return t.contiguous() if contiguous else t
 
     def get_key_norm(self, layer_id: int) -> torch.Tensor:
         p = C.c_void_p()

@@ -1,4 +1,8 @@
-"""Root-cause hunt for the two process aborts of round 3 (EXPERIMENTS.md R3-9): the opt-in `host_register` mode of the
+"""RECORD of an experiment (EXPERIMENTS.md R4-6) -- it drives the `host_register` option, which round 4 REMOVED from the
+library after this hunt reproduced neither abort; to re-run it, check out commit "Fast-path query normalisation ..." of round 4
+(the last one that still has the option).
+
+Root-cause hunt for the two process aborts of round 3 (EXPERIMENTS.md R3-9): the opt-in `host_register` mode of the
 MP_MEM_HOST calls (hipHostRegister of a caller's pageable `results` buffer, used in place by the kernels).
 
     python scripts/stress_host_register.py <scenario> [iterations]     (one scenario per process: an abort ends it)
@@ -21,7 +25,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -298,22 +298,13 @@ def test_pipeline_vs_reference_and_oracle(mp, name, where):
     _check_attention(r, g)
 
 
-# hipHostRegister of caller buffers (the opt-in `host_register` mode) aborted INSIDE the ROCm runtime in two suite runs
-# of round 3 (EXPERIMENTS.md R3-9; the second time right at this test) -- an abort takes the whole pytest process with
-# it, so the mode is exercised on request (MP_TEST_HOST_REGISTER=1; bench.py --host-register-leg times it), not by
-# default.
-_REGISTER = pytest.param("register", marks=pytest.mark.skipif(not os.environ.get("MP_TEST_HOST_REGISTER"),
-                                                              reason="opt-in: MP_TEST_HOST_REGISTER=1"))
-
-
 @pytest.mark.parametrize("pinned", [True, False])
-@pytest.mark.parametrize("mode", ["zero_copy", "flag_wait", _REGISTER, "staged"])
+@pytest.mark.parametrize("mode", ["zero_copy", "flag_wait", "staged"])
 def test_host_buffer_modes_agree(mp, mode, pinned):
     """MP_MEM_HOST calls (the unchanged caller of models/attnserver.py:299-300) give what the device-buffer calls
     give, bit for bit, whichever way the buffers cross PCIe: kernels working on the caller's PINNED tensors in place
-    (:61-66), on the handle's pinned mirror for PAGEABLE ones (`results_lsh_cpu`, `nnz`, :59-60; the default), on a
-    pageable buffer registered once (`host_register`, for buffers that live as long as the handle), or through staged
-    copies (`host_zero_copy = 0`); rows behind nnz stay untouched; a second call with other queries works as the first."""
+    (:61-66), on the handle's pinned mirror for PAGEABLE ones (`results_lsh_cpu`, `nnz`, :59-60; the default), with the
+    completion word instead of a stream synchronisation (`host_flag_wait`), or through staged copies (`host_zero_copy = 0`); rows behind nnz stay untouched; a second call with other queries works as the first."""
     import magicpig_amd._lib as L_
 
     g = cases.load_golden("gqa_32h")
@@ -328,9 +319,8 @@ def test_host_buffer_modes_agree(mp, mode, pinned):
     srv.fill(0, 0, bf16_t(keys[0], "cuda"), bf16_t(vals[0], "cuda"), torch.from_numpy(kns[0]).cuda())
     mk = (lambda t: t.pin_memory()) if pinned else (lambda t: t)
     L_.set_option("host_zero_copy", 0 if mode == "staged" else 1)
-    L_.set_option("host_register", 1 if mode == "register" else 0)
     L_.set_option("host_flag_wait", 1 if mode == "flag_wait" else 0)     # completion word in pinned memory instead of a sync
-    keep = []                                           # registered buffers must outlive the handles
+    keep = []
     try:
         for rep in range(2):
             q = bf16_t(qb if rep == 0 else np.roll(qb, 3, axis=0), "cuda")
@@ -368,10 +358,9 @@ def test_host_buffer_modes_agree(mp, mode, pinned):
             srv.attention_wrapper(0, K, L, h_out, h_mve, h_q, h_qn, h_res, h_nnz)
             assert torch.equal(h_out, d_out.cpu()) and torch.equal(h_mve, d_mve.cpu())
             assert not torch.equal(srv.get_score().reshape(BH, M)[r, :z], d_probs[r, :z])
-        del lsh, srv                                    # (handles first: they unregister what they registered)
+        del lsh, srv
     finally:
         L_.set_option("host_zero_copy", 1)
-        L_.set_option("host_register", 0)
         L_.set_option("host_flag_wait", 0)
 
 
@@ -940,7 +929,9 @@ def test_decode_with_planes_split_over_the_cluster(mp, B, H, Hkv, D, K, L):
 def test_decode_with_mfma_hash_launch_equals_fused_hash(mp, B, H, Hkv, D):
     """The decode entry with the query SimHash computed by the MFMA kernel in a launch of its own
     (decode_mfma_hash option: the A/B variant north_star's "the projection uses MFMA" asks about) against the
-    default, where the hash is the decode kernel's prologue: same codes, nnz, ids -> bit-identical outputs."""
+    default, where the hash is the decode kernel's prologue: same codes, nnz, ids.  ||q|| (a factor of every cosine) is
+    the exact f32 norm in the MFMA kernel and, since round 4, within 5e-7 of it in the fused prologue (the fast
+    normalisation keeps the bf16 ROW exact, not the last ulps of the norm): outputs agree to a bf16 ulp, not bit for bit."""
     import magicpig_amd._lib as L_
 
     n, M, K, L = 5000, 5120, 9, 40
@@ -957,7 +948,8 @@ def test_decode_with_mfma_hash_launch_equals_fused_hash(mp, B, H, Hkv, D):
             torch.cuda.synchronize()
         finally:
             L_.set_option("decode_mfma_hash", 0)
-        assert torch.equal(server.nnz, z1) and torch.equal(out2, o1) and torch.equal(lse2, l1)
+        assert torch.equal(server.nnz, z1)
+        assert torch.allclose(out2.float(), o1.float(), rtol=2 ** -7, atol=1e-4) and torch.allclose(lse2, l1, atol=1e-5)
         assert torch.equal(server.lsh_retriever.get_mask(), m1)        # recomputed from the codes each variant wrote
 
 
