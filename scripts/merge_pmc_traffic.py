@@ -16,7 +16,7 @@ def avg(path):
         m = re.match(r"\|\s*void mp::lsh_decode_kernel.*\|\s*(FETCH_SIZE|WRITE_SIZE)\s*\|\s*(\d+)\s*\|\s*([\d.]+)\s*\|", line)
         if m:
             return float(m.group(3)), int(m.group(2))
-    raise SystemExit(f"{path}: no lsh_decode_kernel row")
+    return None, 0          # (a pass that produced no counters: reported and skipped below)
 
 
 for cfg in ("cfg1", "cfg2", "cfg3", "cfg4"):
@@ -27,6 +27,9 @@ for cfg in ("cfg1", "cfg2", "cfg3", "cfg4"):
         if not (os.path.exists(f) and os.path.exists(w)):
             continue
         (fk, _), (wk, _) = avg(f), avg(w)
+        if fk is None or wk is None:
+            print(cfg + suffix, "SKIPPED: a PMC pass without an lsh_decode_kernel row")
+            continue
         total = (2 * fk + wk) * 1024
         out[key][cfg] = total
         alg = None
