@@ -338,24 +338,47 @@ def end_to_end(args, cfg, rank, world, dev, dist):
     from magicpig_amd import decode_harness as dh
     from magicpig_amd import sharding
 
-    assert cfg["model"].startswith("Llama-3.1-8B"), "--end-to-end is wired for the 8B shape"
     steps, warmup = args.steps, args.warmup
-    dec = dh.SyntheticLlamaDecoder(dh.LLAMA_3_1_8B, K=cfg["K"], L=cfg["L"], batch_size=cfg["B"],
+    big = cfg["model"].startswith("Llama-3.1-70B")
+    shape = dh.LLAMA_3_1_70B if big else dh.LLAMA_3_1_8B
+    # --shard head: the TENSOR-PARALLEL harness (llama_dist.py:195-220): every rank holds H / world heads and 1 / world of
+    # the MLP, o_proj / down_proj partials are all-reduced over RCCL; the ranks decode the SAME B requests (strong
+    # scaling).  --emulate-rank R/W (one process): rank R's share of a TP = W step with the all-reduce left out -- the
+    # per-GPU compute of the step, for context.  --shard batch: an independent replica per rank (weak scaling).
+    tp_rank, tp_world, reduce_fn = 0, 1, None
+    if args.shard == "head":
+        tp_rank, tp_world = rank, world
+        if args.emulate_rank:
+            tp_rank, tp_world = (int(x) for x in args.emulate_rank.split("/"))
+            reduce_fn = lambda t: None                                            # noqa: E731
+    assert big or cfg["model"].startswith("Llama-3.1-8B"), "--end-to-end is wired for the 8B and 70B shapes"
+    assert not big or tp_world > 1, "the 70B shape needs --shard head over several ranks (or --emulate-rank R/W)"
+    dec = dh.SyntheticLlamaDecoder(shape, K=cfg["K"], L=cfg["L"], batch_size=cfg["B"],
                                    max_length=cfg["M"], generation_buffer=max(256, steps + warmup + 8),
-                                   dense_layers=cfg["dense"], device=str(dev), seed=rank)
+                                   dense_layers=cfg["dense"], device=str(dev), seed=0 if tp_world > 1 else rank,
+                                   tp_rank=tp_rank, tp_world=tp_world, all_reduce=reduce_fn)
     ms, tps = dh.run_decode_benchmark(dec, cfg["P"], warmup=warmup, steps=steps, use_graph=not args.no_graph)
     ms = sharding.max_over_ranks(ms, device=dev)
+    tokens = cfg["B"] if tp_world > 1 else world * cfg["B"]
     if rank == 0:
+        what = (f"tp{tp_world} (heads and MLP sharded, 2 all-reduces per layer over RCCL"
+                + (", ALL-REDUCE LEFT OUT: one emulated rank" if reduce_fn is not None else "") + ")") if tp_world > 1 \
+            else f"dp{world} (independent replicas)"
         print(json.dumps({
-            "metric": f"end-to-end decode tokens/sec, synthetic-weight {cfg['model']} P={cfg['P']} K{cfg['K']}L{cfg['L']}",
-            "value": world * cfg["B"] * 1e3 / ms, "unit": "tokens/s", "n_gpus": world, "steps": steps,
-            "warmup": warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "metric": f"end-to-end decode tokens/sec, synthetic-weight {shape_name(big)} P={cfg['P']} K{cfg['K']}L{cfg['L']}",
+            "value": tokens * 1e3 / ms, "unit": "tokens/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if tp_world > 1 else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.config} end-to-end: {cfg['model']} B={cfg['B']} P={cfg['P']}, random weights, "
-                                   "30 LSH-sparse layers + 2 dense layers + projections/MLP/lm_head (torch-ROCm)",
-                       "launch": "eager" if args.no_graph else "hipGraph"}}))
+            "config": {"workload": f"{args.config} end-to-end: {shape_name(big)} B={cfg['B']} P={cfg['P']}, random weights, "
+                                   f"{len(dec.sparse_layers)} LSH-sparse layers + {len(dec.dense_layers)} dense layers + "
+                                   "projections/MLP/lm_head (torch-ROCm)",
+                       "parallelism": what, "launch": "eager" if args.no_graph else "hipGraph"}}))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def shape_name(big: bool) -> str:
+    return "Llama-3.1-70B" if big else "Llama-3.1-8B"
 
 
 def dry_run(args, rank, world):

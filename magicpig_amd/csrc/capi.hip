@@ -1031,6 +1031,9 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
                MP_ERR_INVALID, "mp_attn_alloc: bad head/layer/batch counts");
     MP_REQUIRE((int64_t)batch_size * num_attention_heads <= 16384, MP_ERR_UNSUPPORTED,
                "mp_attn_alloc: more than 16384 query heads per call");
+    // (the gather addresses a KV group's rows as one base + a 32-bit byte offset: max_length x 4 head_dim bytes < 2^32;
+    // the same bound as mp_lsh_alloc's)
+    MP_REQUIRE(max_length <= (1 << 22), MP_ERR_INVALID, "mp_attn_alloc: max_length must be in [1, 2^22]");
     h->device = current_device();
     h->layers = num_layers; h->H = num_attention_heads; h->Hkv = num_key_value_heads;
     h->D = head_dim; h->B = batch_size; h->G = h->H / h->Hkv; h->M = max_length;

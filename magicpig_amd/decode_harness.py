@@ -15,6 +15,13 @@ What runs where:
   * everything else (embedding, RMSNorm, q/k/v/o and MLP projections, RoPE, lm_head) is plain
     torch-ROCm -- model plumbing outside the north-star path, kept only so that an end-to-end
     tokens/s can be quoted next to the hot-path number.
+
+Tensor-parallel variant (round 4; the reference's evaluations/RULER/pred/llama_dist.py:195-220 with
+attnserver_dist.py:252-254): rank r of W holds the query / kv heads [r H/W, (r+1) H/W) -- its own LSH tables, KV store and
+window, nothing of the attention path crosses ranks -- the matching rows of wq / wk / wv / gate / up and columns of wo /
+down, and the partial outputs of o_proj and down_proj are summed over the ranks (`dist.all_reduce`: RCCL); embedding and
+lm_head are replicated.  Weights and the synthetic prompt KV are drawn per BLOCK (a rank's slice, seeded by the block's
+global index), so a TP = W run and a TP = 1 run built with `tp_blocks = W` hold the same model.
 """
 from __future__ import annotations
 
@@ -82,7 +89,26 @@ class SyntheticLlamaDecoder:
 
     def __init__(self, shape: LlamaShape = LLAMA_3_1_8B, K: int = 10, L: int = 150, batch_size: int = 1,
                  max_length: int = 8192, generation_buffer: int = 256, dense_layers=(0, 16, 32, 48, 64),
-                 device: str = "cuda:0", dtype=torch.bfloat16, seed: int = 0):
+                 device: str = "cuda:0", dtype=torch.bfloat16, seed: int = 0,
+                 tp_rank: int = 0, tp_world: int = 1, tp_blocks: int | None = None, all_reduce=None):
+        """tp_rank / tp_world: this process's slice of the heads and of the MLP (llama_dist.py); tp_blocks: the number of
+        blocks the weights are DRAWN in (default tp_world; a TP = 1 decoder with tp_blocks = W holds the model of a TP = W
+        run); all_reduce: callable summing a tensor over the ranks in place (default: torch.distributed when a process
+        group exists and tp_world > 1, else nothing to do)."""
+        self.tp_rank, self.tp_world = tp_rank, tp_world
+        self.tp_blocks = tp_blocks if tp_blocks is not None else tp_world
+        assert 0 <= tp_rank < tp_world and self.tp_blocks % tp_world == 0
+        full = shape
+        assert full.num_key_value_heads % self.tp_blocks == 0 and full.intermediate_size % self.tp_blocks == 0
+        self.full_shape = full
+        # the shape this rank computes with: its heads, its share of the MLP (hidden size and head_dim are the model's)
+        shape = LlamaShape(hidden_size=full.hidden_size, num_hidden_layers=full.num_hidden_layers,
+                           num_attention_heads=full.num_attention_heads // tp_world,
+                           num_key_value_heads=full.num_key_value_heads // tp_world,
+                           intermediate_size=full.intermediate_size // tp_world, vocab_size=full.vocab_size,
+                           rms_norm_eps=full.rms_norm_eps, rope_theta=full.rope_theta)
+        self._head_dim = full.head_dim
+        self._all_reduce_fn = all_reduce
         self.shape, self.K, self.L = shape, K, L
         self.fused_window = True      # sparse layers: decode_full_fused (two launches); False: decode_full (four)
         self.batch_size, self.max_length = batch_size, max_length
@@ -90,23 +116,36 @@ class SyntheticLlamaDecoder:
         self.num_layers = shape.num_hidden_layers
         self.dense_layers = tuple(i for i in dense_layers if i < self.num_layers)
         self.sparse_layers = tuple(i for i in range(self.num_layers) if i not in self.dense_layers)
-        H, Hkv, D = shape.num_attention_heads, shape.num_key_value_heads, shape.head_dim
+        H, Hkv, D = shape.num_attention_heads, shape.num_key_value_heads, self._head_dim
         g = torch.Generator(device=self.device).manual_seed(seed)
 
         def w(*dims, scale):
             return (torch.randn(dims, device=self.device, dtype=torch.float32, generator=g) * scale).to(dtype)
 
-        hs, it = shape.hidden_size, shape.intermediate_size
-        self.embed_tokens = w(shape.vocab_size, hs, scale=1.0)
-        self.lm_head = w(shape.vocab_size, hs, scale=hs ** -0.5)
+        # a sharded matrix is drawn block by block, every block from a generator seeded by (seed, layer, matrix, GLOBAL
+        # block index): the blocks a rank owns are the same numbers whatever tp_world is
+        nb = self.tp_blocks
+        mine = range(tp_rank * nb // tp_world, (tp_rank + 1) * nb // tp_world)
+
+        def wb(layer, which, rows, cols, scale, dim):
+            parts = []
+            for blk in mine:
+                gb = torch.Generator(device=self.device).manual_seed(((seed * 1009 + layer) * 16 + which) * 4096 + blk + 1)
+                parts.append((torch.randn((rows, cols), device=self.device, dtype=torch.float32, generator=gb) * scale).to(dtype))
+            return torch.cat(parts, dim=dim).contiguous()
+
+        hs, it = full.hidden_size, full.intermediate_size
+        Hf, Hkvf = full.num_attention_heads, full.num_key_value_heads
+        self.embed_tokens = w(full.vocab_size, hs, scale=1.0)                     # replicated (same seed on every rank)
+        self.lm_head = w(full.vocab_size, hs, scale=hs ** -0.5)
         self.norm_weight = torch.ones(hs, device=self.device, dtype=dtype)
         self.layers = []
-        for _ in range(self.num_layers):
+        for li in range(self.num_layers):
             self.layers.append(dict(
-                wq=w(H * D, hs, scale=hs ** -0.5), wk=w(Hkv * D, hs, scale=hs ** -0.5),
-                wv=w(Hkv * D, hs, scale=hs ** -0.5), wo=w(hs, H * D, scale=(H * D) ** -0.5),
-                gate=w(it, hs, scale=hs ** -0.5), up=w(it, hs, scale=hs ** -0.5),
-                down=w(hs, it, scale=it ** -0.5),
+                wq=wb(li, 0, Hf // nb * D, hs, hs ** -0.5, 0), wk=wb(li, 1, Hkvf // nb * D, hs, hs ** -0.5, 0),
+                wv=wb(li, 2, Hkvf // nb * D, hs, hs ** -0.5, 0), wo=wb(li, 3, hs, Hf // nb * D, (Hf * D) ** -0.5, 1),
+                gate=wb(li, 4, it // nb, hs, hs ** -0.5, 0), up=wb(li, 5, it // nb, hs, hs ** -0.5, 0),
+                down=wb(li, 6, hs, it // nb, it ** -0.5, 1),
                 ln1=torch.ones(hs, device=self.device, dtype=dtype),
                 ln2=torch.ones(hs, device=self.device, dtype=dtype)))
         # RoPE tables (models/llama.py:114-126)
@@ -134,14 +173,17 @@ class SyntheticLlamaDecoder:
         """Stands in for `LLM.prefill` (models/llama.py:304-325): per layer a KV cache bf16
         [seq_len, Hkv, D] (random unless `kv(layer) -> (k, v)` supplies one) is handed to the attention
         state exactly as `layer_prefill` does (:264, 282: fill + build_table)."""
-        Hkv, D = self.shape.num_key_value_heads, self.shape.head_dim
+        Hkv, D = self.shape.num_key_value_heads, self._head_dim
         for layer in range(self.num_layers):
             if kv is not None:
                 k, v = kv(layer)
-            else:
-                g = torch.Generator(device=self.device).manual_seed(seed * 1000 + layer)
-                k = torch.randn((seq_len, Hkv, D), device=self.device, generator=g).to(self.dtype)
-                v = torch.randn((seq_len, Hkv, D), device=self.device, generator=g).to(self.dtype)
+            else:       # per GLOBAL kv head: a rank's prompt KV does not depend on tp_world
+                ks, vs = [], []
+                for gkv in range(self.tp_rank * Hkv, (self.tp_rank + 1) * Hkv):
+                    g = torch.Generator(device=self.device).manual_seed((seed * 1000 + layer) * 64 + gkv)
+                    ks.append(torch.randn((seq_len, 1, D), device=self.device, generator=g).to(self.dtype))
+                    vs.append(torch.randn((seq_len, 1, D), device=self.device, generator=g).to(self.dtype))
+                k, v = torch.cat(ks, dim=1), torch.cat(vs, dim=1)
             if layer in self.dense_index:
                 kk = k.transpose(0, 1).contiguous()
                 self.dense_server.fill(self.dense_index[layer], request_id, kk, v.transpose(0, 1).contiguous(),
@@ -155,7 +197,7 @@ class SyntheticLlamaDecoder:
     # ------------------------------------------------------------------ decode
     def _dense_attention(self, q, k, v, layer: int) -> torch.Tensor:
         """models/attnserver.py:235-259: append, then exact attention over the whole sequence."""
-        B, H, Hkv, D = self.batch_size, self.shape.num_attention_heads, self.shape.num_key_value_heads, self.shape.head_dim
+        B, H, Hkv, D = self.batch_size, self.shape.num_attention_heads, self.shape.num_key_value_heads, self._head_dim
         di = self.dense_index[layer]
         self.dense_server.append(di, k.reshape(B, Hkv, D).contiguous(), v.reshape(B, Hkv, D).contiguous(),
                                  self.dense_len - 1)
@@ -171,7 +213,7 @@ class SyntheticLlamaDecoder:
     def layer_compute(self, layer: int, hidden_states: torch.Tensor, position_ids: torch.Tensor) -> torch.Tensor:
         """models/llama.py:185-220 (+ pre/post_attention_compute :134-183)."""
         W = self.layers[layer]
-        B, H, Hkv, D = self.batch_size, self.shape.num_attention_heads, self.shape.num_key_value_heads, self.shape.head_dim
+        B, H, Hkv, D = self.batch_size, self.shape.num_attention_heads, self.shape.num_key_value_heads, self._head_dim
         eps = self.shape.rms_norm_eps
         residual = hidden_states
         x = rms_norm(hidden_states, W["ln1"], eps)
@@ -185,10 +227,25 @@ class SyntheticLlamaDecoder:
         else:
             decode = self.attention_server.decode_full_fused if self.fused_window else self.attention_server.decode_full
             attn = decode(q.contiguous(), k.contiguous(), v.contiguous(), self.sparse_index[layer])
-        h = residual + F.linear(attn.reshape(B, 1, H * D), W["wo"])
+        o = F.linear(attn.reshape(B, 1, H * D), W["wo"])
+        self._all_reduce(o)                                   # llama_dist.py:209: partial o_proj outputs summed over the ranks
+        h = residual + o
         y = rms_norm(h, W["ln2"], eps)
         y = F.linear(F.silu(F.linear(y, W["gate"])) * F.linear(y, W["up"]), W["down"])
+        self._all_reduce(y)                                   # llama_dist.py:218: partial down_proj outputs
         return h + y
+
+    def _all_reduce(self, t: torch.Tensor) -> None:
+        """Sum `t` over the tensor-parallel ranks in place (RCCL through torch.distributed); nothing to do at TP = 1."""
+        if self._all_reduce_fn is not None:
+            self._all_reduce_fn(t)
+            return
+        if self.tp_world > 1:
+            import torch.distributed as dist
+
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("tensor-parallel decoder: no process group (torch.distributed.init_process_group first)")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
     @torch.inference_mode()
     def inference(self, input_ids: torch.Tensor, position_ids: torch.Tensor) -> torch.Tensor:

@@ -197,3 +197,85 @@ def test_decode_benchmark_loop_runs():
                                    dense_layers=(0,), seed=1)
     ms, tps = dh.run_decode_benchmark(dec, prompt_len=1500, warmup=4, steps=8)
     assert ms > 0 and tps > 0
+
+
+def test_tensor_parallel_decoder_equals_the_unsharded_one():
+    """The TP variant of the harness (evaluations/RULER/pred/llama_dist.py:195-220 + attnserver_dist.py:252-254: heads
+    and MLP columns sharded, the partial o_proj / down_proj outputs all-reduced) with TWO ranks emulated by two threads
+    on one device -- each rank its own decoder (own LSH tables, KV store, window: nothing of the attention path crosses
+    ranks) and an all_reduce that meets the other rank's partial at a barrier -- against the TP = 1 decoder holding
+    the same model (weights and prompt KV are drawn per block).  K = 1, L = 64: practically every token is sampled, so
+    the comparison is not at the mercy of a token flipping in or out of a sample.  Logits agree to bf16 summation
+    order (two bf16 partials added vs one bf16 sum)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import threading
+
+    from magicpig_amd import decode_harness as dh
+
+    shape = dh.LlamaShape(hidden_size=512, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2,
+                          intermediate_size=1024, vocab_size=1000)
+    B, P, steps, W = 2, 600, 3, 2
+    common = dict(K=1, L=64, batch_size=B, max_length=1024, generation_buffer=8, dense_layers=(0,), seed=11)
+    one = dh.SyntheticLlamaDecoder(shape, tp_blocks=W, **common)
+    for b in range(B):
+        one.prefill_synthetic(b, P, seed=b)
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    ids = torch.randint(0, 1000, (B, steps), device="cuda", generator=gen)
+    want = []
+    for t in range(steps):
+        pos = torch.full((B, 1), P + t, device="cuda", dtype=torch.long)
+        want.append(one.inference(ids[:, t:t + 1], pos).clone())
+    torch.cuda.synchronize()
+
+    # ---- two ranks, two threads, one device: partial sums meet at a barrier (all launches go to the default stream,
+    # so "both partials enqueued, then the sum" is also their order on the device)
+    meet = threading.Barrier(W)
+    slot = [None] * W
+    errors = []
+
+    def make_reduce(rank):
+        def all_reduce(t):
+            slot[rank] = t
+            meet.wait()
+            total = slot[0] + slot[1]
+            meet.wait()                     # both have read both partials
+            t.copy_(total)
+        return all_reduce
+
+    got = [[None] * steps for _ in range(W)]
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            dec = dh.SyntheticLlamaDecoder(shape, tp_rank=rank, tp_world=W, all_reduce=make_reduce(rank), **common)
+            assert dec.shape.num_attention_heads == 2 and dec.shape.num_key_value_heads == 1
+            for b in range(B):
+                dec.prefill_synthetic(b, P, seed=b)
+            for t in range(steps):
+                pos = torch.full((B, 1), P + t, device="cuda", dtype=torch.long)
+                got[rank][t] = dec.inference(ids[:, t:t + 1], pos).clone()
+            torch.cuda.synchronize()
+        except BaseException as e:          # noqa: BLE001 -- a failing rank must not leave the other at the barrier
+            errors.append((rank, repr(e)))
+            meet.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=600)
+    assert not errors, errors
+    for t in range(steps):
+        assert torch.equal(got[0][t], got[1][t])                      # replicated lm_head on identical hidden states
+        a, b = got[0][t].float(), want[t].float()
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max() <= 0.06 * b.abs().max(), (t, float((a - b).abs().max()), float(b.abs().max()))
+        assert torch.equal(a.argmax(-1), b.argmax(-1)) or (a - b).abs().max() <= 0.02 * b.abs().max()
+    # the slices really are the unsharded model's: rank r's rows of wq / columns of wo are block r of the TP = 1 matrices
+    r1 = dh.SyntheticLlamaDecoder(shape, tp_rank=1, tp_world=W, **{**common, "dense_layers": (0,)})
+    D, H = 128, 4
+    assert torch.equal(r1.layers[1]["wq"], one.layers[1]["wq"][H // W * D:])
+    assert torch.equal(r1.layers[1]["wo"], one.layers[1]["wo"][:, H // W * D:])
+    assert torch.equal(r1.layers[2]["down"], one.layers[2]["down"][:, 512:])
+    assert torch.equal(r1.embed_tokens, one.embed_tokens)
