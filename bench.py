@@ -528,16 +528,20 @@ def main():
         t_s = time.time() - t_s
         q = torch.empty((NQ, NL, B, H, 1, D), device=dev, dtype=torch.float32)
         hv = queries == "heavy" or (queries == "auto" and data != "randn")
+        jj = torch.zeros((NQ, NL, B, H), device=dev, dtype=torch.long)
         for b in range(B):
             for hl in range(H):                 # one query head of one request at a time, seeded by its GLOBAL id
                 gh = g_kv_heads[hl // G_heads] * G_heads + hl % G_heads
                 gen_q = torch.Generator(device=dev).manual_seed(2000 + 100_003 * g_requests[b] + gh)
                 q[:, :, b, hl, 0] = torch.randn((NQ, NL, D), device=dev, dtype=torch.float32, generator=gen_q)
-                if hv:   # pulled toward one (centred) key of its kv group: q <- 0.5 q + 3 k_j
-                    j = torch.randint(0, n, (NQ, NL), device=dev, generator=gen_q)
-                    for li in range(NL):
-                        kc = srv.attn_server.get_key_cache(li)                     # [B, Hkv, M, D] centred keys
-                        q[:, li, b, hl, 0] = 0.5 * q[:, li, b, hl, 0] + 3.0 * kc[b, hl // G_heads, j[:, li]].float()
+                if hv:
+                    jj[:, :, b, hl] = torch.randint(0, n, (NQ, NL), device=dev, generator=gen_q)
+        if hv:   # every query is pulled toward one (centred) key of its kv group: q <- 0.5 q + 3 k_j (one gather per layer)
+            bi = torch.arange(B, device=dev)[None, :, None].expand(NQ, B, H)
+            gi = (torch.arange(H, device=dev) // G_heads)[None, None, :].expand(NQ, B, H)
+            for li in range(NL):
+                kc = srv.attn_server.get_key_cache(li)                             # [B, Hkv, M, D] centred keys
+                q[:, li, :, :, 0] = 0.5 * q[:, li, :, :, 0] + 3.0 * kc[bi, gi, jj[:, li]].float()
         return srv, q.to(torch.bfloat16), hv, t_s
 
     server, qs, heavy, t_setup = build_workload(args.data, args.queries)
