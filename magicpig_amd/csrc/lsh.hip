@@ -606,7 +606,24 @@ __device__ __forceinline__ void lsh_head_body(
     const int BHp = (AD > 0) ? aa.BHp : 1;
     const int64_t h = (AD > 0) ? (int64_t)(blockIdx.x % BHp) : (int64_t)blockIdx.x;
     const int rank = (AD > 0) ? (int)(blockIdx.x / BHp) : 0;
-    if (AD > 0 && h >= aa.BH) return;
+    // (a padding block -- h >= B*H, only where B*H is not a multiple of 8 -- leaves BELOW, behind the query row's request:
+    // in front of it the test was a kernel-argument round trip of its own ahead of the row's address)
+    const bool padding_block = AD > 0 && h >= aa.BH;
+    // -- the query row FIRST (its round trip heads the dependent chain: q -> norm -> LDS -> dots): wave 0, D/64
+    //    elements per lane (D = 64, 128 or 256).  Requested before anything else touches the kernel arguments: they
+    //    arrive in half a dozen dependent scalar loads, and behind them the row was requested ~1 us into the kernel.
+    uint32_t e01 = 0u, e23 = 0u;                                 // elements 0,1 | 2,3 of this lane (bf16 pairs)
+    if ((HASH == 1 || HASH == 3) && wave == 0) {                 // ONE load per lane, no loop: nothing to wait for here
+        const int per0 = ha.D >> 6;
+        const uint16_t* src = ha.q + (padding_block ? 0 : h) * ha.D + lane * per0;
+        if (per0 == 2) e01 = *reinterpret_cast<const uint32_t*>(src);
+        else if (per0 == 1) e01 = *src;
+        else {
+            const uint2 t = *reinterpret_cast<const uint2*>(src);
+            e01 = t.x;
+            e23 = t.y;
+        }
+    }
     MP_STAMP_INIT(stamp);
     const int clog = (AD > 0) ? aa.cluster_log2 : 0;
     const bool lead = rank == 0;                              // the member that writes codes / ||q||
@@ -620,22 +637,8 @@ __device__ __forceinline__ void lsh_head_body(
     const int64_t trem = M - t0;
     const uint32_t tlen = (AD > 0) ? (uint32_t)(trem <= 0 ? 0 : (trem < range_len ? trem : range_len)) : (uint32_t)M;
 
-    // -- the query row FIRST (its round trip heads the dependent chain: q -> norm -> LDS -> dots): wave 0, D/64
-    //    elements per lane (D = 64, 128 or 256).  Requested before anything else touches the kernel arguments: they
-    //    arrive in half a dozen dependent scalar loads, and behind them the row was requested ~1 us into the kernel.
-    uint32_t e01 = 0u, e23 = 0u;                                 // elements 0,1 | 2,3 of this lane (bf16 pairs)
-    if ((HASH == 1 || HASH == 3) && wave == 0) {                 // ONE load per lane, no loop: nothing to wait for here
-        const int per0 = ha.D >> 6;
-        const uint16_t* src = ha.q + h * ha.D + lane * per0;
-        if (per0 == 2) e01 = *reinterpret_cast<const uint32_t*>(src);
-        else if (per0 == 1) e01 = *src;
-        else {
-            const uint2 t = *reinterpret_cast<const uint2*>(src);
-            e01 = t.x;
-            e23 = t.y;
-        }
-    }
     MP_STAMP(stamp, 16);
+    if (padding_block) return;
     if (tid == 0) {
         *s_ntail = 0;
         s_tmp[30] = 0;                                            // pieces that overflow their direct slot
@@ -644,20 +647,22 @@ __device__ __forceinline__ void lsh_head_body(
     // collision bitmaps and piece lengths start at zero: done here, under the query row's round trip
     for (int i = tid; i < 2 * words; i += RT_THREADS) s_u32[i] = 0u;
     for (int l = tid; l < Lpad; l += RT_THREADS) s_len[l] = 0;
-    // -- the layer's id width and the state of this KV group's payloads, as the device knows them: independent scalar
-    //    loads behind the row's request, one wait, no short-circuit between them; first needed when table words are counted
-    if (AD > 0 && aa.idbits_dev != nullptr) {
-        const int ib = *aa.idbits_dev;
-        int bad = 1;
-        unsigned int av = 0u, kv = 1u;
+    // -- the layer's id width and the state of this KV group's payloads, as the device knows them: four words, requested
+    //    HERE -- behind the row's request, in front of the hyperplanes -- as VECTOR loads (buffer loads of a uniform
+    //    address) and looked at only where table words are first counted, behind the hash.  As scalar loads they came
+    //    back through lgkmcnt, which the compiler waits on as a whole: it issued two of them, waited, issued the
+    //    third, waited (round 3: three dependent round trips at the head of the kernel; round 4's first form: two, in
+    //    front of the plane loads and of wave 0's look at the query row -- "q row in" 0.4 us late under the stamps).
+    //    Vector loads return in order behind the row and are counted exactly.
+    uint32_t st_ib = 0u, st_bad = 1u, st_av = 0u, st_kv = 1u;
+    const bool st_live = AD > 0 && aa.idbits_dev != nullptr;       // uniform
+    if (st_live) {
+        st_ib = __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(aa.idbits_dev), 0, 4, 0x00020000), 0, 0, 0);
         if (aa.pay_bad != nullptr) {
-            bad = aa.pay_bad[g];
-            av = aa.att_ver[g];
-            kv = aa.kn_ver[g];
+            st_bad = __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(aa.pay_bad + g), 0, 4, 0x00020000), 0, 0, 0);
+            st_av = __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(aa.att_ver + g), 0, 4, 0x00020000), 0, 0, 0);
+            st_kv = __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(aa.kn_ver + g), 0, 4, 0x00020000), 0, 0, 0);
         }
-        idbits = ib;
-        pay = (ib != 0) & (bad == 0) & (av == kv);
-        idmask = idbits ? ((1u << idbits) - 1u) : 0xffffffffu;
     }
     bool bits_exchanged = false;                                 // uniform: the split hash delivered every sign word
     if (HASH == 2) {   // the hash ran as its own launch: only the raw query row (for q.k) and ||q|| are fetched here
@@ -908,6 +913,15 @@ __device__ __forceinline__ void lsh_head_body(
         for (int l = tid; l < L; l += RT_THREADS) ha.codes_out[h * L + l] = code_of(l);
         MP_STAMP_FLUSH(stamp);
         return;
+    }
+    if (st_live) {                                                  // (the four state words requested at the head of the kernel)
+        const int ib = __builtin_amdgcn_readfirstlane((int)st_ib);
+        const int bad = __builtin_amdgcn_readfirstlane((int)st_bad);
+        const uint32_t av = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_av);
+        const uint32_t kv = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_kv);
+        idbits = ib;
+        pay = (ib != 0) & (bad == 0) & (av == kv);
+        idmask = idbits ? ((1u << idbits) - 1u) : 0xffffffffu;
     }
     const int32_t* slots = (AD > 0) ? aa.slots : nullptr;
     if (AD > 0 && HASH != 0 && slots != nullptr) {
