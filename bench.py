@@ -122,6 +122,9 @@ def parse():
     ap.add_argument("--emulate-rank", default=None,
                     help="R/W: ONE process that serves the units rank R of W would own (no process group): what the "
                          "multi-GPU tests compare a real rank's outputs with")
+    ap.add_argument("--ab-option", default="", help="NAME=v0,v1[,..]: A/B of a library debug option on one workload (alternating "
+                    "timed regions of --steps graph replays each); prints its own JSON line instead of the bench line")
+    ap.add_argument("--ab-reps", type=int, default=5)
     ap.add_argument("--distinct-layers", type=int, default=0,
                     help="DIAGNOSTIC (not a valid bench line): the step's launches cycle over only this many of the "
                          "model's sparse layers -- the HBM footprint a step touches shrinks (address translation, "
@@ -594,6 +597,43 @@ def main():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             step()
+
+    if args.ab_option:
+        # A/B of a library option that is read at call time: one captured step per value over the SAME workload, timed
+        # alternately (profiles/*_ab_*.txt).  Not a bench line.
+        name, vals = args.ab_option.split("=")
+        vals = [int(v) for v in vals.split(",")]
+        graphs = []
+        for v in vals:
+            L.set_option(name, v)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            graphs.append(g)
+        L.set_option(name, vals[0])
+        res = {str(v): [] for v in vals}
+        for rep in range(args.ab_reps):
+            for v, g in zip(vals, graphs):
+                for i in range(args.warmup):
+                    q_static.copy_(qs[i % NQ])
+                    g.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    q_static.copy_(qs[i % NQ])
+                    g.replay()
+                torch.cuda.synchronize()
+                res[str(v)].append(round((time.perf_counter() - t0) / args.steps / NL * 1e6, 3))
+        server.attn_server.check()
+        print(json.dumps({"ab_option": name, "config": args.config, "data": args.data, "steps": args.steps,
+                          "us_per_layer": res}))
+        return
 
     def run_steps(k0, count):
         for i in range(count):
