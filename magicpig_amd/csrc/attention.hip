@@ -816,20 +816,6 @@ hipError_t launch_host_rows(const int32_t* ind_host, const int32_t* nnz_host, in
                        (int)((small_bytes + 15) / 16));
     return hipGetLastError();
 }
-// relay_kernel plus a second, 4-byte-granular segment (device to device): one launch for the attention entry's small
-// arguments (q | qn: pinned -> HBM) and the counts of the rows it recognised (the lsh handle's step buffer -> the store's own)
-__global__ __launch_bounds__(1024) void relay2_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16,
-                                                      const int32_t* __restrict__ src2, int32_t* __restrict__ dst2, int n4) {
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
-    for (int i = threadIdx.x; i < n4; i += blockDim.x) dst2[i] = src2[i];
-}
-hipError_t launch_relay2(const void* src, void* dst, size_t bytes, const int32_t* src2, int32_t* dst2, int n4,
-                         hipStream_t st) {
-    hipLaunchKernelGGL(relay2_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const uint4*>(src),
-                       reinterpret_cast<uint4*>(dst), (int)((bytes + 15) / 16), src2, dst2, n4);
-    return hipGetLastError();
-}
-
 // host-buffer mode: "everything before me on this stream is done" as a word in pinned memory (capi.hip: host_wait)
 __global__ void host_flag_kernel(volatile unsigned int* flag, unsigned int value) {
     *flag = value;

@@ -42,7 +42,7 @@ hipError_t launch_lsh_subbounds(const int32_t*, int32_t*, int, int, int, int64_t
 hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int, int32_t*, int32_t*, int*, const float*, int,
                             int, int*, bool*, hipStream_t);
 hipError_t launch_lsh_retrieve(const int32_t*, const int32_t*, const int32_t*, int32_t*, int32_t*, int,
-                               int, int, int, int64_t, int, const int*, int32_t*, uint32_t*, hipStream_t);
+                               int, int, int, int64_t, int, const int*, int32_t*, int32_t*, uint32_t*, hipStream_t);
 hipError_t launch_lsh_attach_norms(int32_t*, const float*, int, int, int64_t, int, int*, hipStream_t);
 hipError_t launch_lsh_hash_retrieve(const int32_t*, const int32_t*, const uint16_t*, const uint16_t*,
                                     const float*, int, int, int, int32_t*, float*, int32_t*, int32_t*,
@@ -75,7 +75,6 @@ hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, 
 bool lsh_hash_only_supported(int L);
 hipError_t launch_attn_ticket_check(int*, int, int*, hipStream_t);
 hipError_t launch_relay(const void*, void*, size_t, hipStream_t);
-hipError_t launch_relay2(const void*, void*, size_t, const int32_t*, int32_t*, int, hipStream_t);
 hipError_t launch_host_flag(unsigned int*, unsigned int, hipStream_t);
 hipError_t launch_host_rows(const int32_t*, const int32_t*, int32_t*, int64_t, int, const void*, void*, size_t, int,
                             hipStream_t);
@@ -365,6 +364,9 @@ struct mp_attn {
     HostFlag hostflag;             // host-buffer mode: completion word (host_flag_wait)
     int32_t* ind_rows = nullptr;   // host-buffer mode: [BH][M] device copy of `ind`
     int32_t* last_nnz = nullptr;   // [BH] staging copy of host-side nnz
+    std::vector<int32_t> lastz_host;   // host-buffer fast path: the counts of the last call as the caller held them; get_score
+                                       // uploads them into last_nnz on demand (lastz == nullptr then) -- the lsh handle's device
+                                       // copy the kernel read does not outlive that handle's next call
     const int32_t* lastz = nullptr;// device nnz of the last call (for get_score): last_nnz or the
                                    // caller's own device buffer (valid until it changes)
     int score_state = 0;           // 0 none, 1 logits, 2 probabilities
@@ -791,7 +793,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
         h->lastq = query;
         h->last_layer = layer_id;
         MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], query, results,
-                                         nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, nullptr, nullptr, st));
+                                         nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, nullptr, nullptr, nullptr, st));
         return MP_OK;
     }
     // host callers (models/attnserver.py:299 passes CPU tensors).  Zero copy: the kernel reads the codes from the handle's
@@ -824,7 +826,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
             MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id],
                                              reinterpret_cast<const int32_t*>(hd + o_codes),
                                              reinterpret_cast<int32_t*>(res_dev), reinterpret_cast<int32_t*>(hd), BH,
-                                             h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, h->results,
+                                             h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, h->results, h->nnz,
                                              reinterpret_cast<uint32_t*>(hd + o_sums), st));
             if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) return rc;
             memcpy(nnz, hp, (size_t)BH * 4);
@@ -855,7 +857,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     h->lastq = h->last_query;
     h->last_layer = layer_id;
     MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], h->last_query,
-                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, nullptr, nullptr, st));
+                                     h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, nullptr, nullptr, nullptr, st));
     int32_t* d_offs = reinterpret_cast<int32_t*>(h->small.dp) + BH;           // dp: [nnz BH | offs BH + 1]
     MP_HIP_CHECK(launch_ragged_offsets(h->nnz, BH, h->M, d_offs, st));
     MP_HIP_CHECK(hipMemcpyAsync(h->small.dp, h->nnz, (size_t)BH * 4, hipMemcpyDeviceToDevice, st));
@@ -1287,27 +1289,38 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
                 l = nullptr;
         }
         if (l != nullptr) {
-            for (int i = 0; i < BH && l != nullptr; ++i) {
+            // Launched BEFORE the rows are verified: the attention kernel works on the rows + counts the retrieve kernel left
+            // in HBM while the host checks the caller's rows against the retrieve's checksums.  A row that was edited (or a
+            // stale pairing) is found before anything is handed back: the launch is waited for, its outputs dropped, and
+            // the upload path below serves the caller's rows.  Few heads (B*H <= 64: cfg 1 / 4): ONE launch, every
+            // workgroup reads its (q | qn) straight from the pinned block, two PCIe reads under its index loads
+            // (-5 us per call at cfg 1 against a relay launch in front).  Many heads (cfg 2 / 3: 256 heads x the
+            // workgroups of a head, 256 bytes each) would queue on PCIe -- measured +23 us -- so there a one-workgroup
+            // relay brings (q | qn) into HBM first.
+            char* hd = reinterpret_cast<char*>(h->small.hd);
+            const bool direct = BH <= 64;
+            if (!direct) MP_HIP_CHECK(launch_relay(hd, dp, o_nnz, st));
+            const char* qsrc = direct ? hd : dp;
+            rc = attn_run(h, layer_id, false, K, L, reinterpret_cast<uint16_t*>(hd + o_out),
+                          reinterpret_cast<float*>(hd + o_mve), qsrc + o_q, query_dtype,
+                          reinterpret_cast<const float*>(qsrc + o_qn), l->results, l->nnz, st);
+            if (rc) return rc;
+            bool same = true;
+            for (int i = 0; i < BH && same; ++i) {
                 int64_t z = nnz[i];
                 z = z < 0 ? 0 : (z > h->M ? h->M : z);
                 uint32_t s1, s2;
                 host_row_sum(ind + (size_t)i * h->M, z, &s1, &s2);
-                if (s1 != l->host_ret.sums[2 * i] || s2 != l->host_ret.sums[2 * i + 1]) l = nullptr;
+                same = s1 == l->host_ret.sums[2 * i] && s2 == l->host_ret.sums[2 * i + 1];
             }
-        }
-        if (l != nullptr) {
-            char* hd = reinterpret_cast<char*>(h->small.hd);
-            // ONE launch for (q | qn) pinned -> HBM and the counts, which must outlive the lsh handle's next call
-            // (get_score reads them later): lsh step buffer -> this store's own
-            MP_HIP_CHECK(launch_relay2(hd, dp, o_nnz, reinterpret_cast<const int32_t*>(hd + o_nnz), h->last_nnz, BH, st));
-            rc = attn_run(h, layer_id, false, K, L, reinterpret_cast<uint16_t*>(hd + o_out),
-                          reinterpret_cast<float*>(hd + o_mve), dp + o_q, query_dtype,
-                          reinterpret_cast<const float*>(dp + o_qn), l->results, h->last_nnz, st);
-            if (rc) return rc;
             if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) return rc;
-            memcpy(output, hp + o_out, (size_t)BH * h->D * 2);
-            memcpy(mve, hp + o_mve, (size_t)2 * BH * 4);
-            return MP_OK;
+            if (same) {
+                h->lastz_host.assign(nnz, nnz + BH);
+                h->lastz = nullptr;
+                memcpy(output, hp + o_out, (size_t)BH * h->D * 2);
+                memcpy(mve, hp + o_mve, (size_t)2 * BH * 4);
+                return MP_OK;
+            }
         }
     }
     // Zero copy: ONE launch brings (q | qn | nnz) and the first nnz[h] entries of every index row into HBM with
@@ -1489,6 +1502,12 @@ int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream) {
                                             h->seg_R, h->M, st));
             h->seg_cnt = nullptr;
             h->seg_R = 1;
+        }
+        if (h->lastz == nullptr) {                      // host-buffer fast path: the counts are still on the host
+            MP_REQUIRE((int)h->lastz_host.size() == h->B * h->H, MP_ERR_STATE, "mp_attn_get_score: no counts of the last call");
+            MP_HIP_CHECK(hipMemcpyAsync(h->last_nnz, h->lastz_host.data(), h->lastz_host.size() * 4, hipMemcpyHostToDevice, st));
+            MP_HIP_CHECK(hipStreamSynchronize(st));     // (the pageable source may be rewritten by the next call)
+            h->lastz = h->last_nnz;
         }
         MP_HIP_CHECK(launch_attn_normalize(h->score, h->lastz, h->head_mz, h->B * h->H, h->M, st));
         h->score_state = 2;

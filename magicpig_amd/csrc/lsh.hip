@@ -557,6 +557,7 @@ struct AttnArgs {
     // position-weighted checksum (two u32 sums) per row, by which the attention entry recognises the rows it is handed
     int32_t* rows2;          // [BH][M] or nullptr
     uint32_t* rowsum;        // [BH][2] or nullptr
+    int32_t* nnz2;           // [BH] or nullptr: a second copy of the counts, in HBM beside rows2 (nnz is pinned host memory then)
 };
 
 // HASH: 0 = the codes are given (`query`), 1 = fused SimHash prologue, 3 = the same with the planes split over the
@@ -1211,7 +1212,10 @@ __device__ __forceinline__ void lsh_head_body(
             ++off;
         }
     }
-    if (tid == 0 && (AD == 0 || clog == 0)) nnz[h] = total;
+    if (tid == 0 && (AD == 0 || clog == 0)) {
+        nnz[h] = total;
+        if (AD == 0 && aa.nnz2 != nullptr) aa.nnz2[h] = total;
+    }
     MP_STAMP(stamp, 21);
     if (AD == 0) {
         if (aa.rowsum != nullptr) {         // block sum of the two u32 checksums (wrap-around arithmetic: order-free)
@@ -1457,9 +1461,11 @@ __global__ __launch_bounds__(RT_THREADS, 4) void lsh_retrieve_kernel(
     const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     const int32_t* __restrict__ query, int32_t* __restrict__ results, int32_t* __restrict__ nnz,
     int G, int L, int NB, int64_t M, int R, int words, int Lpad, const int* __restrict__ idbits_dev, HashArgs ha,
-    int32_t* __restrict__ rows2, uint32_t* __restrict__ rowsum, unsigned long long* __restrict__ stamp) {
+    int32_t* __restrict__ rows2, int32_t* __restrict__ nnz2, uint32_t* __restrict__ rowsum,
+    unsigned long long* __restrict__ stamp) {
     AttnArgs aa = {};
     aa.rows2 = rows2;
+    aa.nnz2 = nnz2;
     aa.rowsum = rowsum;
     // the layer's id width from the device word (written in stream order by a fill that widens the layer): a launch
     // argument would be frozen in a captured graph
@@ -1760,14 +1766,15 @@ static hipError_t retrieve_attr_once() {
 
 hipError_t launch_lsh_retrieve(const int32_t* bounds, const int32_t* table, const int32_t* query,
                                int32_t* results, int32_t* nnz, int BH, int G, int L, int NB,
-                               int64_t M, int R, const int* idbits, int32_t* rows2, uint32_t* rowsum, hipStream_t st) {
+                               int64_t M, int R, const int* idbits, int32_t* rows2, int32_t* nnz2, uint32_t* rowsum,
+                               hipStream_t st) {
     const int words = (int)((M + 31) / 32);
     const int Lpad = (L + 63) & ~63;
     hipError_t e = retrieve_attr_once();
     if (e != hipSuccess) return e;
     HashArgs ha = {};
     hipLaunchKernelGGL((lsh_retrieve_kernel<0, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
-                       st, bounds, table, query, results, nnz, G, L, NB, M, R, words, Lpad, idbits, ha, rows2, rowsum, g_stamp);
+                       st, bounds, table, query, results, nnz, G, L, NB, M, R, words, Lpad, idbits, ha, rows2, nnz2, rowsum, g_stamp);
     return hipGetLastError();
 }
 
@@ -1786,11 +1793,11 @@ hipError_t launch_lsh_hash_retrieve(const int32_t* bounds, const int32_t* table,
     if (D >= 128)
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 16>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, R, words,
-                           Lpad, idbits, ha, (int32_t*)nullptr, (uint32_t*)nullptr, g_stamp);
+                           Lpad, idbits, ha, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr, g_stamp);
     else
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 8>), dim3(BH), dim3(RT_THREADS), retrieve_lds_bytes(M, L),
                            st, bounds, table, (const int32_t*)nullptr, results, nnz, G, L, NB, M, R, words,
-                           Lpad, idbits, ha, (int32_t*)nullptr, (uint32_t*)nullptr, g_stamp);
+                           Lpad, idbits, ha, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr, g_stamp);
     return hipGetLastError();
 }
 
@@ -1805,11 +1812,11 @@ hipError_t launch_lsh_hash_only(const uint16_t* q, const uint16_t* Wk, const flo
     if (D >= 128)
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 16>), dim3(rows), dim3(RT_THREADS), lds, st, (const int32_t*)nullptr,
                            (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 1, L,
-                           1 << K, (int64_t)0, 1, 0, Lpad, (const int*)nullptr, ha, (int32_t*)nullptr, (uint32_t*)nullptr, g_stamp);
+                           1 << K, (int64_t)0, 1, 0, Lpad, (const int*)nullptr, ha, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr, g_stamp);
     else
         hipLaunchKernelGGL((lsh_retrieve_kernel<1, 8>), dim3(rows), dim3(RT_THREADS), lds, st, (const int32_t*)nullptr,
                            (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 1, L,
-                           1 << K, (int64_t)0, 1, 0, Lpad, (const int*)nullptr, ha, (int32_t*)nullptr, (uint32_t*)nullptr, g_stamp);
+                           1 << K, (int64_t)0, 1, 0, Lpad, (const int*)nullptr, ha, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr, g_stamp);
     return hipGetLastError();
 }
 

@@ -364,6 +364,45 @@ def test_host_buffer_modes_agree(mp, mode, pinned):
         L_.set_option("host_flag_wait", 0)
 
 
+@pytest.mark.parametrize("pinned", [True, False])
+def test_host_mode_scores_outlive_the_next_retrieve(mp, pinned):
+    """MP_MEM_HOST attention over the rows batch_retrieve has just handed out runs on the lsh handle's HBM copy of rows
+    and counts (one launch, verified against the caller's rows while the kernel runs).  That copy is rewritten by the
+    handle's next retrieve: get_score afterwards must still normalise with the counts of ITS call."""
+    g = cases.load_golden("gqa_32h")
+    seed, B, H, Hkv, n, M, D, K, L = (int(x) for x in g["meta"])
+    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L)
+    BH = B * H
+    sh = mp.SimHash(bf16_t(W, "cuda"), K, L)
+    lsh, srv = mp.LSH(), mp.SparseAttentionServer()
+    lsh.alloc(K, L, 1, H, Hkv, B, M)
+    srv.alloc(1, H, Hkv, D, B, M)
+    lsh.fastfill(0, 0, sh.keys(bf16_t(keys[0], "cuda")))
+    srv.fill(0, 0, bf16_t(keys[0], "cuda"), bf16_t(vals[0], "cuda"), torch.from_numpy(kns[0]).cuda())
+    mk = (lambda t: t.pin_memory()) if pinned else (lambda t: t)
+    q = bf16_t(qb, "cuda")
+    codes, qn = sh.query(q)
+    d_res = torch.zeros((BH, M), dtype=torch.int32, device="cuda")
+    d_nnz = torch.zeros((BH,), dtype=torch.int32, device="cuda")
+    lsh.batch_retrieve(0, codes, d_res, d_nnz)
+    d_out = torch.zeros((BH, D), dtype=torch.bfloat16, device="cuda")
+    d_mve = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
+    srv.attention_wrapper(0, K, L, d_out, d_mve, q, qn, d_res, d_nnz)
+    d_probs = srv.get_score().reshape(BH, M).clone()
+    h_res, h_nnz = mk(torch.zeros((BH, M), dtype=torch.int32)), torch.zeros((BH,), dtype=torch.int32)
+    lsh.batch_retrieve(0, mk(codes.cpu()), h_res, h_nnz)
+    h_out, h_mve = mk(torch.zeros((BH, D), dtype=torch.bfloat16)), mk(torch.zeros((2, BH), dtype=torch.float32))
+    srv.attention_wrapper(0, K, L, h_out, h_mve, mk(q.cpu()), qn.cpu(), h_res, h_nnz)
+    assert torch.equal(h_out, d_out.cpu())
+    # another step's retrieve on the same handle (other codes, other buffers) before the scores are asked for
+    q2 = bf16_t(np.roll(qb, 5, axis=0), "cuda")
+    codes2, _ = sh.query(q2)
+    h_res2, h_nnz2 = mk(torch.zeros((BH, M), dtype=torch.int32)), torch.zeros((BH,), dtype=torch.int32)
+    lsh.batch_retrieve(0, mk(codes2.cpu()), h_res2, h_nnz2)
+    assert not torch.equal(h_nnz2, h_nnz)
+    assert torch.equal(srv.get_score().reshape(BH, M), d_probs)
+
+
 @pytest.mark.parametrize("name", ["lsh_small", "gqa_32h"])
 def test_device_table_build_equals_sorted_fill(mp, name):
     g = cases.load_golden(name)
