@@ -557,7 +557,9 @@ struct AttnArgs {
     // position-weighted checksum (two u32 sums) per row, by which the attention entry recognises the rows it is handed
     int32_t* rows2;          // [BH][M] or nullptr
     uint32_t* rowsum;        // [BH][2] or nullptr
-    int32_t* nnz2;           // [BH] or nullptr: a second copy of the counts, in HBM beside rows2 (nnz is pinned host memory then)
+    // (with rows2 the stand-alone retrieve also leaves a second copy of its counts in HBM -- nnz is pinned host memory then --
+    // through part_cnt, which only the decode uses otherwise: a field of its own grew the decode kernel's argument block and
+    // cost cfg 1 0.1 us per launch)
 };
 
 // HASH: 0 = the codes are given (`query`), 1 = fused SimHash prologue, 3 = the same with the planes split over the
@@ -1214,7 +1216,7 @@ __device__ __forceinline__ void lsh_head_body(
     }
     if (tid == 0 && (AD == 0 || clog == 0)) {
         nnz[h] = total;
-        if (AD == 0 && aa.nnz2 != nullptr) aa.nnz2[h] = total;
+        if (AD == 0 && aa.rows2 != nullptr && aa.part_cnt != nullptr) aa.part_cnt[h] = total;
     }
     MP_STAMP(stamp, 21);
     if (AD == 0) {
@@ -1465,7 +1467,7 @@ __global__ __launch_bounds__(RT_THREADS, 4) void lsh_retrieve_kernel(
     unsigned long long* __restrict__ stamp) {
     AttnArgs aa = {};
     aa.rows2 = rows2;
-    aa.nnz2 = nnz2;
+    aa.part_cnt = nnz2;
     aa.rowsum = rowsum;
     // the layer's id width from the device word (written in stream order by a fill that widens the layer): a launch
     // argument would be frozen in a captured graph
