@@ -120,7 +120,7 @@ int mp_lsh_get_mask(mp_lsh_t* h, int8_t* mask, int mem, mp_stream_t stream);
  * bounds int32 [B*Hkv, L, NB, R+1]: entry 0 = start and entry R = end of a bucket inside its table row (the
  * reference's table_start / table_end, lsh.h:38-39), entry r = first position of the bucket whose token id is
  * >= r * range_len (ids ascend inside a bucket when R > 1); table int32 [B*Hkv, L, M].
- * R (1, 2, 4 or 8) is the number of token ranges a table row is cut into = the number of workgroups that serve
+ * R (1, 2, 4, 8, 16 or 32) is the number of token ranges a table row is cut into = the number of workgroups that serve
  * one query head in mp_decode_sparse_layer, chosen at alloc from B*H and the device's CU count. */
 int mp_lsh_get_tables(mp_lsh_t* h, int layer_id, void** bounds_dev, void** table_dev);
 int mp_lsh_get_ranges(mp_lsh_t* h, int* ranges, int* range_len);
@@ -217,7 +217,7 @@ int mp_debug_xcd_round_robin(void);
  * production; unknown names return MP_ERR_INVALID):
  *   "decode_two_launch"  0/1   mp_decode_sparse_layer as (hash + retrieve) then attention: two launches
  *   "decode_cluster"     0 = auto, n = workgroups per head of the one-launch decode = token ranges of the
- *                        tables (rounded down to 1, 2, 4 or 8); read by mp_lsh_alloc
+ *                        tables (rounded down to a power of two, at most 32); read by mp_lsh_alloc
  *   "decode_agent_scope" 0/1   cluster hand-off through memory even where the XCD placement was observed
  *   "stamp_stride"       n > 0: every workgroup b of the decode kernel writes its phase stamps at
  *                        [b * n + slot] of the stamp buffer (which must hold grid * n entries); 0 = workgroup 0 only

@@ -8,7 +8,7 @@
 //                                  token ranges: entry 0 = start, entry R = end of the bucket (the
 //                                  reference's table_start / table_end, lsh.h:38-39, interleaved: a probe
 //                                  is one 8-byte-wide random read), entry r = first position whose token id
-//                                  is >= r * range_len.  R = 1, 2, 4 or 8 = the number of workgroups that
+//                                  is >= r * range_len.  R = 1, 2, 4, 8, 16 or 32 = the number of workgroups that
 //                                  serve one query head in the decode kernel (fixed at alloc): member r of
 //                                  a head's cluster probes entries (r, r+1) and streams, counts, emits and
 //                                  gathers ONLY the tokens of its range -- nothing is replicated;
@@ -514,7 +514,7 @@ static int g_exact_norm = 0;   // mp_debug_set_option("simhash_exact_norm"): rea
 void set_exact_norm(int v) { g_exact_norm = v; }
 
 // AD > 0 (with HASH) appends the sparse attention of the head to the same launch (attn_head.h): the
-// selected ids never leave the workgroup's LDS.  A head is served by a CLUSTER of R = 1, 2, 4 or 8
+// selected ids never leave the workgroup's LDS.  A head is served by a CLUSTER of R = 1, 2, 4, 8, 16 or 32
 // workgroups (grid = R * BH, block b -> head b % BH, rank b / BH).  The head's TOKENS are partitioned over
 // the members: member r owns tokens [r * range_len, (r + 1) * range_len).  Every bucket's ids ascend, so
 // the part of a probed bucket that falls into the range is the contiguous piece between the bucket's
@@ -1823,7 +1823,7 @@ hipError_t launch_lsh_hash_only(const uint16_t* q, const uint16_t* Wk, const flo
 }
 
 // the whole sparse layer in ONE launch (mp_decode_sparse_layer): hash + retrieve + attention.
-// D = 64 or 128; R = workgroups per head = token ranges of the tables (1, 2, 4 or 8).
+// D = 64 or 128; R = workgroups per head = token ranges of the tables (1, 2, 4, 8, 16 or 32).
 bool lsh_decode_supported(int64_t M, int L, int D, int R) {
     return (D == 64 || D == 128) && decode_lds_bytes(lsh_range_len(M, R), L, D) <= RT_LDS_DYN_MAX;
 }
