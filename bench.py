@@ -617,6 +617,14 @@ def main():
                 step()
             graphs.append(g)
         L.set_option(name, vals[0])
+        # same queries through every captured variant: the last layer's outputs must be the same bits
+        outs = []
+        for g in graphs:
+            q_static.copy_(qs[0])
+            g.replay()
+            torch.cuda.synchronize()
+            outs.append((server.output.clone(), server.max_value_expsum.clone()))
+        same = all(torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) for o in outs[1:])
         res = {str(v): [] for v in vals}
         for rep in range(args.ab_reps):
             for v, g in zip(vals, graphs):
@@ -632,7 +640,7 @@ def main():
                 res[str(v)].append(round((time.perf_counter() - t0) / args.steps / NL * 1e6, 3))
         server.attn_server.check()
         print(json.dumps({"ab_option": name, "config": args.config, "data": args.data, "steps": args.steps,
-                          "us_per_layer": res}))
+                          "outputs_bit_identical": same, "us_per_layer": res}))
         return
 
     def run_steps(k0, count):
