@@ -86,6 +86,10 @@ hipError_t set_stamp_stride(int stride) {
 constexpr int RT_THREADS = MP_RT_THREADS;  // 16 waves: one workgroup per query head (A/B builds: 512, two per CU)
 constexpr int RT_WAVES = RT_THREADS / 64;
 constexpr int RT_GROUP = 12;               // buckets in flight per wave per round (x 2 chunks of 64 ids)
+// Table-side loads -- direct slots, bucket records, table ids: every line of them is read once per launch, by one CU -- are
+// non-temporal (`nt`: no claim on the L2 the K / V rows and the hyperplanes live in).  Round 4, same instruction schedule with
+// and without the bit on these 121 loads: cfg 3 29.77 -> 29.13 us per layer, cfg 1 and cfg 4 within +-0.1 (EXPERIMENTS.md R4-15).
+#define MP_TLOAD(p) __builtin_nontemporal_load(p)
 constexpr int RT_TAIL_CAP = 2048;          // pooled chunk descriptors for ids beyond 128 per bucket
 constexpr int RT_TAIL_UNROLL = 8;
 constexpr int CLUSTER_MAX = MP_CLUSTER_MAX; // workgroups per query head of the decode kernel, at most (common.h)
@@ -976,7 +980,7 @@ __device__ __forceinline__ void lsh_head_body(
                 at[b] = (((((uint32_t)lc << ha.K) + (uint32_t)cd[b]) << clog) << SWL) + (uint32_t)sl;
             }
 #pragma unroll
-            for (int b = 0; b < DG; ++b) v[b] = sg[at[b]];
+            for (int b = 0; b < DG; ++b) v[b] = MP_TLOAD(sg + at[b]);
             MP_STAMP(stamp, 42);                                     // slot loads issued
             if ((HASH == 1 || HASH == 3) && lead && sl == 0) {
 #pragma unroll
@@ -1017,11 +1021,11 @@ __device__ __forceinline__ void lsh_head_body(
                     const int lc = l < L ? l : L - 1;
                     const int32_t* row = tab + (int64_t)lc * M;
                     const int at0 = pp + SLOT_IDS + sl;
-                    e0[b] = row[sl < r1 ? at0 : 0];
+                    e0[b] = MP_TLOAD(row + (sl < r1 ? at0 : 0));
                     if (__ballot(r1 > SW)) {
                         wide |= 1u << b;
-                        e1[b] = row[sl + SW < r1 ? at0 + SW : 0];
-                        e2[b] = row[sl + 2 * SW < r1 ? at0 + 2 * SW : 0];
+                        e1[b] = MP_TLOAD(row + (sl + SW < r1 ? at0 + SW : 0));
+                        e2[b] = MP_TLOAD(row + (sl + 2 * SW < r1 ? at0 + 2 * SW : 0));
                     }
                     if (sl == 0 && rest > SLOT_MORE) {                  // skewed data: the chunk pool takes the rest
                         s_start[l] = pp + SLOT_IDS + SLOT_MORE;
@@ -1082,7 +1086,7 @@ __device__ __forceinline__ void lsh_head_body(
             }
             if (code >= 0 && code < NB) {
                 const int32_t* rec = bnd + ((int64_t)l * NB + code) * RS;
-                const int lo = rec[e_lo], hi = rec[e_hi];
+                const int lo = MP_TLOAD(rec + e_lo), hi = MP_TLOAD(rec + e_hi);
                 st = lo;
                 len = hi - lo;
                 if (st < 0 || len < 0 || (int64_t)st + len > M) len = 0;
@@ -1126,7 +1130,7 @@ __device__ __forceinline__ void lsh_head_body(
             ln[b] = l < L ? __builtin_amdgcn_readfirstlane(ln[b]) : 0;       // wave-uniform: one table per wave
             sa[b] = __builtin_amdgcn_readfirstlane(sa[b]);
             const int32_t* row = tab + (int64_t)lc * M + sa[b];
-            id0[b] = row[lane < ln[b] ? lane : 0];
+            id0[b] = MP_TLOAD(row + (lane < ln[b] ? lane : 0));
         }
         // applied in issue order: the first piece's ids are counted while the last piece's are still on their way
 #pragma unroll
@@ -1140,7 +1144,7 @@ __device__ __forceinline__ void lsh_head_body(
                 const int l = l0 + b * RT_WAVES;
                 const int lc = l < L ? l : L - 1;
                 const int32_t* row = tab + (int64_t)lc * M + sa[b];
-                id1[b] = row[lane + 64 < ln[b] ? lane + 64 : 0];
+                id1[b] = MP_TLOAD(row + (lane + 64 < ln[b] ? lane + 64 : 0));
             }
 #pragma unroll
             for (int b = 0; b < RT_GROUP; ++b) apply(lane + 64 < ln[b] ? id1[b] : -1);
