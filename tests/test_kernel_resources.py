@@ -77,3 +77,32 @@ def test_no_kernel_spills_vector_registers_or_reserves_scratch(tmp_path):
         if r["max_flat_workgroup_size"] >= 1024:
             assert r["vgpr_count"] <= 128, (name, r)
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+@pytest.mark.skipif(not all(os.path.exists(f"{LLVM}/{t}") for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")),
+                    reason="ROCm LLVM tools not found")
+def test_decode_kernel_streams_tables_and_rows_past_the_l2(tmp_path):
+    """Cache policy of the decode kernel's big read-once streams, read off the disassembly: the K / V row gather
+    (16-byte loads) and the table-side loads (direct slots, bucket records, table ids: 4-byte loads) carry `nt`
+    (EXPERIMENTS.md R4-15: without it on the table side cfg 3 is 0.65 us per launch slower)."""
+    from magicpig_amd import build as B
+    B.build()
+    d = tmp_path / "lsh"
+    d.mkdir()
+    obj = os.path.join(B.OBJDIR, "lsh.o")
+    fat, co, scratch = str(d / "fat.bin"), str(d / "co.elf"), str(d / "copy.o")
+    shutil.copyfile(obj, scratch)
+    subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", scratch, str(d / "out.o")], check=True)
+    subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+    dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for m in re.finditer(r"<(_ZN2mp17lsh_decode_kernelILi\d+ELi\d+ELb[01]ELi[13]E\w*)>:\n(.*?)\n\n", dis, re.S):
+        body = m.group(2)
+        rows = re.findall(r"global_load_dwordx4 .* nt\b", body)
+        tables = re.findall(r"global_load_dword v\d+, .* nt\b", body)
+        assert len(rows) >= 16, (m.group(1), len(rows))          # a 32-token step alone is 16 row loads
+        assert len(tables) >= 40, (m.group(1), len(tables))
+        seen += 1
+    assert seen >= 6
+    shutil.rmtree(tmp_path, ignore_errors=True)
