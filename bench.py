@@ -125,6 +125,8 @@ def parse():
     ap.add_argument("--ab-option", default="", help="NAME=v0,v1[,..]: A/B of a library debug option on one workload (alternating "
                     "timed regions of --steps graph replays each); prints its own JSON line instead of the bench line")
     ap.add_argument("--ab-reps", type=int, default=5)
+    ap.add_argument("--ab-worker", action="store_true", help="one side of scripts/ab_libs.py (two builds of the library, one "
+                    "process each, timed in alternating regions on one GPU): waits for go / quit lines on stdin")
     ap.add_argument("--distinct-layers", type=int, default=0,
                     help="DIAGNOSTIC (not a valid bench line): the step's launches cycle over only this many of the "
                          "model's sparse layers -- the HBM footprint a step touches shrinks (address translation, "
@@ -597,6 +599,45 @@ def main():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             step()
+
+    if args.ab_worker:
+        # One side of scripts/ab_libs.py: this process holds ONE build of the library (--lib), the workload and a captured
+        # step; the parent alternates timed regions between two such processes on the same GPU.  Protocol on stdin / stdout:
+        # "ready" once the step is captured; per "go" line one JSON line {"us_per_layer", "checksum"}; "quit" ends.
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        q_static.copy_(qs[0])
+        g.replay()
+        torch.cuda.synchronize()
+        chk = int(server.output.view(torch.int16).to(torch.int64).sum().item()) * 1_000_003 + \
+            int((server.max_value_expsum[1] * 1024).to(torch.int64).sum().item())
+        print("ready", flush=True)
+        for line in sys.stdin:
+            cmd = line.strip()
+            if cmd == "quit":
+                break
+            if cmd != "go":
+                continue
+            for i in range(args.warmup):
+                q_static.copy_(qs[i % NQ])
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                q_static.copy_(qs[i % NQ])
+                g.replay()
+            torch.cuda.synchronize()
+            print(json.dumps({"us_per_layer": round((time.perf_counter() - t0) / args.steps / NL * 1e6, 3),
+                              "checksum": chk}), flush=True)
+        server.attn_server.check()
+        return
 
     if args.ab_option:
         # A/B of a library option that is read at call time: one captured step per value over the SAME workload, timed
