@@ -73,7 +73,11 @@ int mp_simhash_destroy(mp_simhash_t* s);
 int mp_simhash_set_planes(mp_simhash_t* s, int D, int K, int L, const uint16_t* hash_func,
                           int mem, mp_stream_t stream);
 /* q: bf16 [R, D]; codes: int32 [R, L] (== q_hashcode, attnserver.py:270);
- * qnorm: f32 [R] or NULL (== pinned_query.float().norm(p=2, dim=-1), attnserver.py:300). */
+ * qnorm: f32 [R] or NULL (== pinned_query.float().norm(p=2, dim=-1), attnserver.py:300).
+ * ||q|| is exact (f32 sqrt of the f32-rounded exact sum of squares) from the MFMA kernel (R > 64); the fused prologue of
+ * the one-launch decode and the R <= 64 form compute it from an f32 sum and a Newton-refined v_sqrt: within 2 ulps of the
+ * exact value, identical between those two, NOT bit-identical with the MFMA kernel's.  The CODES are identical everywhere
+ * (the fast form falls back to the exact sequence wherever a bf16 rounding could differ). */
 int mp_simhash_query(mp_simhash_t* s, const uint16_t* q, int R, int32_t* codes, float* qnorm,
                      int mem, mp_stream_t stream);
 /* keys: bf16 [Hkv, n, D] (centred keys); codes: int16 [Hkv, L, n] (== hash_code_buffer[:, :, :n],
@@ -138,7 +142,9 @@ int mp_lsh_get_id_bits(mp_lsh_t* h, int layer_id, int* id_bits);
 /* ---------------------------------------------------------------- sparse attention */
 int mp_attn_create(mp_attn_t** out);                  /* sparse_attention.cc:519-527 */
 int mp_attn_destroy(mp_attn_t* h);                    /* sparse_attention.cc:529-544 */
-/* SparseAttentionServer::alloc, sparse_attention.cc:546-583 (same argument order). */
+/* SparseAttentionServer::alloc, sparse_attention.cc:546-583 (same argument order).  max_length x 4 x head_dim bytes must
+ * fit a 32-bit row offset (2^23 tokens at head_dim 128, 2^24 at 64); a store that pairs with an LSH handle in
+ * mp_decode_* shares that handle's max_length (<= 2^22). */
 int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads,
                   int num_key_value_heads, int head_dim, int batch_size, int max_length);
 /* SparseAttentionServer::fill, sparse_attention.cc:601-627.  k, v bf16 [Hkv, n, D];
@@ -175,7 +181,12 @@ int mp_attn_clear(mp_attn_t* h, mp_stream_t stream);  /* sparse_attention.cc:586
  * (a second mp_attn_t whose max_length is sink + local + generation buffer; the window's exact
  * attention is mp_attn_full on it, replacing BatchDecodeWithPagedKVCacheWrapper.run_return_lse,
  * :293-296).  k, v bf16 [B, Hkv, D]; pos int32 [B]; device pointers; the key norm of the new row
- * is computed on the fly.  A position >= max_length is reported by mp_attn_check (MP_ERR_DATA). */
+ * is computed on the fly.  A position >= max_length is reported by mp_attn_check (MP_ERR_DATA).
+ * An append changes norms at caller-chosen rows of EVERY request of the layer: if this store is the one an LSH handle's
+ * table words carry norms of (mp_lsh_build_with_norms / the decode entries' lazy packing), those payloads are no longer
+ * used for the layer -- the decode kernels read a selected token's norm from HBM again (one more line request per
+ * token: ~+1.5 us per layer at cfg 1) -- until the next mp_attn_fill* + table build.  Append into the window store (as
+ * the reference does), not into the LSH-indexed one, to keep the payload path. */
 int mp_attn_append(mp_attn_t* h, int layer_id, const uint16_t* k, const uint16_t* v,
                    const int32_t* pos, mp_stream_t stream);
 /* The same with the two torch lines in front of it folded in (models/attnserver.py:267, 281-290):

@@ -9,7 +9,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-import weakref
 
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
@@ -174,28 +173,6 @@ def expect(t: torch.Tensor, dtype, shape, name: str, same_numel_ok: bool = False
     if not t.is_contiguous():
         raise ValueError(f"{name}: tensor must be contiguous")
     return t
-
-
-class ArgCache:
-    """Per-object memo of validated arguments: a call that is handed the SAME tensor objects as the last one (the
-    reference's caller passes its persistent buffers every step, models/attnserver.py:59-66, 299-300) skips the dtype /
-    shape / contiguity checks -- ~1.4 us of torch attribute reads per tensor, 27 us per layer over batch_retrieve +
-    attention_wrapper before (EXPERIMENTS.md R4-5).  Weak references: the memo keeps no caller buffer alive."""
-    __slots__ = ("_slots",)
-
-    def __init__(self):
-        self._slots = {}
-
-    def expect(self, slot: str, t, dtype, shape, name: str, same_numel_ok: bool = False):
-        r = self._slots.get(slot)
-        if r is not None and r() is t:
-            return t
-        expect(t, dtype, shape, name, same_numel_ok)
-        try:
-            self._slots[slot] = weakref.ref(t)
-        except TypeError:
-            self._slots.pop(slot, None)
-        return t
 
 
 def same_memory(*tensors) -> int:

@@ -162,6 +162,7 @@ __device__ __forceinline__ void attn_head_fold(
     // rows are 4 D bytes, max_length <= 2^22 tokens, so every offset of a KV group is below 2^32 -- half the address
     // registers and none of the 64-bit multiply-adds of a pointer per row (A/B, same box: cfg 3 31.25 -> 30.4 us per layer,
     // cfg 2 33.9 -> 33.7, cfg 1 19.3 -> 19.2; EXPERIMENTS.md R4-2)
+    // (mp_attn_alloc enforces max_length x 4 D <= 2^32 -- the one check this arithmetic rests on)
     const char* kvb = reinterpret_cast<const char*>(kv_g);
     const uint32_t coff = (uint32_t)c * 16u;
 
@@ -183,7 +184,7 @@ __device__ __forceinline__ void attn_head_fold(
         // stays unconditional -- loads under a branch would make the compiler drain vmcnt at every
         // join.  Rows are read once and never reused: non-temporal loads.
         const int id_first = DENSE ? jb : __builtin_amdgcn_readfirstlane((int)idv[0][0]);
-        const uint32_t M32 = (uint32_t)M;                               // max_length <= 2^22
+        const uint32_t M32 = (uint32_t)M;                               // max_length <= 2^32 / (4 D)
         const int id_safe = ((uint32_t)id_first < M32) ? id_first : 0;
         u32x4 kreg[UPS], vreg[UPS];
         int idc[UPS];

@@ -326,8 +326,18 @@ struct mp_lsh {
         const void* results = nullptr;
         const void* nnz = nullptr;
         std::vector<int32_t> nnzv;
-        std::vector<uint32_t> sums;        // [BH][2]: sum of (id + 1), sum of (id + 1) (position + 1), mod 2^32
+        std::vector<uint32_t> sums;        // [BH][2]: sum of row_mix(id + 1, position + 1), sum of (id + 1) (position + 1), mod 2^32
+        const int32_t* kept = nullptr;     // [BH][M] the handle's pinned mirror when the caller's rows are pageable: the rows as
+                                           // the kernel wrote them, compared EXACTLY (memcmp) with what the caller hands on;
+                                           // nullptr when the kernel wrote the caller's pinned rows directly (checksums then)
     } host_ret;
+    // the HBM copy of the rows / counts a MP_MEM_HOST batch_retrieve hands out.  Buffers of their OWN (allocated at the
+    // first such call), not the decode path's step buffers `results` / `nnz`: an mp_decode_* launch -- eager, or replayed
+    // from a captured graph, which the host never sees -- rewrites those in stream order, and the attention entry would
+    // attend over the graph's rows while the caller's (unchanged) rows still pass the comparison.  Only the
+    // host-mode retrieve writes these, and it forgets the pairing first.
+    int32_t* hr_rows = nullptr;    // [BH][M]
+    int32_t* hr_nnz = nullptr;     // [BH]
     int32_t* last_query = nullptr; // [BH][L] staging copy of host-side query codes
     const int32_t* lastq = nullptr;// device codes of the last retrieve (for get_mask): last_query,
                                    // `codes`, or the caller's own device buffer (valid until it changes)
@@ -388,15 +398,17 @@ static void host_ret_forget(mp_lsh_t* h) {
     if (h) h->host_ret.valid = false;
     if (g_host_ret_lsh == h) g_host_ret_lsh = nullptr;
 }
-// position-weighted checksum of the first n entries of a row, two u32 sums with wrap-around -- what the retrieve kernel
-// leaves per row (lsh.hip: rowsum).  32-bit lanes on purpose: the loop vectorises (vpmulld), ~1 us for cfg 1's 49 K ids.
+// checksum of the first n entries of a row, two u32 sums with wrap-around -- what the retrieve kernel leaves per row
+// (lsh.hip: rowsum): a non-linear mix of (entry, position) and the position-weighted linear sum.  32-bit lanes on
+// purpose: the loop vectorises (vpmulld); it runs while the attention kernel does.  Used only where the kernel wrote the
+// caller's PINNED rows (no kept copy to compare with); pageable rows are compared exactly with the handle's mirror.
 #if defined(__x86_64__)
 __attribute__((target("avx2")))
 static void host_row_sum_avx2(const int32_t* row, int64_t n, uint32_t* s1, uint32_t* s2) {
     uint32_t a = 0u, b = 0u;
     for (int64_t j = 0; j < n; ++j) {
         const uint32_t v = (uint32_t)row[j] + 1u;
-        a += v;
+        a += row_mix(v, (uint32_t)(j + 1));
         b += v * (uint32_t)(j + 1);
     }
     *s1 = a;
@@ -411,7 +423,7 @@ static void host_row_sum(const int32_t* row, int64_t n, uint32_t* s1, uint32_t* 
     uint32_t a = 0u, b = 0u;
     for (int64_t j = 0; j < n; ++j) {
         const uint32_t v = (uint32_t)row[j] + 1u;
-        a += v;
+        a += row_mix(v, (uint32_t)(j + 1));
         b += v * (uint32_t)(j + 1);
     }
     *s1 = a;
@@ -548,8 +560,10 @@ static void lsh_free(mp_lsh_t* h) {
     h->bounds.clear();
     h->table.clear();
     h->slots.clear();
-    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->xw, h->xseq, h->pay_bad, h->att_ver_dev, h->idbits_dev};
+    void* ptrs[] = {h->last_query, h->err, h->codes, h->results, h->nnz, h->qnorm, h->xw, h->xseq, h->pay_bad, h->att_ver_dev, h->idbits_dev,
+                    h->hr_rows, h->hr_nnz};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->hr_rows = nullptr; h->hr_nnz = nullptr;
     h->last_query = nullptr; h->err = nullptr; h->codes = nullptr; h->results = nullptr;
     h->nnz = nullptr; h->qnorm = nullptr; h->xw = nullptr; h->xseq = nullptr; h->pay_bad = nullptr; h->att_ver_dev = nullptr; h->idbits_dev = nullptr;
     h->small.release();
@@ -799,7 +813,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     // host callers (models/attnserver.py:299 passes CPU tensors).  Zero copy: the kernel reads the codes from the handle's
     // pinned block and writes the ids straight into the caller's `results` rows (mapped once, HostMap) and the counts
     // into the pinned block: ONE launch, ONE synchronisation, no copy engine.
-    host_ret_forget(h);                                   // the step buffers are about to be rewritten
+    host_ret_forget(h);                                   // hr_rows / hr_nnz are about to be rewritten
     const size_t o_codes = (size_t)(2 * BH + 1) * 4, o_sums = (o_codes + qb + 7) & ~(size_t)7;
     int rc = h->small.reserve(o_sums + (size_t)BH * 8);
     if (rc) return rc;
@@ -813,6 +827,12 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
             res_dev = h->big.hd;
             mirror = res_dev != nullptr;
         }
+        if (res_dev != nullptr && h->hr_rows == nullptr) {            // the HBM copy's own buffers, once
+            if (hipMalloc((void**)&h->hr_rows, rbytes) != hipSuccess) { (void)hipGetLastError(); h->hr_rows = nullptr; res_dev = nullptr; }
+            else if (hipMalloc((void**)&h->hr_nnz, (size_t)BH * 4) != hipSuccess) {
+                (void)hipGetLastError(); (void)hipFree(h->hr_rows); h->hr_rows = nullptr; h->hr_nnz = nullptr; res_dev = nullptr;
+            }
+        }
         if (res_dev != nullptr) {
             char* hp = reinterpret_cast<char*>(h->small.hp);
             char* hd = reinterpret_cast<char*>(h->small.hd);
@@ -821,12 +841,12 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
             h->last_layer = layer_id;
             // ONE launch, ONE synchronisation, no copy engine: the kernel reads the codes from the pinned block, writes
             // the ids straight into the caller's rows (where they are pinned) or the pinned mirror and the counts into the
-            // pinned block -- and leaves a second copy of the rows in HBM (the handle's step buffer) with a checksum
-            // per row, so that the attention entry of the paired store need not upload what it is handed next
+            // pinned block -- and leaves a second copy of the rows in HBM (hr_rows / hr_nnz: buffers no other launch writes)
+            // with a checksum per row, so that the attention entry of the paired store need not upload what it is handed next
             MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id],
                                              reinterpret_cast<const int32_t*>(hd + o_codes),
                                              reinterpret_cast<int32_t*>(res_dev), reinterpret_cast<int32_t*>(hd), BH,
-                                             h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, h->results, h->nnz,
+                                             h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, h->hr_rows, h->hr_nnz,
                                              reinterpret_cast<uint32_t*>(hd + o_sums), st));
             if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) return rc;
             memcpy(nnz, hp, (size_t)BH * 4);
@@ -845,6 +865,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
                 h->host_ret.nnzv.assign(nnz, nnz + BH);
                 const uint32_t* sums = reinterpret_cast<const uint32_t*>(hp + o_sums);
                 h->host_ret.sums.assign(sums, sums + 2 * (size_t)BH);
+                h->host_ret.kept = mirror ? reinterpret_cast<const int32_t*>(h->big.hp) : nullptr;
                 h->host_ret.valid = true;
                 g_host_ret_lsh = h;
             }
@@ -1033,9 +1054,11 @@ int mp_attn_alloc(mp_attn_t* h, int num_layers, int num_attention_heads, int num
                MP_ERR_INVALID, "mp_attn_alloc: bad head/layer/batch counts");
     MP_REQUIRE((int64_t)batch_size * num_attention_heads <= 16384, MP_ERR_UNSUPPORTED,
                "mp_attn_alloc: more than 16384 query heads per call");
-    // (the gather addresses a KV group's rows as one base + a 32-bit byte offset: max_length x 4 head_dim bytes < 2^32;
-    // the same bound as mp_lsh_alloc's)
-    MP_REQUIRE(max_length <= (1 << 22), MP_ERR_INVALID, "mp_attn_alloc: max_length must be in [1, 2^22]");
+    // ONE bound, the real one: the gathers (attn_head.h: attn_head_fold, `ro[u]`) address a KV group's rows as one base +
+    // a 32-bit byte offset, a token's K | V rows are 4 x head_dim bytes -> max_length x 4 head_dim <= 2^32 (2^23 tokens at
+    // head_dim 128, 2^24 at 64).  Stores that pair with an LSH handle are further limited by mp_lsh_alloc's 2^22.
+    MP_REQUIRE((int64_t)max_length * 4 * head_dim <= (1ll << 32), MP_ERR_INVALID,
+               "mp_attn_alloc: max_length x 4 x head_dim bytes must fit 32-bit row offsets (<= 2^32)");
     h->device = current_device();
     h->layers = num_layers; h->H = num_attention_heads; h->Hkv = num_key_value_heads;
     h->D = head_dim; h->B = batch_size; h->G = h->H / h->Hkv; h->M = max_length;
@@ -1275,43 +1298,52 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
     MP_REQUIRE(total <= (size_t)INT32_MAX, MP_ERR_UNSUPPORTED, std::string(who) + ": more than 2^31 index entries in one call");
     // The rows a paired LSH handle has just handed out (round 4).  The reference's caller passes the `results` /
     // `nnz` of batch_retrieve straight on as `ind` / `nnz` (models/attnserver.py:299-300); the handle that produced them
-    // still holds the same rows in HBM.  They are recognised by the caller's pointers, the counts and a position-weighted
-    // checksum of every live row computed on both sides -- a caller that edited `ind` in between is served its edit
-    // through the upload below -- and then only (q | qn) cross PCIe: no index upload, no second copy of the rows.
+    // still holds the same rows in HBM (in buffers only that retrieve writes).  They are recognised by the caller's
+    // pointers, the counts and a comparison of every live row -- exact where the handle kept the rows it wrote (pageable
+    // caller rows: its pinned mirror), two checksums where the kernel wrote the caller's pinned rows -- a caller that
+    // edited `ind` in between is served its edit through the upload below -- and then only (q | qn) cross PCIe: no
+    // index upload, no second copy of the rows.
     if (!dense && g_opt.host_zero_copy.load() != 0 && h->small.hd != nullptr) {
-        mp_lsh_t* l = nullptr;
-        {
-            std::lock_guard<std::mutex> lock(g_host_ret_mu);
-            l = g_host_ret_lsh;
-            if (l != nullptr && !(l->host_ret.valid && l->allocated && l->device == h->device && l->B * l->H == BH &&
-                                  l->M == h->M && l->host_ret.results == ind && l->host_ret.nnz == nnz &&
-                                  memcmp(l->host_ret.nnzv.data(), nnz, (size_t)BH * 4) == 0))
-                l = nullptr;
-        }
+        // The pairing is looked up AND used under the mutex: the paired handle's destroy / next host-mode retrieve on
+        // another thread (host_ret_forget takes the same mutex) waits until this call no longer reads its state or its
+        // HBM rows (`l` used to be dereferenced after the lock was released).
+        std::lock_guard<std::mutex> lock(g_host_ret_mu);
+        mp_lsh_t* l = g_host_ret_lsh;
+        if (l != nullptr && !(l->host_ret.valid && l->allocated && l->device == h->device && l->B * l->H == BH &&
+                              l->M == h->M && l->hr_rows != nullptr && l->host_ret.results == ind && l->host_ret.nnz == nnz &&
+                              memcmp(l->host_ret.nnzv.data(), nnz, (size_t)BH * 4) == 0))
+            l = nullptr;
         if (l != nullptr) {
             // Launched BEFORE the rows are verified: the attention kernel works on the rows + counts the retrieve kernel left
-            // in HBM while the host checks the caller's rows against the retrieve's checksums.  A row that was edited (or a
-            // stale pairing) is found before anything is handed back: the launch is waited for, its outputs dropped, and
-            // the upload path below serves the caller's rows.  Few heads (B*H <= 64: cfg 1 / 4): ONE launch, every
-            // workgroup reads its (q | qn) straight from the pinned block, two PCIe reads under its index loads
-            // (-5 us per call at cfg 1 against a relay launch in front).  Many heads (cfg 2 / 3: 256 heads x the
-            // workgroups of a head, 256 bytes each) would queue on PCIe -- measured +23 us -- so there a one-workgroup
-            // relay brings (q | qn) into HBM first.
+            // in HBM (l->hr_rows / hr_nnz: written by that retrieve and by nothing else) while the host compares the
+            // caller's rows with what the retrieve handed out -- exactly (memcmp against the handle's pinned mirror, which
+            // still holds the rows as the kernel wrote them) where the caller's rows are pageable, by the two checksums
+            // where the kernel wrote the caller's pinned rows directly.  A row that was edited (or a stale pairing) is
+            // found before anything is handed back: the launch is waited for, its outputs dropped, and the upload path
+            // below serves the caller's rows.  Few heads (B*H <= 64: cfg 1 / 4): ONE launch, every workgroup reads its
+            // (q | qn) straight from the pinned block, two PCIe reads under its index loads (-5 us per call at cfg 1
+            // against a relay launch in front).  Many heads (cfg 2 / 3: 256 heads x the workgroups of a head, 256 bytes
+            // each) would queue on PCIe -- measured +23 us -- so there a one-workgroup relay brings (q | qn) into HBM first.
             char* hd = reinterpret_cast<char*>(h->small.hd);
             const bool direct = BH <= 64;
             if (!direct) MP_HIP_CHECK(launch_relay(hd, dp, o_nnz, st));
             const char* qsrc = direct ? hd : dp;
             rc = attn_run(h, layer_id, false, K, L, reinterpret_cast<uint16_t*>(hd + o_out),
                           reinterpret_cast<float*>(hd + o_mve), qsrc + o_q, query_dtype,
-                          reinterpret_cast<const float*>(qsrc + o_qn), l->results, l->nnz, st);
+                          reinterpret_cast<const float*>(qsrc + o_qn), l->hr_rows, l->hr_nnz, st);
             if (rc) return rc;
             bool same = true;
+            const int32_t* kept = l->host_ret.kept;
             for (int i = 0; i < BH && same; ++i) {
                 int64_t z = nnz[i];
                 z = z < 0 ? 0 : (z > h->M ? h->M : z);
-                uint32_t s1, s2;
-                host_row_sum(ind + (size_t)i * h->M, z, &s1, &s2);
-                same = s1 == l->host_ret.sums[2 * i] && s2 == l->host_ret.sums[2 * i + 1];
+                if (kept != nullptr) {
+                    same = z == 0 || memcmp(ind + (size_t)i * h->M, kept + (size_t)i * h->M, (size_t)z * 4) == 0;
+                } else {
+                    uint32_t s1, s2;
+                    host_row_sum(ind + (size_t)i * h->M, z, &s1, &s2);
+                    same = s1 == l->host_ret.sums[2 * i] && s2 == l->host_ret.sums[2 * i + 1];
+                }
             }
             if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) return rc;
             if (same) {
@@ -1584,7 +1616,8 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
     MP_REQUIRE(layer_id >= 0 && layer_id < lsh->layers && layer_id < attn->layers, MP_ERR_INVALID,
                w + ": layer_id out of range");
     const int BH = lsh->B * lsh->H;
-    host_ret_forget(lsh);                                  // the fused entry rewrites the handle's step buffers
+    // (the rows a host-mode batch_retrieve handed out live in buffers of their own, hr_rows / hr_nnz: this entry's
+    // by-products -- eager or replayed from a graph -- no longer touch them)
     lsh->lastq = lsh->codes;
     lsh->last_layer = layer_id;
     const bool two_launch = g_opt.decode_two_launch.load() != 0;                // A/B switch

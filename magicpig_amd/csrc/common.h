@@ -68,6 +68,21 @@ __device__ __forceinline__ void dot8_bf16_chain(float& acc, const u32x4& a, cons
 }
 __device__ __forceinline__ void dot_settle(float& acc) { asm("s_nop 3" : "+v"(acc)); }
 
+// ---------------------------------------------------------------- row checksum (host-buffer mode)
+// One word of the per-row checksum the stand-alone retrieve leaves for rows it writes straight into a caller's PINNED
+// `results` (capi.hip: HostRetrieve): a non-linear 32-bit mix (lowbias32) of (entry, position).  Summed with wrap-around
+// next to the position-weighted linear sum: an edit of the row that keeps both needs to be constructed for it (the
+// linear pair alone was kept by e.g. +1, -2, +1 on three neighbours -- ADVICE r04).
+__host__ __device__ inline uint32_t row_mix(uint32_t v, uint32_t pos) {
+    uint32_t x = v ^ (pos * 0x9E3779B1u);
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
 // ---------------------------------------------------------------- debug phase timestamps
 // Compiled in only with -DMP_STAMPS=1 (scripts/build_variant.py stamps -DMP_STAMPS=1; the measurement scripts load that
 // build): the product's kernels carry no stamp code at all.  There: stamp == nullptr unless set through

@@ -558,7 +558,8 @@ struct AttnArgs {
     const int32_t* win_len;  // [BH]
     int64_t win_M;
     // stand-alone retrieve, host-buffer mode (capi.hip: HostRetrieve): a second copy of the emitted rows in HBM and a
-    // position-weighted checksum (two u32 sums) per row, by which the attention entry recognises the rows it is handed
+    // checksum per row (two u32 sums: row_mix of (entry, position), entry x position), by which the attention entry
+    // recognises rows the kernel wrote straight into the caller's pinned memory
     int32_t* rows2;          // [BH][M] or nullptr
     uint32_t* rowsum;        // [BH][2] or nullptr
     // (with rows2 the stand-alone retrieve also leaves a second copy of its counts in HBM -- nnz is pinned host memory then --
@@ -1212,7 +1213,7 @@ __device__ __forceinline__ void lsh_head_body(
             if (AD > 0 && off < aa.cap) s_ids[off] = base + p;
             if (AD == 0 && out2 != nullptr) {
                 out2[off] = base + p;
-                cs1 += (uint32_t)(base + p + 1);
+                cs1 += row_mix((uint32_t)(base + p + 1), (uint32_t)(off + 1));
                 cs2 += (uint32_t)(base + p + 1) * (uint32_t)(off + 1);
             }
             ++off;

@@ -16,7 +16,6 @@ class LSH:
         self._h = C.c_void_p()
         L.check(L.lib().mp_lsh_create(C.byref(self._h)))
         self._alloc = False
-        self._args = L.ArgCache()
 
     def __del__(self):                                    # LSH::~LSH(), lsh.cc:29-42
         try:
@@ -71,10 +70,9 @@ class LSH:
         """LSH::batch_retrieve, lsh.cc:210-241: query int32 [B*H,L] -> results int32 [B*H,M]
         (first nnz[h] valid, ascending ids), nnz int32 [B*H]."""
         BH = self.B * self.H
-        a = self._args
-        a.expect("br.query", query, torch.int32, (BH, self.L), "query")
-        a.expect("br.results", results, torch.int32, (BH, self.M), "results")
-        a.expect("br.nnz", nnz, torch.int32, (BH,), "nnz")
+        L.expect(query, torch.int32, (BH, self.L), "query")
+        L.expect(results, torch.int32, (BH, self.M), "results")
+        L.expect(nnz, torch.int32, (BH,), "nnz")
         mem = L.same_memory(query, results, nnz)
         L.check(L.lib().mp_lsh_batch_retrieve(self._h, layer_id, query.data_ptr(), results.data_ptr(),
                                               nnz.data_ptr(), mem, L.current_stream(query, self._device)))

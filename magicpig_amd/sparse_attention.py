@@ -15,7 +15,6 @@ class SparseAttentionServer:
     def __init__(self):                                   # sparse_attention.cc:519-527
         self._h = C.c_void_p()
         L.check(L.lib().mp_attn_create(C.byref(self._h)))
-        self._args = L.ArgCache()
 
     def __del__(self):                                    # sparse_attention.cc:529-544
         try:
@@ -80,17 +79,16 @@ class SparseAttentionServer:
         non-AVX512BF16 build's `.to(kFloat32)`) [B*H,D]; query_norm f32 [B*H]; ind int32 [B*H,M];
         nnz int32 [B*H]."""
         BH = self.B * self.H
-        a = self._args
-        a.expect("aw.output", output, torch.bfloat16, (BH, self.D), "output")
-        a.expect("aw.mve", max_value_expsum, torch.float32, (2, BH), "max_value_expsum")
+        L.expect(output, torch.bfloat16, (BH, self.D), "output")
+        L.expect(max_value_expsum, torch.float32, (2, BH), "max_value_expsum")
         qdt = query.dtype
         if qdt is not torch.bfloat16 and qdt is not torch.float32:
             query = query.float()
             qdt = torch.float32
-        a.expect("aw.query", query, None, (BH, self.D), "query", same_numel_ok=True)
-        a.expect("aw.qn", query_norm, torch.float32, (BH,), "query_norm")
-        a.expect("aw.ind", ind, torch.int32, (BH, self.M), "ind")
-        a.expect("aw.nnz", nnz, torch.int32, (BH,), "nnz")
+        L.expect(query, None, (BH, self.D), "query", same_numel_ok=True)
+        L.expect(query_norm, torch.float32, (BH,), "query_norm")
+        L.expect(ind, torch.int32, (BH, self.M), "ind")
+        L.expect(nnz, torch.int32, (BH,), "nnz")
         mem = L.same_memory(output, max_value_expsum, query, query_norm, ind, nnz)
         qd = L.DTYPE_BF16 if qdt is torch.bfloat16 else L.DTYPE_F32
         L.check(L.lib().mp_attn_sparse(self._h, layer_id, K, L_, output.data_ptr(), max_value_expsum.data_ptr(),

@@ -403,6 +403,87 @@ def test_host_mode_scores_outlive_the_next_retrieve(mp, pinned):
     assert torch.equal(srv.get_score().reshape(BH, M), d_probs)
 
 
+@pytest.mark.parametrize("pinned", [True, False])
+def test_host_fast_path_after_a_replayed_decode_and_checksum_neutral_edits(mp, pinned):
+    """ADVICE r04 (capi.hip attn_entry).  (1) Between the caller's batch_retrieve and attention_wrapper on CPU tensors the
+    SAME handles run one-launch decodes of OTHER queries -- eagerly and as a replayed hipGraph, which the host side of
+    the library never sees: the attention call must still attend over the rows IT was handed (the rows' HBM copy lives
+    in buffers only the host-mode retrieve writes), not over the decode's by-product rows.  (2) An in-place edit of
+    `ind` that keeps BOTH linear sums of the round-4 checksum (ids +1, -2, +1 on three neighbouring positions: sum and
+    position-weighted sum unchanged) must be served, pinned rows (non-linear checksum) and pageable rows (exact compare)."""
+    g = cases.load_golden("gqa_32h")
+    seed, B, H, Hkv, n, M, D, K, L = (int(x) for x in g["meta"])
+    keys, kns, vals, W, qb = cases.case_inputs(seed, B, H, Hkv, n, D, K, L)
+    BH = B * H
+    sh = mp.SimHash(bf16_t(W, "cuda"), K, L)
+    lsh, srv = mp.LSH(), mp.SparseAttentionServer()
+    lsh.alloc(K, L, 1, H, Hkv, B, M)
+    srv.alloc(1, H, Hkv, D, B, M)
+    lsh.fastfill(0, 0, sh.keys(bf16_t(keys[0], "cuda")))
+    srv.fill(0, 0, bf16_t(keys[0], "cuda"), bf16_t(vals[0], "cuda"), torch.from_numpy(kns[0]).cuda())
+    mk = (lambda t: t.pin_memory()) if pinned else (lambda t: t)
+    import magicpig_amd._lib as L_
+
+    def decode(qdev, out, mve):
+        L_.check(L_.lib().mp_decode_sparse_layer(sh._h, lsh._h, srv._h, 0, L_.ptr(qdev), L_.ptr(out), L_.ptr(mve), None,
+                                                L_.current_stream(qdev)))
+
+    q = bf16_t(qb, "cuda")
+    q_other = bf16_t(np.roll(qb, 7, axis=0), "cuda")
+    codes, qn = sh.query(q)
+    d_res = torch.zeros((BH, M), dtype=torch.int32, device="cuda")
+    d_nnz = torch.zeros((BH,), dtype=torch.int32, device="cuda")
+    lsh.batch_retrieve(0, codes, d_res, d_nnz)
+    d_out = torch.zeros((BH, D), dtype=torch.bfloat16, device="cuda")
+    d_mve = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
+    srv.attention_wrapper(0, K, L, d_out, d_mve, q, qn, d_res, d_nnz)
+    want_out, want_mve = d_out.cpu(), d_mve.cpu()
+    # a captured decode step of the other queries
+    g_out = torch.zeros((BH, D), dtype=torch.bfloat16, device="cuda")
+    g_mve = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
+    decode(q_other, g_out, g_mve)                          # (packs / warms outside the capture)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        decode(q_other, g_out, g_mve)
+    other_out = g_out.clone()
+    assert not torch.equal(other_out.cpu(), want_out)
+    for between in ("nothing", "eager", "replay"):
+        h_res, h_nnz = mk(torch.zeros((BH, M), dtype=torch.int32)), torch.zeros((BH,), dtype=torch.int32)
+        lsh.batch_retrieve(0, mk(codes.cpu()), h_res, h_nnz)
+        assert torch.equal(h_nnz, d_nnz.cpu())
+        if between == "eager":
+            decode(q_other, g_out, g_mve)
+        elif between == "replay":
+            graph.replay()
+        torch.cuda.synchronize()
+        h_out, h_mve = mk(torch.zeros((BH, D), dtype=torch.bfloat16)), mk(torch.zeros((2, BH), dtype=torch.float32))
+        srv.attention_wrapper(0, K, L, h_out, h_mve, mk(q.cpu()), qn.cpu(), h_res, h_nnz)
+        assert torch.equal(h_out, want_out) and torch.equal(h_mve, want_mve), between
+    # (2) the checksum-neutral edit: three neighbouring entries of the longest row, ids +1, -2, +1
+    r = int(torch.argmax(h_nnz))
+    z = int(h_nnz[r])
+    row = h_res[r, :z].tolist()
+    have = set(row)
+    j = next(j for j in range(1, z - 2)
+             if row[j] + 1 not in have and row[j + 1] - 2 not in have and row[j + 2] + 1 not in have
+             and row[j + 1] - 2 >= 0 and row[j + 2] + 1 < n and len({row[j] + 1, row[j + 1] - 2, row[j + 2] + 1}) == 3)
+    before = (sum(v + 1 for v in row), sum((v + 1) * (i + 1) for i, v in enumerate(row)))
+    h_res[r, j] += 1
+    h_res[r, j + 1] -= 2
+    h_res[r, j + 2] += 1
+    row2 = h_res[r, :z].tolist()
+    assert before == (sum(v + 1 for v in row2), sum((v + 1) * (i + 1) for i, v in enumerate(row2)))
+    e_res = d_res.clone()
+    e_res[r, :z] = h_res[r, :z].cuda()
+    srv.attention_wrapper(0, K, L, d_out, d_mve, q, qn, e_res, d_nnz)
+    assert not torch.equal(d_out.cpu(), want_out)
+    h_out, h_mve = mk(torch.zeros((BH, D), dtype=torch.bfloat16)), mk(torch.zeros((2, BH), dtype=torch.float32))
+    srv.attention_wrapper(0, K, L, h_out, h_mve, mk(q.cpu()), qn.cpu(), h_res, h_nnz)
+    assert torch.equal(h_out, d_out.cpu()) and torch.equal(h_mve, d_mve.cpu())
+    del graph
+
+
 @pytest.mark.parametrize("name", ["lsh_small", "gqa_32h"])
 def test_device_table_build_equals_sorted_fill(mp, name):
     g = cases.load_golden(name)

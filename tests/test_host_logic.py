@@ -30,6 +30,10 @@ def test_status_codes_without_device():
     assert lib.mp_attn_alloc(a, 1, 4, 2, 96, 1, 128) == 5           # head_dim must be 64 or 128
     assert b"head_dim" in lib.mp_last_error()
     assert lib.mp_attn_clear(a, None) == 2
+    # ONE bound on max_length: 32-bit row offsets of the gather, max_length x 4 head_dim <= 2^32 -- rejected
+    # before any allocation; a dense / window store may be longer than an LSH handle's 2^22
+    assert lib.mp_attn_alloc(a, 1, 4, 2, 128, 1, (1 << 23) + 1) == 1 and b"32-bit row offsets" in lib.mp_last_error()
+    assert lib.mp_attn_alloc(a, 1, 4, 2, 64, 1, (1 << 24) + 1) == 1
     assert lib.mp_attn_destroy(a) == 0
     s = C.c_void_p()
     assert lib.mp_simhash_create(C.byref(s)) == 0
@@ -56,6 +60,20 @@ def test_mirror_classes_check_tensors():
         lsh.batch_retrieve(0, good_q.t().contiguous().t(), res, nnz)  # not contiguous
     with pytest.raises(TypeError):
         lsh.fill(0, 0, torch.zeros((2, 8, 16), dtype=torch.int32), torch.zeros((2, 8, 16), dtype=torch.int32))
+    # no memo of "already validated" tensors (round 4's ArgCache skipped the checks for a tensor OBJECT it had
+    # seen): the same object after an in-place metadata change, or after the handle was re-dimensioned, is checked again
+    same = torch.zeros((4, 8), dtype=torch.int32)
+    L.expect(same, torch.int32, (4, 8), "query")
+    same.resize_(2, 8)
+    with pytest.raises(ValueError):
+        lsh.batch_retrieve(0, same, res, nnz)
+    same.resize_(8, 4).t_()
+    with pytest.raises(ValueError):
+        lsh.batch_retrieve(0, same, res, nnz)                         # right shape, transposed in place
+    lsh.M = 256                                                       # "re-alloc" with another max_length
+    with pytest.raises(ValueError):
+        lsh.batch_retrieve(0, good_q, res, nnz)
+    lsh.M = 128
     srv = magicpig_amd.SparseAttentionServer()
     srv.H, srv.Hkv, srv.D, srv.B, srv.M = 4, 2, 128, 1, 128
     out = torch.zeros((4, 128), dtype=torch.bfloat16)
