@@ -6,15 +6,26 @@ A "step" is one decode token of the hot path: for every sparse layer of the mode
 (30 of Llama-3.1-8B's 32), q SimHash -> L table probes + collision-count dedupe -> gathered
 sparse KV attention with importance-sampling correction (models/attnserver.py:264-300), on
 synthetic Q/K/V already resident in HBM.  Loop shape as examples/bench.py:47-56 (32 warm-up +
-128 timed steps by default).  One process per GPU; for N > 1 the driver launches this file under
-torch.distributed.run and every rank serves its own batch of requests (weak scaling, no
-collective inside the path; RCCL only for the barrier and the max-over-ranks time).
+128 timed steps by default).
+
+One process per GPU.  `--gpus N` with N > 1 runs N ranks whichever way it is started: under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE / MASTER_* in the
+environment) it IS one of the ranks; started plainly (`python bench.py --gpus N`, no WORLD_SIZE) it re-executes
+itself under torch.distributed.run on 127.0.0.1 (evaluations/RULER/run_tensor_parallel.sh:84 starts the reference's
+TP variant the same way).  A world size that is not --gpus, or fewer visible GPUs than --gpus, is an error, never a
+silent 1-GPU run.  Ranks own disjoint units -- requests (cfg 1-3: --shard batch, weak scaling) or the model's kv
+heads (cfg 4: --shard head, attnserver_dist.py:252-254, strong scaling); no collective inside the path, RCCL only for
+the hyperplane broadcast, the barrier, the max-over-ranks time and the checksums.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying
   roofline      the dominant kernel (lsh_decode_kernel, one launch per sparse layer): algorithmic
                 bytes per launch / average launch duration from HIP events on the launch stream;
   cpu_baseline  the reference's own AVX512 path (oracle/_ref, kind "reference") or the oracle
-                port (kind "port") timed on this box's host cores on a bounded sample.
+                port (kind "port") timed on this box's host cores on a bounded sample;
+  legs          (default single-GPU run of cfg 1) the same measurement, shorter, at cfg 2 and at cfg 4's per-GPU
+                share -- tokens/s, us per layer, roofline, the full-size first layer against the CPU path -- so that
+                those configurations are observed by whoever runs this file, not only claimed in profiles/.
+A leg that fails is recorded in the line AND makes the exit status non-zero (unless --allow-missing-legs).
 """
 from __future__ import annotations
 
@@ -132,9 +143,19 @@ def parse():
                          "model's sparse layers -- the HBM footprint a step touches shrinks (address translation, "
                          "MALL) while launch count and shapes stay")
     ap.add_argument("--table-build", default="counting", choices=["sort", "counting"])
-    ap.add_argument("--shard", default="batch", choices=["batch", "head"],
+    ap.add_argument("--shard", default=None, choices=["batch", "head"],
                     help="batch: every rank serves its own B requests (weak scaling); head: the kv heads of the "
-                         "whole model are partitioned over the ranks like the reference's TP variant (strong scaling)")
+                         "whole model are partitioned over the ranks like the reference's TP variant (strong scaling).  "
+                         "Default: head for cfg4 on more than one GPU (the configuration IS the TP = 8 layout), batch otherwise")
+    ap.add_argument("--legs", default="cfg2,cfg4",
+                    help="extra configurations measured after the headline in the default single-GPU cfg1 run and reported "
+                         "under `legs` (cfg4 = its per-GPU share, as --config cfg4 on one GPU); '' or --no-legs: none")
+    ap.add_argument("--no-legs", action="store_true")
+    ap.add_argument("--leg-cpu-steps", type=int, default=1024,
+                    help="decode steps of one sparse layer the CPU path is timed on in a leg (one thread placement)")
+    ap.add_argument("--allow-missing-legs", action="store_true",
+                    help="a failing host-mode / CPU-baseline / clustered / config leg is recorded in the line but does "
+                         "not turn the exit status non-zero")
     ap.add_argument("--lib", default=None,
                     help="A/B: path of an alternative build of libmagicpig_hip.so (the product reads no environment)")
     ap.add_argument("--cluster", type=int, default=0,
@@ -155,6 +176,8 @@ def parse():
                     help="examples/bench.py-style full decode step with synthetic weights (SURVEY 8f-3) "
                          "instead of the hot path alone")
     args = ap.parse_args()
+    if args.no_legs:
+        args.legs = ""
     if args.config_json:
         CONFIGS["custom"] = dict(json.loads(args.config_json))
         CONFIGS["custom"]["dense"] = tuple(CONFIGS["custom"].get("dense", ()))
@@ -227,9 +250,9 @@ def cpu_worker(path: str) -> None:
     print("CPU_BASELINE_JSON " + json.dumps(res))
 
 
-def run_cpu_baseline(cfg, server, qs, steps, H, Hkv):
+def run_cpu_baseline(cfg, server, qs, steps, H, Hkv, placements=(None, "cores")):
     """Dump the first sparse layer (tables, KV, queries) and time the CPU path on it.  H, Hkv: the heads this
-    process actually serves (cfg's, or the head shard's)."""
+    process actually serves (cfg's, or the head shard's).  placements: OMP_PLACES settings tried (best one reported)."""
     B, D, M, K, Lt = (cfg[k] for k in ("B", "D", "M", "K", "L"))
     n = cfg["P"] - 68
     layer = 0
@@ -257,7 +280,7 @@ def run_cpu_baseline(cfg, server, qs, steps, H, Hkv):
     # is reported: (a) libgomp default places, (b) one thread per physical core, packed
     best = None
     try:
-        for places in (None, "cores"):
+        for places in placements:
             env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_THREAD_LIMIT=str(cores),
                        OMP_PROC_BIND="close", MKL_NUM_THREADS=str(cores))
             if places:
@@ -285,7 +308,7 @@ def run_cpu_baseline(cfg, server, qs, steps, H, Hkv):
 
 # ---------------------------------------------------------------------------- host-buffer mode leg
 
-def host_mode_leg(server, cfg, qs, H, reps=40):
+def host_mode_leg(server, cfg, qs, H, reps=40, pin_results=False):
     """Per-layer cost of the UNCHANGED caller: the decode lines of models/attnserver.py:264-303 -- q hash on the GPU,
     codes + query copied to pinned CPU tensors, batch_retrieve and attention_wrapper on CPU tensors (`results` and
     `nnz` pageable, the rest pinned, exactly as :59-66), output + LSE copied back -- eager, synchronised per layer.
@@ -296,6 +319,8 @@ def host_mode_leg(server, cfg, qs, H, reps=40):
     pin = lambda *shape, dtype: torch.zeros(shape, dtype=dtype).pin_memory()       # noqa: E731
     pinned_hashcode, pinned_query = pin(BH, Lt, dtype=torch.int32), pin(BH, D, dtype=torch.bfloat16)
     results, nnz = torch.zeros((BH, M), dtype=torch.int32), torch.zeros((BH,), dtype=torch.int32)      # :59-60: pageable
+    if pin_results:      # the ONE caller-side change INTEGRATION.md 1 recommends: pin_memory=True on these two allocations
+        results, nnz = results.pin_memory(), nnz.pin_memory()
     output, mve = pin(BH, D, dtype=torch.bfloat16), pin(2, BH, dtype=torch.float32)
     out_cuda = torch.zeros((BH, D), dtype=torch.bfloat16, device=dev)
     lse_cuda = torch.zeros((BH,), dtype=torch.float32, device=dev)
@@ -330,8 +355,10 @@ def host_mode_leg(server, cfg, qs, H, reps=40):
     torch.cuda.synchronize()
     same = bool(torch.equal(server.nnz.cpu(), nnz)) and float((server.output.float().cpu() - output.float()).abs().max()) < 2e-2
     return {"us_per_layer": us, "matches_device_entry": same, "reps": reps,
-            "what": "models/attnserver.py:264-303 unchanged: GPU q-hash, pinned codes/query/output, pageable results/nnz, "
-                    "batch_retrieve + attention_wrapper on CPU tensors, eager + synchronised per layer"}
+            "what": "models/attnserver.py:264-303 unchanged: GPU q-hash, pinned codes/query/output, "
+                    + ("results/nnz allocated with pin_memory=True (the one flag INTEGRATION.md 1 recommends), "
+                       if pin_results else "pageable results/nnz, ")
+                    + "batch_retrieve + attention_wrapper on CPU tensors, eager + synchronised per layer"}
 
 
 # ---------------------------------------------------------------------------- end-to-end variant
@@ -418,6 +445,9 @@ def dry_run(args, rank, world):
     line = {"metric": "dry-run", "value": world * cfg["B"] * args.steps / dt, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "config": {"workload": args.config + " (dry run: a sleep stands in for the kernels)", "shard": args.shard,
+                       "process_group": None if dist is None else f"{dist.get_backend()} x{dist.get_world_size()}"},
+            "rank_checksums": sharding.gather_scalars(1000 + rank),
             "planes_checksum": int(hash_func.view(torch.int16).to(torch.int64).sum())}
     if args.shard == "head":
         # the head-sharded layout of main(): partition -> (stand-in outputs: element = global head index) ->
@@ -434,6 +464,265 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------- N ranks from a plain start
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: re-execute this file under
+    torch.distributed.run with N local ranks on 127.0.0.1 (evaluations/RULER/run_tensor_parallel.sh:84 starts the
+    reference's tensor-parallel variant with `torchrun --nproc_per_node=8`).  Rank 0's JSON line is the child's stdout,
+    the exit status the child's.  Fewer visible GPUs than ranks is an ERROR -- the measurement the caller asked for
+    does not exist on this node -- never a smaller run under the same label."""
+    import socket
+
+    n = args.gpus
+    if not args.dry_run:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            sys.exit(f"bench.py: --gpus {n} asked for, {have} GPU(s) visible on this node: refusing to run fewer ranks "
+                     f"under the label n_gpus = {n}")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes needs it on this driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+# ---------------------------------------------------------------------------- one configuration on this rank
+
+class Workload:
+    """One configuration's server (all sparse layers of the model shape on synthetic keys), NQ steps' worth of
+    queries, and the captured step.  Units -- (request, kv head) -- are drawn from their GLOBAL ids, so a rank's data
+    does not depend on how many ranks share the work."""
+    NQ = 16
+
+    def __init__(self, mp, sharding, args, name, cfg, dev, rank, urank, uworld, shard_mode, data, queries):
+        self.mp, self.args, self.name, self.cfg, self.dev, self.data = mp, args, name, cfg, dev, data
+        B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
+        self.shard = None
+        if shard_mode == "head":
+            # the model's heads over the ranks (evaluations/RULER/pred/attnserver_dist.py:252-254): rank r owns kv heads
+            # [r * Hkv_full / world, ...) and their query heads; nothing is exchanged inside the path
+            H_full, Hkv_full = cfg.get("H_full", H), cfg.get("Hkv_full", Hkv)
+            self.shard = sharding.partition(B, H_full, Hkv_full, uworld, urank, mode="head")
+            H, Hkv = self.shard.local_heads, self.shard.local_kv_heads
+        self.B, self.H, self.Hkv, self.D, self.M, self.K, self.Lt, self.P = B, H, Hkv, D, M, K, Lt, P
+        self.G = H // Hkv
+        self.g_requests = list(range(B)) if self.shard is not None else list(range(urank * B, (urank + 1) * B))
+        self.g_kv_heads = list(self.shard.kv_heads) if self.shard is not None else list(range(Hkv))
+        self.NL = len([i for i in range(cfg["layers"]) if i not in cfg["dense"]])
+        self.BH, self.n = B * H, P - 68
+        # identical hyperplanes on every rank: rank 0's are broadcast once (attnserver_dist.py:279)
+        gen0 = torch.Generator(device="cpu").manual_seed(7 + rank)
+        hash_func = torch.randn((D, K * Lt), generator=gen0, dtype=torch.float32).to(torch.bfloat16).to(dev)
+        self.hash_func = sharding.sync_hash_func(hash_func, src=0)
+        self.graph = None
+        self._build(queries)
+        self.q_static = self.qs[0].clone()
+        self.ND = args.distinct_layers if args.distinct_layers > 0 else self.NL
+
+    def _build(self, queries):
+        mp, dev, data, NQ = self.mp, self.dev, self.data, self.NQ
+        B, H, Hkv, D, P, NL, n, G = self.B, self.H, self.Hkv, self.D, self.P, self.NL, self.n, self.G
+        srv = mp.LSHSparseAttnServer(NL, H, Hkv, D, K=self.K, L=self.Lt, batch_size=B, max_length=self.M,
+                                     dense_layers=(), device=str(dev), hash_func=self.hash_func,
+                                     table_build=self.args.table_build)
+        t_s = time.time()
+        for li in range(NL):
+            for b in range(B):
+                ks, vs = [], []
+                for gkv in self.g_kv_heads:      # one (request, kv head) unit at a time, seeded by its GLOBAL id
+                    gen_kv = torch.Generator(device=dev).manual_seed(1000 + 1_000_003 * li + 10_007 * self.g_requests[b] + gkv)
+                    k1, v1 = synth_kv(data, P, 1, D, dev, gen_kv)
+                    ks.append(k1)
+                    vs.append(v1)
+                kc, vc = torch.cat(ks, dim=1), torch.cat(vs, dim=1)
+                srv.fill(li, b, kc, vc, P)
+                srv.build_table(li, b, P)
+                del kc, vc, ks, vs
+        torch.cuda.synchronize()
+        self.t_setup = time.time() - t_s
+        q = torch.empty((NQ, NL, B, H, 1, D), device=dev, dtype=torch.float32)
+        hv = queries == "heavy" or (queries == "auto" and data != "randn")
+        jj = torch.zeros((NQ, NL, B, H), device=dev, dtype=torch.long)
+        for b in range(B):
+            for hl in range(H):                 # one query head of one request at a time, seeded by its GLOBAL id
+                gh = self.g_kv_heads[hl // G] * G + hl % G
+                gen_q = torch.Generator(device=dev).manual_seed(2000 + 100_003 * self.g_requests[b] + gh)
+                q[:, :, b, hl, 0] = torch.randn((NQ, NL, D), device=dev, dtype=torch.float32, generator=gen_q)
+                if hv:
+                    jj[:, :, b, hl] = torch.randint(0, n, (NQ, NL), device=dev, generator=gen_q)
+        if hv:   # every query is pulled toward one (centred) key of its kv group: q <- 0.5 q + 3 k_j (one gather per layer)
+            bi = torch.arange(B, device=dev)[None, :, None].expand(NQ, B, H)
+            gi = (torch.arange(H, device=dev) // G)[None, None, :].expand(NQ, B, H)
+            for li in range(NL):
+                kc = srv.attn_server.get_key_cache(li)                             # [B, Hkv, M, D] centred keys
+                q[:, li, :, :, 0] = 0.5 * q[:, li, :, :, 0] + 3.0 * kc[bi, gi, jj[:, li]].float()
+        self.server, self.qs, self.heavy = srv, q.to(torch.bfloat16), hv
+
+    # -- one decode token: every sparse layer once
+    def step(self):
+        for li in range(self.NL):
+            self.server.decode(self.q_static[li], li % self.ND)
+
+    def capture(self):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.step()
+        return g
+
+    def run_steps(self, k0, count, graph="own"):
+        g = self.graph if graph == "own" else graph
+        for i in range(count):
+            self.q_static.copy_(self.qs[(k0 + i) % self.NQ])    # this step's queries (produced by the QKV GEMM in a model)
+            if g is not None:
+                g.replay()
+            else:
+                self.step()
+
+    def observe(self):
+        """Untimed stats pass on step 0's queries: selected tokens per head, candidates, probed piece lengths."""
+        srv, dev, BH, H, Hkv, Lt, NL = self.server, self.dev, self.BH, self.H, self.Hkv, self.Lt, self.NL
+        srv.collect_nnz = True
+        nnz_obs, cand_obs, piece_obs = [], [], []
+        for li in range(NL):
+            srv.decode(self.q_static[li], li)
+            nnz_obs.append(srv.nnz.clone())
+            if li < 4:
+                codes, _ = srv.hasher.query(self.q_static[li].reshape(BH, self.D))
+                bounds, _ = srv.lsh_retriever.get_tables(li)
+                g = torch.arange(BH, device=dev) // (H // Hkv)
+                be = bounds[g[:, None], torch.arange(Lt, device=dev)[None, :], codes.long()]   # [BH, L, R + 1]
+                cand_obs.append((be[..., -1] - be[..., 0]).sum(-1))
+                piece_obs.append((be[..., 1:] - be[..., :-1]).flatten())   # (table, bucket, token range) pieces probed
+        torch.cuda.synchronize()
+        srv.collect_nnz = False      # no statistics copies inside the timed region
+        self.nnz_all = torch.stack(nnz_obs).float()
+        self.nnz_mean = float(self.nnz_all.mean())
+        self.cand_mean = float(torch.stack(cand_obs).float().mean())
+        pieces = torch.cat(piece_obs).float()
+        sample = pieces if pieces.numel() < (1 << 24) else pieces[:1 << 24]
+        self.piece_stats = {"ranges_per_head": int(srv.lsh_retriever.R), "mean": float(pieces.mean()),
+                            "p50": float(sample.quantile(0.5)), "p99": float(sample.quantile(0.99)),
+                            "max": float(pieces.max()), "share_gt_30": float((pieces > 30).float().mean()),
+                            "share_gt_126": float((pieces > 126).float().mean())}
+
+    def bytes_per_launch(self):
+        """Whole-layer algorithmic bytes, SURVEY.md 8(d): per head L bucket probes (8 B), the candidate ids (4 B), the
+        selected ids (4 B), per selected token K row + V row + key norm + id, q and out; plus the hyperplanes once."""
+        BH, Lt, D, K = self.BH, self.Lt, self.D, self.K
+        return BH * (8 * Lt + 4 * self.cand_mean + 4 * self.nnz_mean + self.nnz_mean * (4 * D + 4) + 4 * self.nnz_mean
+                     + 2 * D + 8) + 2 * D * K * Lt + BH * (2 * D + 4 * Lt)
+
+    def launch_us(self, reps=8):
+        """Average duration of one launch of the dominant kernel (a sparse layer IS one launch of lsh_decode_kernel):
+        HIP events recorded on the launch stream around back-to-back launches (graph replays when captured)."""
+        self.q_static.copy_(self.qs[0])
+
+        def layer_pass():
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                for li in range(self.NL):
+                    self.server.decode(self.q_static[li], li)
+        layer_pass()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            layer_pass()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (reps * self.NL), reps * self.NL
+
+    def footprint(self):
+        """HBM this configuration holds per sparse layer on this GPU: what the reference keeps in
+        host memory (KV, norms, table) and what this implementation adds to it (sub-bounds, direct slots)."""
+        f = dict(self.server.attn_server.footprint())
+        f.update(self.server.lsh_retriever.footprint())
+        total = f["kv"] + f["key_norms"] + f["bounds"] + f["table"] + f["slots"]
+        f["total"] = total
+        f["all_sparse_layers_GB"] = round(total * self.NL / 1e9, 2)
+        f["index_over_kv"] = round((f["bounds"] + f["table"] + f["slots"]) / f["kv"], 2)
+        return f
+
+    def roofline(self, fused=True):
+        k_us, n_timed = self.launch_us()
+        bl = self.bytes_per_launch()
+        achieved = bl / (k_us * 1e-6) / 1e9
+        return {"bound": "hbm", "kernel": "lsh_decode_kernel" if fused else "lsh_retrieve_kernel + attn_sparse_kernel",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "traffic_source": None, "bytes_per_launch": bl, "avg_launch_us": k_us,
+                "launches_timed": n_timed}
+
+    def cpu_check(self, cpu_steps, placements):
+        """The CPU path on this box's host cores on the first sparse layer, and the GPU's full-size first layer against it."""
+        cb = run_cpu_baseline(self.cfg, self.server, self.qs, cpu_steps, self.H, self.Hkv, placements=placements)
+        t_layer = cb["t_retrieve_us"] + cb["t_attention_us"]
+        res = {"value": self.B / (self.NL * t_layer * 1e-6), "unit": "tokens/s", "cores": cb["cores"], "kind": cb["kind"],
+               "sample": f"1 of {self.NL} sparse layers x {cb['steps']} decode steps, same tables/KV/queries as "
+                         f"the GPU's first sparse layer; tokens/s = B / ({self.NL} x t_layer); "
+                         f"OMP_PLACES={cb.get('omp_places')}, best of {len(placements)} placement(s)",
+               "t_retrieve_us": cb["t_retrieve_us"], "t_attention_us": cb["t_attention_us"]}
+        self.q_static.copy_(self.qs[0])
+        self.server.collect_nnz = True
+        o, _ = self.server.decode(self.q_static[0], 0)
+        torch.cuda.synchronize()
+        same_nnz = self.server.nnz.cpu().tolist() == cb["nnz0"]
+        dmax = float((o.float().flatten().cpu() - torch.tensor(cb["out0"])).abs().max())
+        self.server.collect_nnz = False
+        res["gpu_matches"] = {"nnz_equal": same_nnz, "max_abs_out_diff": dmax}
+        return res
+
+    def release(self):
+        self.graph = None
+        self.server = None
+        self.qs = self.q_static = None
+        torch.cuda.empty_cache()
+
+
+def config_leg(mp, sharding, args, name, dev):
+    """A second / third CONFIGURATION in the same line: the headline's measurement at cfg 2 or at
+    cfg 4's per-GPU share, shorter legs around it -- same loop, same graph capture, HIP-event launch average, SURVEY
+    8(d) bytes, the full-size first layer against the CPU path of this box."""
+    cfg = CONFIGS[name]
+    w = Workload(mp, sharding, args, name, cfg, dev, 0, 0, 1, "batch", "randn", "auto")
+    w.observe()
+    if not args.no_graph:
+        w.graph = w.capture()
+    w.run_steps(0, args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    w.run_steps(args.warmup, args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    roof = w.roofline()
+    w.server.attn_server.check()
+    leg = {"workload": f"{name}{' (per-GPU share of TP=8)' if name == 'cfg4' else ''}: {cfg['model']} B={w.B} P={w.P} "
+                       f"K={w.K} L={w.Lt}, {w.NL} sparse layers/step, H={w.H} Hkv={w.Hkv} D={w.D}",
+           "tokens_per_s": w.B * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+           "us_per_layer": dt / args.steps * 1e6 / w.NL, "steps": args.steps, "warmup": args.warmup,
+           "nnz_per_head": w.nnz_mean, "candidates_per_head": w.cand_mean, "selected_fraction": w.nnz_mean / w.n,
+           "ranges_per_head": w.piece_stats["ranges_per_head"],
+           "roofline": {k: roof[k] for k in ("bytes_per_launch", "avg_launch_us", "achieved", "frac", "launches_timed")},
+           "hbm_bytes_per_layer": w.footprint()}
+    if not args.no_cpu_baseline:
+        leg["cpu_baseline"] = w.cpu_check(args.leg_cpu_steps, ("cores",))
+        leg["speedup_vs_cpu"] = leg["tokens_per_s"] / leg["cpu_baseline"]["value"]
+    w.release()
+    return leg
+
+
 # ---------------------------------------------------------------------------- main
 
 def main():
@@ -441,12 +730,23 @@ def main():
     if args.cpu_baseline_worker:
         cpu_worker(args.cpu_baseline_worker)
         return
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_rank:
+        launch_ranks(args)                       # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: start it as `python bench.py --gpus N` or under "
+                 "`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (one rank per GPU)")
+    if args.shard is None:     # cfg 4 IS the TP = 8 layout of the 70B model: on several GPUs its kv heads are what is sharded
+        args.shard = "head" if (args.config == "cfg4" and world > 1) else "batch"
     if args.dry_run:
         return dry_run(args, rank, world)
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have <= local_rank:
+        sys.exit(f"bench.py: rank {rank} (LOCAL_RANK {local_rank}) has no GPU: {have} visible on this node")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -481,82 +781,16 @@ def main():
         L.set_option("decode_direct", args.direct_slots)
     if args.end_to_end:
         return end_to_end(args, cfg, rank, world, dev, dist)
-    B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
     # which units (request, kv head) this process serves: by its rank in the process group, or -- --emulate-rank R/W,
     # one process, no group -- those rank R of W would serve
     urank, uworld = rank, world
     if args.emulate_rank:
         urank, uworld = (int(x) for x in args.emulate_rank.split("/"))
-        assert world == 1 and 0 <= urank < uworld
-    shard = None
-    if args.shard == "head":
-        # the model's heads over the ranks (evaluations/RULER/pred/attnserver_dist.py:252-254): rank r owns kv heads
-        # [r * Hkv_full / world, ...) and their query heads; nothing is exchanged inside the path
-        H_full, Hkv_full = cfg.get("H_full", H), cfg.get("Hkv_full", Hkv)
-        shard = sharding.partition(B, H_full, Hkv_full, uworld, urank, mode="head")
-        H, Hkv = shard.local_heads, shard.local_kv_heads
-    # global ids of the units: synthetic K/V and queries are drawn PER UNIT from its global id, so a unit's data does
-    # not depend on how many ranks share the work (a rank's outputs equal the single-process outputs of the same units)
-    G_heads = H // Hkv
-    g_requests = list(range(B)) if shard is not None else list(range(urank * B, (urank + 1) * B))
-    g_kv_heads = list(shard.kv_heads) if shard is not None else list(range(Hkv))
-    sparse_layers = [i for i in range(cfg["layers"]) if i not in cfg["dense"]]
-    NL = len(sparse_layers)
-    BH = B * H
-    n = P - 68
-
-    # identical hyperplanes on every rank: rank 0's are broadcast once (attnserver_dist.py:279)
-    gen0 = torch.Generator(device="cpu").manual_seed(7 + rank)
-    hash_func = torch.randn((D, K * Lt), generator=gen0, dtype=torch.float32).to(torch.bfloat16).to(dev)
-    hash_func = sharding.sync_hash_func(hash_func, src=0)
-    NQ = 16
-
-    def build_workload(data, queries):
-        """A server holding all sparse layers of the model shape on `data` keys, and NQ steps' worth of queries."""
-        srv = mp.LSHSparseAttnServer(NL, H, Hkv, D, K=K, L=Lt, batch_size=B, max_length=M,
-                                     dense_layers=(), device=str(dev), hash_func=hash_func,
-                                     table_build=args.table_build)
-        t_s = time.time()
-        for li in range(NL):
-            for b in range(B):
-                ks, vs = [], []
-                for gkv in g_kv_heads:          # one (request, kv head) unit at a time, seeded by its GLOBAL id
-                    gen_kv = torch.Generator(device=dev).manual_seed(1000 + 1_000_003 * li + 10_007 * g_requests[b] + gkv)
-                    k1, v1 = synth_kv(data, P, 1, D, dev, gen_kv)
-                    ks.append(k1)
-                    vs.append(v1)
-                kc, vc = torch.cat(ks, dim=1), torch.cat(vs, dim=1)
-                srv.fill(li, b, kc, vc, P)
-                srv.build_table(li, b, P)
-                del kc, vc, ks, vs
-        torch.cuda.synchronize()
-        t_s = time.time() - t_s
-        q = torch.empty((NQ, NL, B, H, 1, D), device=dev, dtype=torch.float32)
-        hv = queries == "heavy" or (queries == "auto" and data != "randn")
-        jj = torch.zeros((NQ, NL, B, H), device=dev, dtype=torch.long)
-        for b in range(B):
-            for hl in range(H):                 # one query head of one request at a time, seeded by its GLOBAL id
-                gh = g_kv_heads[hl // G_heads] * G_heads + hl % G_heads
-                gen_q = torch.Generator(device=dev).manual_seed(2000 + 100_003 * g_requests[b] + gh)
-                q[:, :, b, hl, 0] = torch.randn((NQ, NL, D), device=dev, dtype=torch.float32, generator=gen_q)
-                if hv:
-                    jj[:, :, b, hl] = torch.randint(0, n, (NQ, NL), device=dev, generator=gen_q)
-        if hv:   # every query is pulled toward one (centred) key of its kv group: q <- 0.5 q + 3 k_j (one gather per layer)
-            bi = torch.arange(B, device=dev)[None, :, None].expand(NQ, B, H)
-            gi = (torch.arange(H, device=dev) // G_heads)[None, None, :].expand(NQ, B, H)
-            for li in range(NL):
-                kc = srv.attn_server.get_key_cache(li)                             # [B, Hkv, M, D] centred keys
-                q[:, li, :, :, 0] = 0.5 * q[:, li, :, :, 0] + 3.0 * kc[bi, gi, jj[:, li]].float()
-        return srv, q.to(torch.bfloat16), hv, t_s
-
-    server, qs, heavy, t_setup = build_workload(args.data, args.queries)
-    q_static = qs[0].clone()
-
-    ND = args.distinct_layers if args.distinct_layers > 0 else NL
-
-    def step():
-        for li in range(NL):
-            server.decode(q_static[li], li % ND)
+        if world != 1 or not 0 <= urank < uworld:
+            sys.exit("bench.py: --emulate-rank R/W needs one process and 0 <= R < W")
+    w = Workload(mp, sharding, args, args.config, cfg, dev, rank, urank, uworld, args.shard, args.data, args.queries)
+    shard, server, qs, q_static = w.shard, w.server, w.qs, w.q_static
+    B, H, Hkv, D, M, K, Lt, P, NL, NQ, n = w.B, w.H, w.Hkv, w.D, w.M, w.K, w.Lt, w.P, w.NL, w.NQ, w.n
 
     def sync_all():
         torch.cuda.synchronize()
@@ -564,55 +798,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # stats pass (untimed): nnz and candidate counts actually observed on step 0
-    nnz_obs, cand_obs, piece_obs = [], [], []
-    for li in range(NL):
-        server.decode(q_static[li], li)
-        nnz_obs.append(server.nnz.clone())
-        if li < 4:
-            codes, _ = server.hasher.query(q_static[li].reshape(BH, D))
-            bounds, _ = server.lsh_retriever.get_tables(li)
-            g = torch.arange(BH, device=dev) // (H // Hkv)
-            be = bounds[g[:, None], torch.arange(Lt, device=dev)[None, :], codes.long()]   # [BH, L, R + 1]
-            cand_obs.append((be[..., -1] - be[..., 0]).sum(-1))
-            piece_obs.append((be[..., 1:] - be[..., :-1]).flatten())   # (table, bucket, token range) pieces probed
-    torch.cuda.synchronize()
-    nnz_all = torch.stack(nnz_obs).float()
-    nnz_mean = float(nnz_all.mean())
-    cand_mean = float(torch.stack(cand_obs).float().mean())
-    pieces = torch.cat(piece_obs).float()
-    piece_stats = {"ranges_per_head": int(server.lsh_retriever.R), "mean": float(pieces.mean()),
-                   "p50": float(pieces.quantile(0.5)) if pieces.numel() < (1 << 24) else float(pieces[:1 << 24].quantile(0.5)),
-                   "p99": float(pieces.quantile(0.99)) if pieces.numel() < (1 << 24) else float(pieces[:1 << 24].quantile(0.99)),
-                   "max": float(pieces.max()), "share_gt_30": float((pieces > 30).float().mean()),
-                   "share_gt_126": float((pieces > 126).float().mean())}
-
-    server.collect_nnz = False      # no statistics copies inside the timed region
-    graph = None
+    w.observe()
     if not args.no_graph:
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            step()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
+        w.graph = w.capture()
 
     if args.ab_worker:
         # One side of scripts/ab_libs.py: this process holds ONE build of the library (--lib), the workload and a captured
         # step; the parent alternates timed regions between two such processes on the same GPU.  Protocol on stdin / stdout:
         # "ready" once the step is captured; per "go" line one JSON line {"us_per_layer", "checksum"}; "quit" ends.
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            step()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            step()
+        g = w.capture()
         q_static.copy_(qs[0])
         g.replay()
         torch.cuda.synchronize()
@@ -625,14 +819,10 @@ def main():
                 break
             if cmd != "go":
                 continue
-            for i in range(args.warmup):
-                q_static.copy_(qs[i % NQ])
-                g.replay()
+            w.run_steps(0, args.warmup, g)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(args.steps):
-                q_static.copy_(qs[i % NQ])
-                g.replay()
+            w.run_steps(0, args.steps, g)
             torch.cuda.synchronize()
             print(json.dumps({"us_per_layer": round((time.perf_counter() - t0) / args.steps / NL * 1e6, 3),
                               "checksum": chk}), flush=True)
@@ -647,16 +837,7 @@ def main():
         graphs = []
         for v in vals:
             L.set_option(name, v)
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                step()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                step()
-            graphs.append(g)
+            graphs.append(w.capture())
         L.set_option(name, vals[0])
         # same queries through every captured variant: the last layer's outputs must be the same bits
         outs = []
@@ -669,14 +850,10 @@ def main():
         res = {str(v): [] for v in vals}
         for rep in range(args.ab_reps):
             for v, g in zip(vals, graphs):
-                for i in range(args.warmup):
-                    q_static.copy_(qs[i % NQ])
-                    g.replay()
+                w.run_steps(0, args.warmup, g)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for i in range(args.steps):
-                    q_static.copy_(qs[i % NQ])
-                    g.replay()
+                w.run_steps(0, args.steps, g)
                 torch.cuda.synchronize()
                 res[str(v)].append(round((time.perf_counter() - t0) / args.steps / NL * 1e6, 3))
         server.attn_server.check()
@@ -684,18 +861,10 @@ def main():
                           "outputs_bit_identical": same, "us_per_layer": res}))
         return
 
-    def run_steps(k0, count):
-        for i in range(count):
-            q_static.copy_(qs[(k0 + i) % NQ])    # this step's queries (produced by the QKV GEMM in a model)
-            if graph is not None:
-                graph.replay()
-            else:
-                step()
-
-    run_steps(0, args.warmup)
+    w.run_steps(0, args.warmup)
     sync_all()
     t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
+    w.run_steps(args.warmup, args.steps)
     sync_all()
     dt = time.perf_counter() - t0
     dt = sharding.max_over_ranks(dt, device=dev)
@@ -730,36 +899,12 @@ def main():
     # so the dominant kernel is the step itself: its average duration is taken from HIP events recorded
     # on the launch stream around back-to-back launches (graph replays when the step is captured), its
     # algorithmic bytes are the whole-layer figure of SURVEY.md 8(d).
-    prof_reps = 8
-    q_static.copy_(qs[0])
-    def layer_pass():
-        if graph is not None:
-            graph.replay()
-        else:
-            for li in range(NL):
-                server.decode(q_static[li], li)
-    layer_pass()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(prof_reps):
-        layer_pass()
-    e1.record()
-    torch.cuda.synchronize()
-    n_timed = prof_reps * NL
-    k_us = e0.elapsed_time(e1) * 1e3 / n_timed
+    fused = not args.two_launch
+    roof = w.roofline(fused)
     # the device-side validations of all the launches above (append overflow, a cluster seen on two XCDs): raises
     server.attn_server.check()
-    # whole-layer algorithmic bytes, SURVEY.md 8(d): per head L bucket probes (8 B), the candidate
-    # ids (4 B), the selected ids (4 B), per selected token K row + V row + key norm + id, q and out;
-    # plus the hyperplanes once per layer
-    bytes_layer = BH * (8 * Lt + 4 * cand_mean + 4 * nnz_mean + nnz_mean * (4 * D + 4) + 4 * nnz_mean
-                        + 2 * D + 8) + 2 * D * K * Lt + BH * (2 * D + 4 * Lt)
-    achieved = bytes_layer / (k_us * 1e-6) / 1e9
-    fused = not args.two_launch
     # HBM traffic per launch cannot be counted from inside this process (the PMC counters need rocprofv3 around
     # it): the line carries the figure of the last committed PMC passes over this same command and says so
-    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
     if os.path.exists(tpath) and shard is None:
         try:
@@ -768,11 +913,11 @@ def main():
             key = "lsh_decode_bytes_per_launch" if fused else "two_launch_bytes_per_layer"
             if args.data != "randn":
                 key += "_" + args.data              # PMC passes exist per key distribution (or not at all)
-            traffic = (tj.get(key) or {}).get(args.config)
-            if traffic is not None:
-                traffic_source = "not measured in this run: rocprofv3 PMC passes of " + str(tj.get("source", "profiles/"))
+            roof["traffic"] = (tj.get(key) or {}).get(args.config)
+            if roof["traffic"] is not None:
+                roof["traffic_source"] = "not measured in this run: rocprofv3 PMC passes of " + str(tj.get("source", "profiles/"))
         except Exception:
-            traffic = None
+            roof["traffic"] = None
 
     out = {
         "metric": "decode tokens/sec (LSH sparse-attention path), " + cfg["model"] +
@@ -780,7 +925,7 @@ def main():
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong" if shard is not None else "weak", "vs_baseline": None, "dtype": "bf16",
-        "data": "synthetic" if args.data == "randn" else f"synthetic ({args.data} keys, heavy-hitter queries)" if heavy
+        "data": "synthetic" if args.data == "randn" else f"synthetic ({args.data} keys, heavy-hitter queries)" if w.heavy
                 else f"synthetic ({args.data} keys)",
         "config": {"workload": f"{args.config}: {cfg['model']} B={B} P={P} K={K} L={Lt}, "
                                f"{NL} sparse layers/step, H={H} Hkv={Hkv} D={D}, KV+tables resident in HBM",
@@ -788,115 +933,98 @@ def main():
                    "parallelism": (f"tp{world} (kv heads sharded: {Hkv} of {cfg.get('Hkv_full', Hkv)} kv heads, "
                                    f"{H} of {cfg.get('H_full', H)} query heads per GPU)") if shard is not None
                                   else f"dp{world} (requests sharded)",
-                   "launch": "eager" if graph is None else "hipGraph",
+                   "launch": "eager" if w.graph is None else "hipGraph",
                    "process_group": None if dist is None else f"{dist.get_backend()} x{dist.get_world_size()}"},
         "sparse_attn_us_per_layer": us_per_layer,
         "rank_checksums": rank_checksums,
         **({"emulated_rank": args.emulate_rank} if args.emulate_rank else {}),
-        **({"DIAGNOSTIC_distinct_layers": ND} if ND != NL else {}),
-        "observed": {"nnz_per_head": nnz_mean, "candidates_per_head": cand_mean,
-                     "selected_fraction": nnz_mean / n, "nnz_max_head": float(nnz_all.max()),
-                     "probed_pieces": piece_stats, "key_distribution": args.data,
-                     "queries": "heavy" if heavy else "randn", "setup_s": t_setup},
-        "roofline": {"bound": "hbm",
-                     "kernel": "lsh_decode_kernel" if fused else "lsh_retrieve_kernel + attn_sparse_kernel",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_source, "bytes_per_launch": bytes_layer,
-                     "avg_launch_us": k_us, "launches_timed": n_timed},
+        **({"DIAGNOSTIC_distinct_layers": w.ND} if w.ND != NL else {}),
+        "observed": {"nnz_per_head": w.nnz_mean, "candidates_per_head": w.cand_mean,
+                     "selected_fraction": w.nnz_mean / n, "nnz_max_head": float(w.nnz_all.max()),
+                     "probed_pieces": w.piece_stats, "key_distribution": args.data,
+                     "queries": "heavy" if w.heavy else "randn", "setup_s": w.t_setup,
+                     "hbm_bytes_per_layer": w.footprint()},
+        "roofline": roof,
     }
     if gathered is not None:
         out["head_shard_gather"] = gathered
 
-    if rank == 0 and world == 1 and shard is None and not args.no_host_mode:
+    # ---- the extra legs of a single-GPU run.  A leg that fails is recorded in the line and (unless
+    # --allow-missing-legs) turns the exit status non-zero: a line without its CPU baseline must not look like a success
+    failures = []
+    solo = rank == 0 and world == 1 and dist is None and not args.emulate_rank
+
+    def attempt(name, fn, on_fail):
         try:
-            out["host_mode"] = host_mode_leg(server, cfg, qs, H)
+            return fn()
         except Exception as e:
-            out["host_mode"] = {"us_per_layer": None, "what": f"failed: {e!r}"[:300]}
+            failures.append(f"{name}: {e!r}"[:400])
+            return on_fail(f"failed: {e!r}"[:300])
+
+    if solo and shard is None and not args.no_host_mode:
+        out["host_mode"] = attempt("host_mode", lambda: host_mode_leg(server, cfg, qs, H),
+                                   lambda msg: {"us_per_layer": None, "what": msg})
+        # the same caller with ONE allocation flag changed: results_lsh_cpu / nnz pinned
+        out["host_mode_pinned_results"] = attempt("host_mode_pinned_results",
+                                                  lambda: host_mode_leg(server, cfg, qs, H, pin_results=True),
+                                                  lambda msg: {"us_per_layer": None, "what": msg})
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            cb = run_cpu_baseline(cfg, server, qs, args.cpu_steps, H, Hkv)
-            t_layer = cb["t_retrieve_us"] + cb["t_attention_us"]
-            out["cpu_baseline"] = {
-                "value": B / (NL * t_layer * 1e-6), "unit": "tokens/s", "cores": cb["cores"],
-                "kind": cb["kind"],
-                "sample": f"1 of {NL} sparse layers x {cb['steps']} decode steps, same tables/KV/queries as "
-                          f"the GPU's first sparse layer; tokens/s = B / ({NL} x t_layer); "
-                          f"OMP_PLACES={cb.get('omp_places')}, best of 2 placements",
-                "t_retrieve_us": cb["t_retrieve_us"], "t_attention_us": cb["t_attention_us"]}
-            # cross-check of the GPU result against the CPU path on the full-size layer
-            q_static.copy_(qs[0])
-            server.collect_nnz = True
-            o, lse = server.decode(q_static[0], 0)
-            torch.cuda.synchronize()
-            same_nnz = server.nnz.cpu().tolist() == cb["nnz0"]
-            dmax = float((o.float().flatten().cpu() - torch.tensor(cb["out0"])).abs().max())
-            out["cpu_baseline"]["gpu_matches"] = {"nnz_equal": same_nnz, "max_abs_out_diff": dmax}
+        out["cpu_baseline"] = attempt("cpu_baseline", lambda: w.cpu_check(args.cpu_steps, (None, "cores")),
+                                      lambda msg: {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": msg})
+        if out["cpu_baseline"].get("value"):
             out["speedup_vs_cpu"] = tokens_per_s / out["cpu_baseline"]["value"]
-        except Exception as e:  # the GPU number must still be reported
-            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
-                                   "sample": f"failed: {e!r}"[:300]}
+            if out.get("host_mode", {}).get("us_per_layer"):      # the unchanged caller against the CPU path, same layer
+                t_cpu = out["cpu_baseline"]["t_retrieve_us"] + out["cpu_baseline"]["t_attention_us"]
+                out["host_mode"]["speedup_vs_cpu_layer"] = t_cpu / out["host_mode"]["us_per_layer"]
+                if out["host_mode_pinned_results"].get("us_per_layer"):
+                    out["host_mode_pinned_results"]["speedup_vs_cpu_layer"] = t_cpu / out["host_mode_pinned_results"]["us_per_layer"]
     # ---- second workload in the same line: clustered keys + heavy-hitter queries, the README's
     # ~2 % sampling rate -- randn keys are the easiest case SimHash can see.  Same model shape, same loop, after the
     # headline region and its legs; the first workload's HBM is released first.
-    if rank == 0 and world == 1 and shard is None and args.data == "randn" and not args.no_clustered_leg:
-        try:
-            del graph
-            server = None
-            torch.cuda.empty_cache()
-            srv2, qs2, _, _ = build_workload("clustered", "auto")
-            q2 = qs2[0].clone()
-            srv2.collect_nnz = True
-            nz2 = []
-            for li in range(NL):
-                srv2.decode(q2[li], li)
-                nz2.append(srv2.nnz.clone())
-            torch.cuda.synchronize()
-            nz2 = torch.stack(nz2).float()
-            srv2.collect_nnz = False
-
-            def step2():
-                for li in range(NL):
-                    srv2.decode(q2[li], li)
-
-            g2 = None
+    w.release()
+    del server, qs, q_static
+    if solo and shard is None and args.data == "randn" and not args.no_clustered_leg:
+        def clustered():
+            w2 = Workload(mp, sharding, args, args.config, cfg, dev, rank, urank, uworld, args.shard, "clustered", "auto")
+            w2.observe()
             if not args.no_graph:
-                s2 = torch.cuda.Stream()
-                s2.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s2):
-                    step2()
-                torch.cuda.current_stream().wait_stream(s2)
-                torch.cuda.synchronize()
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2):
-                    step2()
-
-            def run2(k0, count):
-                for i in range(count):
-                    q2.copy_(qs2[(k0 + i) % NQ])
-                    if g2 is not None:
-                        g2.replay()
-                    else:
-                        step2()
-
-            run2(0, args.warmup)
+                w2.graph = w2.capture()
+            w2.run_steps(0, args.warmup)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            run2(args.warmup, args.steps)
+            w2.run_steps(args.warmup, args.steps)
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t0
-            srv2.attn_server.check()
-            out["value_clustered"] = B * args.steps / dt2
-            out["sparse_attn_us_per_layer_clustered"] = dt2 / args.steps * 1e6 / NL
-            out["observed_clustered"] = {"nnz_per_head": float(nz2.mean()), "selected_fraction": float(nz2.mean()) / n,
-                                         "nnz_max_head": float(nz2.max()), "key_distribution": "clustered",
-                                         "queries": "heavy", "steps": args.steps, "warmup": args.warmup}
-        except Exception as e:  # the headline number must still be reported
-            out["value_clustered"] = None
-            out["observed_clustered"] = {"failed": f"{e!r}"[:300]}
+            w2.server.attn_server.check()
+            res = {"value_clustered": B * args.steps / dt2,
+                   "sparse_attn_us_per_layer_clustered": dt2 / args.steps * 1e6 / NL,
+                   "observed_clustered": {"nnz_per_head": w2.nnz_mean, "selected_fraction": w2.nnz_mean / n,
+                                          "nnz_max_head": float(w2.nnz_all.max()), "key_distribution": "clustered",
+                                          "queries": "heavy", "steps": args.steps, "warmup": args.warmup}}
+            w2.release()
+            return res
+        out.update(attempt("clustered", clustered,
+                           lambda msg: {"value_clustered": None, "observed_clustered": {"failed": msg}}))
+    # ---- other CONFIGURATIONS in the same line
+    legs = [x for x in args.legs.split(",") if x]
+    if solo and shard is None and args.config == "cfg1" and args.data == "randn" and legs:
+        out["legs"] = {}
+        for name in legs:
+            if name not in CONFIGS or name == args.config:
+                continue
+            t_leg = time.time()
+            key = name + "_share" if name == "cfg4" else name
+            out["legs"][key] = attempt("leg " + name, lambda: config_leg(mp, sharding, args, name, dev),
+                                       lambda msg: {"tokens_per_s": None, "failed": msg})
+            out["legs"][key]["leg_wall_s"] = round(time.time() - t_leg, 1)
+    if failures:
+        out["failed_legs"] = failures
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if failures and not args.allow_missing_legs:
+        sys.exit("bench.py: " + "; ".join(failures))
 
 
 if __name__ == "__main__":

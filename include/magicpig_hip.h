@@ -128,6 +128,10 @@ int mp_lsh_get_mask(mp_lsh_t* h, int8_t* mask, int mem, mp_stream_t stream);
  * one query head in mp_decode_sparse_layer, chosen at alloc from B*H and the device's CU count. */
 int mp_lsh_get_tables(mp_lsh_t* h, int layer_id, void** bounds_dev, void** table_dev);
 int mp_lsh_get_ranges(mp_lsh_t* h, int* ranges, int* range_len);
+/* HBM the handle holds PER LAYER, bytes: [0] bounds, [1] table, [2] direct piece slots (0 where the handle keeps none),
+ * [3] bytes of one slot (128, 64, 32 or 0).  The reference's tables are [1] alone (lsh.cc:44-91: table + table_start /
+ * table_end); bounds with R + 1 entries and the slots are this implementation's accelerators. */
+int mp_lsh_get_footprint(mp_lsh_t* h, int64_t* bytes4);
 /* Width of the id field of the layer's table words: 17 while every token id the layer's tables hold is below 2^17
  * (any max_length), 0 (plain ids) from the first mp_lsh_fill / mp_lsh_build that brings a wider one until mp_lsh_clear.
  * Where it is 17, a table word is  token id | (payload << 17): the one-launch decode entries let the entries carry
@@ -201,6 +205,9 @@ int mp_attn_check(mp_attn_t* h, mp_stream_t stream);
 int mp_attn_get_kv(mp_attn_t* h, int layer_id, void** key_dev, void** value_dev,
                    int64_t* row_stride_elems);
 int mp_attn_get_key_norm(mp_attn_t* h, int layer_id, void** kn_dev);
+/* HBM the store holds PER LAYER, bytes: [0] the interleaved K | V rows, [1] the f32 key norms
+ * (sparse_attention.cc:546-583 allocates the same three arrays in host memory). */
+int mp_attn_get_footprint(mp_attn_t* h, int64_t* bytes2);
 /* The key-norm view above is writable (the reference's get_key_norm is a from_blob alias too,
  * sparse_attention.cc:1228-1233).  The one-launch decode entries may carry a request's norms inside its LSH table words
  * (see mp_lsh_get_id_bits): a caller that WRITES norms through the view says so here -- the request's norms get a new

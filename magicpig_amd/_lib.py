@@ -66,6 +66,8 @@ def lib() -> C.CDLL:
         "mp_lsh_get_tables": ([p, i32, pp, pp], i32),
         "mp_lsh_get_ranges": ([p, C.POINTER(i32), C.POINTER(i32)], i32),
         "mp_lsh_get_id_bits": ([p, i32, C.POINTER(i32)], i32),
+        "mp_lsh_get_footprint": ([p, C.POINTER(i64)], i32),
+        "mp_attn_get_footprint": ([p, C.POINTER(i64)], i32),
         "mp_attn_create": ([pp], i32),
         "mp_attn_destroy": ([p], i32),
         "mp_attn_alloc": ([p, i32, i32, i32, i32, i32, i32], i32),

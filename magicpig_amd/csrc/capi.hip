@@ -981,6 +981,16 @@ int mp_lsh_get_tables(mp_lsh_t* h, int layer_id, void** bounds_dev, void** table
     return MP_OK;
 }
 
+int mp_lsh_get_footprint(mp_lsh_t* h, int64_t* bytes4) {
+    MP_REQUIRE(h && h->allocated && bytes4, MP_ERR_STATE, "mp_lsh_get_footprint: not allocated / null argument");
+    const int64_t groups = (int64_t)h->B * h->Hkv;
+    bytes4[0] = groups * h->L * h->NB * (int64_t)(h->R + 1) * 4;
+    bytes4[1] = groups * h->L * h->M * 4;
+    bytes4[2] = h->slots.empty() ? 0 : groups * h->L * h->NB * (int64_t)h->R * h->slot_words * 4;
+    bytes4[3] = h->slots.empty() ? 0 : (int64_t)h->slot_words * 4;
+    return MP_OK;
+}
+
 int mp_lsh_get_ranges(mp_lsh_t* h, int* ranges, int* range_len) {
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_lsh_get_ranges: not allocated");
     if (ranges) *ranges = h->R;
@@ -1505,6 +1515,14 @@ int mp_attn_get_kv(mp_attn_t* h, int layer_id, void** key_dev, void** value_dev,
     if (key_dev) *key_dev = h->kv[layer_id];
     if (value_dev) *value_dev = h->kv[layer_id] + h->D;
     if (row_stride_elems) *row_stride_elems = 2 * (int64_t)h->D;
+    return MP_OK;
+}
+
+int mp_attn_get_footprint(mp_attn_t* h, int64_t* bytes2) {
+    MP_REQUIRE(h && h->allocated && bytes2, MP_ERR_STATE, "mp_attn_get_footprint: not allocated / null argument");
+    const int64_t groups = (int64_t)h->B * h->Hkv;
+    bytes2[0] = groups * h->M * 2 * h->D * 2;
+    bytes2[1] = groups * h->M * 4;
     return MP_OK;
 }
 

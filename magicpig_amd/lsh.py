@@ -100,6 +100,13 @@ class LSH:
         L.check(L.lib().mp_lsh_get_id_bits(self._h, layer_id, C.byref(bits)))
         return bits.value
 
+    def footprint(self) -> dict:
+        """HBM bytes per layer of the index structures (mp_lsh_get_footprint): the reference's table (lsh.cc:44-91)
+        plus this implementation's sub-bounds and direct piece slots."""
+        b = (C.c_int64 * 4)()
+        L.check(L.lib().mp_lsh_get_footprint(self._h, b))
+        return {"bounds": int(b[0]), "table": int(b[1]), "slots": int(b[2]), "slot_bytes": int(b[3])}
+
     def get_tables(self, layer_id: int, raw: bool = False):
         b, t = C.c_void_p(), C.c_void_p()
         L.check(L.lib().mp_lsh_get_tables(self._h, layer_id, C.byref(b), C.byref(t)))

@@ -176,6 +176,12 @@ class SparseAttentionServer:
         t = self._kv(layer_id, 1)
         return t.contiguous() if contiguous else t
 
+    def footprint(self) -> dict:
+        """HBM bytes per layer of the store (mp_attn_get_footprint): interleaved K | V rows and f32 key norms."""
+        b = (C.c_int64 * 2)()
+        L.check(L.lib().mp_attn_get_footprint(self._h, b))
+        return {"kv": int(b[0]), "key_norms": int(b[1])}
+
     def get_key_norm(self, layer_id: int) -> torch.Tensor:
         p = C.c_void_p()
         L.check(L.lib().mp_attn_get_key_norm(self._h, layer_id, C.byref(p)))

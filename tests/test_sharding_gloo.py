@@ -160,3 +160,63 @@ def test_bench_head_shard_two_ranks_dry_run():
     d = json.loads(lines[0])
     assert d["scaling"] == "strong" and d["heads_per_rank"] == 32 and d["gathered_shape"] == [1, 64, 128]
     assert d["gathered_checksum"] == float(sum(range(64)) * 128)          # every global head once, in place
+
+
+def _clean_env():
+    import os
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_starts_its_own_ranks_from_a_plain_start():
+    """`python bench.py --gpus 2` started PLAINLY (no launcher, no RANK / WORLD_SIZE in the
+    environment) runs two ranks -- it re-executes itself under torch.distributed.run on 127.0.0.1 -- and rank 0's line
+    says so: n_gpus 2, a process group of two, one checksum per rank.  cfg 4 on more than one rank shards the model's kv
+    heads by default (evaluations/RULER/pred/attnserver_dist.py:252-254)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1",
+                        "--dry-run"], env=_clean_env(), capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["process_group"] == "gloo x2" and d["rank_checksums"] == [1000, 1001]
+    assert d["config"]["shard"] == "batch" and d["ms_per_step"] >= 1.9
+    r4 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                         "--dry-run", "--config", "cfg4"], env=_clean_env(), capture_output=True, text=True, timeout=300,
+                        cwd=root)
+    assert r4.returncode == 0, r4.stderr[-2000:]
+    d4 = json.loads([ln for ln in r4.stdout.splitlines() if ln.startswith("{")][0])
+    assert d4["config"]["shard"] == "head" and d4["scaling"] == "strong" and d4["heads_per_rank"] == 32
+
+
+def test_bench_refuses_a_world_that_is_not_what_was_asked_for():
+    """No silent 1-GPU run under another label: more ranks asked for than GPUs visible (this container has none) ends
+    with a message and a non-zero status before anything is launched; so does a WORLD_SIZE that disagrees with --gpus."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                           env=_clean_env(), capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not r.stdout.strip()
+    env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--dry-run"], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE = 1" in r.stderr and not r.stdout.strip()
+    env = dict(_clean_env(), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE = 2" in r.stderr
