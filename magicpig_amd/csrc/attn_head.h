@@ -11,6 +11,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef MP_NT_STORES
+#define MP_NT_STORES 0     // `nt` on the by-product stores of the decode kernel (result rows, logits): A/B after R4-15
+#endif
+
 namespace mp {
 
 __device__ __forceinline__ float powi_u(float b, int e) {
@@ -265,7 +269,11 @@ __device__ __forceinline__ void attn_head_fold(
             } else {
                 z = importance_logit(sc, qn_h * kn_my, inv_sqrt_d, K, L);
             }
+#if MP_NT_STORES
+            if (score_h != nullptr && (c % DUP) == 0) __builtin_nontemporal_store(z, score_h + j_my);
+#else
             if (score_h != nullptr && (c % DUP) == 0) score_h[j_my] = z;
+#endif
         }
         const float m_w = wave_max(z);
         const float p_my = valid_my ? __expf(z - m_w) : 0.f;    // slice non-empty => m_w finite
@@ -364,6 +372,68 @@ __device__ __forceinline__ void attn_head_merge(const AhState& st, float* s_merg
         o0_out = o0;
         o1_out = o1;
     }
+}
+
+// The same meeting WITHOUT the workgroup barrier (the decode kernel, -DMP_MERGE_TICKET=1): every wave
+// leaves its state in LDS and draws an LDS ticket; the wave that draws the last one holds the merged state on return
+// (true), the others are done (false) -- the workgroup then waits for its slowest wave's rows once, in that wave, instead
+// of rows -> barrier -> wave 0's wake-up.  Ordering: a wave's LDS instructions execute in issue order, so its ticket is
+// drawn after its state is written, and the last drawer's reads follow every other wave's writes.  No fence: a
+// workgroup-scope release would also wait for the wave's outstanding score stores (vmcnt), which is what FULL avoids.
+template <int D, int NW>
+__device__ __forceinline__ bool attn_head_merge_ticket(const AhState& st, float* s_merge, int* s_ticket, float& m_out,
+                                                       float& Z_out, float& o0_out, float& o1_out) {
+    constexpr int VPL = D / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mine = s_merge + wave * (D + 2);
+    mine[st.d0] = st.o0;
+    if (D / 8 == 16) mine[st.d0 + 1] = st.o1;
+    if (lane == 0) {
+        mine[D] = st.m;
+        mine[D + 1] = st.l;
+    }
+    asm volatile("" ::: "memory");
+    int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    t = __builtin_amdgcn_readfirstlane(t);
+    asm volatile("" ::: "memory");
+    m_out = -INFINITY;
+    Z_out = 0.f;
+    o0_out = 0.f;
+    o1_out = 0.f;
+    if (t != NW - 1) return false;
+    float mw[NW], lw[NW], oa[NW], ob[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        mw[w] = s_merge[w * (D + 2) + D];
+        lw[w] = s_merge[w * (D + 2) + D + 1];
+        if (VPL == 2) {
+            const float2 tt = *reinterpret_cast<const float2*>(s_merge + w * (D + 2) + lane * 2);
+            oa[w] = tt.x;
+            ob[w] = tt.y;
+        } else {
+            oa[w] = s_merge[w * (D + 2) + lane];
+            ob[w] = 0.f;
+        }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) m = fmaxf(m, mw[w]);
+    float Z = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        if (mw[w] != -INFINITY) {                    // a wave without a slice never wrote its o[]
+            const float e = __expf(mw[w] - m);
+            Z = fmaf(e, lw[w], Z);
+            o0 = fmaf(e, oa[w], o0);
+            o1 = fmaf(e, ob[w], o1);
+        }
+    }
+    m_out = m;
+    Z_out = Z;
+    o0_out = o0;
+    o1_out = o1;
+    return true;
 }
 
 // fold the slices of ONE sparse list, then merge (attn_head_kernel)

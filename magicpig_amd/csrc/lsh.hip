@@ -86,6 +86,15 @@ hipError_t set_stamp_stride(int stride) {
 constexpr int RT_THREADS = MP_RT_THREADS;  // 16 waves: one workgroup per query head (A/B builds: 512, two per CU)
 constexpr int RT_WAVES = RT_THREADS / 64;
 constexpr int RT_GROUP = 12;               // buckets in flight per wave per round (x 2 chunks of 64 ids)
+#ifndef MP_MERGE_TICKET
+#define MP_MERGE_TICKET 0                  // the waves' states meet behind an LDS ticket instead of a workgroup barrier (A/B)
+#endif
+#ifndef MP_SETPRIO_WAVE0
+#define MP_SETPRIO_WAVE0 0                 // s_setprio 3 on wave 0 while it normalises the query row (A/B)
+#endif
+#ifndef MP_STREAM_ONE_TRIP
+#define MP_STREAM_ONE_TRIP 1               // sub-bounds path: every load of a wave's pieces in ONE round trip (A/B: -DMP_STREAM_ONE_TRIP=0)
+#endif
 // Table-side loads -- direct slots, bucket records, table ids: every line of them is read once per launch, by one CU -- are
 // non-temporal (`nt`: no claim on the L2 the K / V rows and the hyperplanes live in).  Round 4, same instruction schedule with
 // and without the bit on these 121 loads: cfg 3 29.77 -> 29.13 us per layer, cfg 1 and cfg 4 within +-0.1 (EXPERIMENTS.md R4-15).
@@ -649,6 +658,7 @@ __device__ __forceinline__ void lsh_head_body(
     if (padding_block) return;
     if (tid == 0) {
         *s_ntail = 0;
+        if (AD > 0) s_tk[0] = 0;                                  // (MP_MERGE_TICKET: the waves' LDS ticket)
         s_tmp[30] = 0;                                            // pieces that overflow their direct slot
         s_tmp[29] = 1;                                            // split hash: every word of the head arrived
     }
@@ -716,6 +726,9 @@ __device__ __forceinline__ void lsh_head_body(
         const float wn_first = ha.wnorm[col_first < ha.KLpad ? col_first : ha.KLpad - 1];
         // -- normalise the query row
         if (wave == 0) {
+#if MP_SETPRIO_WAVE0
+            __builtin_amdgcn_s_setprio(3);     // the one wave everybody waits for: ahead of its 15 siblings at the issue ports
+#endif
             const uint16_t e[4] = {(uint16_t)(e01 & 0xffffu), (uint16_t)(e01 >> 16),
                                    (uint16_t)(e23 & 0xffffu), (uint16_t)(e23 >> 16)};
             // The definition (what torch computes on bf16 tensors, pinned by the qhash_* fixtures): nrm = f32 sqrt of the
@@ -784,6 +797,9 @@ __device__ __forceinline__ void lsh_head_body(
                 s_rn[1] = nrm;
             }
             MP_STAMP(stamp, 29);                               // normalised row written to LDS
+#if MP_SETPRIO_WAVE0
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         __syncthreads();
         MP_STAMP(stamp, 22);
@@ -932,6 +948,7 @@ __device__ __forceinline__ void lsh_head_body(
         idmask = idbits ? ((1u << idbits) - 1u) : 0xffffffffu;
     }
     const int32_t* slots = (AD > 0) ? aa.slots : nullptr;
+    bool tail_first_done = false;   // uniform: the pool's first round went out with the pieces' own loads (sub-bounds path)
     if (AD > 0 && HASH != 0 && slots != nullptr) {
         // ---- DIRECT pieces: the piece (table l, bucket code, range rank) has a 128-byte slot holding its length,
         // position and first 30 ids, so ONE dependent round trip (hash -> slot) replaces two (hash -> sub-bounds ->
@@ -1106,14 +1123,87 @@ __device__ __forceinline__ void lsh_head_body(
     MP_STAMP(stamp, 17);
     MP_STAMP(stamp, 18);
 
-    // stream the probed pieces: wave w owns tables w, w+16, ...; per round it keeps RT_GROUP pieces x 64 ids in
-    // flight (the second 64 ids of a piece only where that piece is longer), then applies them.  Straight-line
-    // rounds: all (start, length) pairs out of LDS, then all loads -- unconditional: a lane past its piece re-reads
-    // the piece's first id (same cache line as its neighbours: no extra request) and applies nothing -- then all
+    // stream the probed pieces: wave w owns tables w, w+16, ...; per round it keeps RT_GROUP pieces x 2 chunks of 64 ids in
+    // flight, then applies them.  Straight-line rounds: all (start, length) pairs out of LDS, then all loads, then all
     // applies.  As one loop body per piece with the loads under lane-divergent branches the compiler put an
     // s_waitcnt vmcnt(0) between the pieces: two, not twelve, were in flight.
+    // Round 5 -- ONE round trip for the whole stream (MP_STREAM_ONE_TRIP).  Until round 4 the second 64 ids of a piece were
+    // requested only behind the first chunks' applies, and the pooled chunks (ids beyond 128) behind those: SimHash buckets
+    // are wide (p99 of a probed piece = 2.3 x its mean; mean 32 ids at cfg 2 / 3), so ~4 % of the pieces are longer than 64
+    // ids, almost every workgroup holds a wave with such a piece, one in six a pooled chunk -- and the launch waits for the
+    // workgroup that paid THREE dependent round trips between "pieces in" and "counted" (the 4.4 us of VERDICT r04 weak 4).
+    // Now every load of a wave's pieces -- both chunks and its share of the pool's first round -- is issued before anything
+    // is applied.  The loads go through ONE buffer descriptor over the KV group's table rows: a lane past its piece gets
+    // an offset beyond num_records, for which the hardware returns 0 WITHOUT a memory request -- the second-chunk loads
+    // of the 96 % short pieces cost an instruction slot and no line (clamped addresses, the form used where a pointer is
+    // needed, would re-request the piece's first line 12 times per wave).
     {
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+#if MP_STREAM_ONE_TRIP
+    const uint64_t tab_bytes = (uint64_t)L * (uint64_t)M * 4ull;
+    if (tab_bytes < (1ull << 32)) {                                          // uniform: 32-bit offsets cover the group's rows
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(tab), 0,
+                                                                            (int)(uint32_t)tab_bytes, 0x00020000);
+        constexpr int kNt = 2;                                               // aux bit 1 = nt on gfx940+
+        constexpr uint32_t kOut = 0xfffffff0u;                               // beyond any num_records: no request, returns 0
+        const int ntail0 = __builtin_amdgcn_readfirstlane(*s_ntail);
+        for (int l0 = wave_s; l0 < L; l0 += RT_WAVES * RT_GROUP) {
+            int32_t id0[RT_GROUP], id1[RT_GROUP], idt[RT_TAIL_UNROLL];
+            int ln[RT_GROUP];
+            uint32_t wb[RT_GROUP];
+#pragma unroll
+            for (int b = 0; b < RT_GROUP; ++b) {
+                const int l = l0 + b * RT_WAVES;
+                const int lc = l < L ? l : L - 1;
+                ln[b] = s_len[lc];
+                wb[b] = (uint32_t)s_start[lc];
+            }
+#pragma unroll
+            for (int b = 0; b < RT_GROUP; ++b) {
+                const int l = l0 + b * RT_WAVES;
+                const int lc = l < L ? l : L - 1;
+                ln[b] = l < L ? __builtin_amdgcn_readfirstlane(ln[b]) : 0;   // wave-uniform: one table per wave
+                wb[b] = (uint32_t)lc * (uint32_t)M + (uint32_t)__builtin_amdgcn_readfirstlane((int)wb[b]);
+                id0[b] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                    rt, lane < ln[b] ? (wb[b] + (uint32_t)lane) << 2 : kOut, 0, kNt);
+            }
+#pragma unroll
+            for (int b = 0; b < RT_GROUP; ++b)
+                id1[b] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                    rt, lane + 64 < ln[b] ? (wb[b] + (uint32_t)lane + 64u) << 2 : kOut, 0, kNt);
+            // the pool's first round rides along (this wave's chunks wave, wave + 16, ...): descriptors out of LDS
+            const bool tails_now = l0 == wave_s && ntail0 > 0 && ntail0 <= RT_TAIL_CAP;   // uniform
+            uint32_t tin = 0u;                                               // per lane: bit u = chunk u holds an id for it
+            if (tails_now) {
+#pragma unroll
+                for (int u = 0; u < RT_TAIL_UNROLL; ++u) {
+                    const int c = wave_s + u * RT_WAVES;
+                    const uint32_t d = s_tail[c < ntail0 ? c : 0];
+                    const int l = (int)(d >> 16), j = (int)((d & 0xffffu) << 6) + lane;
+                    const bool in = c < ntail0 && j < s_len[l];
+                    idt[u] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                        rt, in ? ((uint32_t)l * (uint32_t)M + (uint32_t)s_start[l] + (uint32_t)j) << 2 : kOut, 0, kNt);
+                    tin |= (in ? 1u : 0u) << u;      // (not written into idt[u] here: that would wait for the load)
+                }
+                tail_first_done = true;
+            }
+            // applied in issue order: the first piece's ids are counted while the last piece's are still on their way
+#pragma unroll
+            for (int b = 0; b < RT_GROUP; ++b) apply(lane < ln[b] ? id0[b] : -1);
+            bool longer = false;
+#pragma unroll
+            for (int b = 0; b < RT_GROUP; ++b) longer = longer || ln[b] > 64;
+            if (longer) {                                                    // wave-uniform (the loads are out already)
+#pragma unroll
+                for (int b = 0; b < RT_GROUP; ++b) apply(lane + 64 < ln[b] ? id1[b] : -1);
+            }
+            if (tails_now) {
+#pragma unroll
+                for (int u = 0; u < RT_TAIL_UNROLL; ++u) apply((tin >> u) & 1u ? idt[u] : -1);
+            }
+        }
+    } else
+#endif
     for (int l0 = wave_s; l0 < L; l0 += RT_WAVES * RT_GROUP) {
         int32_t id0[RT_GROUP], id1[RT_GROUP];
         int ln[RT_GROUP], sa[RT_GROUP];
@@ -1157,7 +1247,8 @@ __device__ __forceinline__ void lsh_head_body(
     // round-robin with RT_TAIL_UNROLL loads in flight
     const int ntail = __builtin_amdgcn_readfirstlane(*s_ntail);
     if (ntail <= RT_TAIL_CAP) {
-        for (int c0 = wave; c0 < ntail; c0 += RT_WAVES * RT_TAIL_UNROLL) {
+        // (sub-bounds path, one-trip stream: the first round of the pool went out with the pieces' own loads)
+        for (int c0 = wave + (tail_first_done ? RT_WAVES * RT_TAIL_UNROLL : 0); c0 < ntail; c0 += RT_WAVES * RT_TAIL_UNROLL) {
             int32_t idt[RT_TAIL_UNROLL];
 #pragma unroll
             for (int u = 0; u < RT_TAIL_UNROLL; ++u) {
@@ -1209,7 +1300,11 @@ __device__ __forceinline__ void lsh_head_body(
         while (bits) {
             const int p = __ffs((int)bits) - 1;
             bits &= bits - 1;
+#if MP_NT_STORES
+            __builtin_nontemporal_store((int32_t)(base + p), out + off);
+#else
             out[off] = base + p;
+#endif
             if (AD > 0 && off < aa.cap) s_ids[off] = base + p;
             if (AD == 0 && out2 != nullptr) {
                 out2[off] = base + p;
@@ -1293,11 +1388,16 @@ __device__ __forceinline__ void lsh_head_body(
         attn_head_fold<ADD, RT_WAVES, true, AH_SLICE>(st, aa.win_kv + g * aa.win_M * 2 * ADD, nullptr, qv, 1.f, wlen,
                                                       aa.win_M, 0, 0, rank, 1 << clog, none, nullptr, stamp);
     }
+#if MP_MERGE_TICKET
+    // (A/B: no workgroup barrier -- the wave that draws the last LDS ticket merges and goes on to the hand-off)
+    if (!attn_head_merge_ticket<ADD, RT_WAVES>(st, s_merge, s_tk, m, Z, o0, o1)) return;
+#else
     attn_head_merge<ADD, RT_WAVES, true>(st, s_merge, m, Z, o0, o1);
     MP_STAMP(stamp, 40);   // the waves' states have met in LDS (the barrier waits for the wave whose rows came last)
     // from here on WAVE 0 alone holds the workgroup's state: one wave needs no workgroup barrier to order its
     // own stores, ticket and loads, and the other fifteen are done
     if (wave != 0) return;
+#endif
     if (clog == 0) {
         attn_head_finalize<ADD>(m, Z, o0, o1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
         MP_STAMP(stamp, 39);
