@@ -164,7 +164,7 @@ def parse():
     ap.add_argument("--no-direct-slots", action="store_true", help="A/B: sub-bounds + ids instead of direct piece slots")
     ap.add_argument("--split-hash", type=int, default=-1, choices=[-1, 0, 1],
                     help="A/B: hyperplanes split over the workgroups of a head's cluster (0 never, 1 always; default: auto)")
-    ap.add_argument("--direct-slots", type=int, default=-1, choices=[-1, 0, 1],
+    ap.add_argument("--direct-slots", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="A/B: direct piece slots: 0 never, 1 always (where R > 1); default: auto")
     ap.add_argument("--kn-payload", type=int, default=-1, choices=[-1, 0, 1],
                     help="A/B: key norms as a payload of the table entries (default: the library's choice)")
@@ -340,21 +340,30 @@ def host_mode_leg(server, cfg, qs, H, reps=40, pin_results=False):
 
     NQ = qs.shape[0]
 
+    per_rep = []
+
     def timed():
         for i in range(4):
             host_layer(qs[i % NQ, 0])
         t0 = time.perf_counter()
         for i in range(reps):
+            t1 = time.perf_counter()
             host_layer(qs[i % NQ, 0])
+            per_rep.append((time.perf_counter() - t1) * 1e6)
         return (time.perf_counter() - t0) / reps * 1e6
 
+    for name in ("host_fast_hits", "host_fast_edited", "host_fast_unpaired"):
+        L.set_option(name, 0)
     us = timed()
+    served = {name[len("host_fast_"):]: L.get_option(name) for name in ("host_fast_hits", "host_fast_edited", "host_fast_unpaired")}
     host_layer(qs[(reps - 1) % NQ, 0])
     server.collect_nnz = True
     server.decode(qs[(reps - 1) % NQ, 0], 0)
     torch.cuda.synchronize()
     same = bool(torch.equal(server.nnz.cpu(), nnz)) and float((server.output.float().cpu() - output.float()).abs().max()) < 2e-2
     return {"us_per_layer": us, "matches_device_entry": same, "reps": reps,
+            "median_us": float(np.median(per_rep)), "max_us": float(np.max(per_rep)),
+            "attention_calls_served": served,      # hits = the rows just handed out were recognised (no index upload)
             "what": "models/attnserver.py:264-303 unchanged: GPU q-hash, pinned codes/query/output, "
                     + ("results/nnz allocated with pin_memory=True (the one flag INTEGRATION.md 1 recommends), "
                        if pin_results else "pageable results/nnz, ")

@@ -258,6 +258,9 @@ int mp_debug_xcd_round_robin(void);
  *                        the copy engine (the fallback, kept under test)
  *   "host_flag_wait"     1 = MP_MEM_HOST calls wait for their launches by spinning on a word a one-thread kernel writes
  *                        to pinned memory instead of hipStreamSynchronize (A/B; measured no gain over the whole layer)
+ *   "host_fast_hits" / "host_fast_edited" / "host_fast_unpaired"   COUNTERS (get to read, set 0 to reset): MP_MEM_HOST
+ *                        mp_attn_sparse calls that recognised the rows mp_lsh_batch_retrieve had just handed out (no index
+ *                        upload) / found the pairing but a row edited (launch dropped, rows uploaded) / found no pairing
  *   "simhash_exact_norm" 1 = the fused query hash normalises the row by the exact f64 sequence always (A/B, tests);
  *                        0 (default) = a fast f32 form with the exact sequence as its fallback: identical codes
  *   "decode_cluster"     0 = auto, else workgroups per query head of the one-launch decode (1 .. 32); read by mp_lsh_alloc

@@ -104,6 +104,11 @@ struct DebugOptions {
     std::atomic<int> host_zero_copy{1};      // MP_MEM_HOST calls: 1 = kernels work on pinned memory in place (the caller's, or the handle's mirror), 0 = staged copies
     std::atomic<int> host_flag_wait{0};      // MP_MEM_HOST calls: 1 = wait for the stream by spinning on a word a one-thread kernel
                                              // writes to pinned memory instead of hipStreamSynchronize (A/B, EXPERIMENTS.md R4-5)
+    // counters (read with mp_debug_get_option, reset with mp_debug_set_option(name, 0)): how the MP_MEM_HOST attention
+    // entry served its calls -- a fast path that silently stops hitting shows here (fallbacks must be observable)
+    std::atomic<int> host_fast_hits{0};      // the rows batch_retrieve had just handed out were recognised: no index upload
+    std::atomic<int> host_fast_edited{0};    // pairing found, but a row differed from what was handed out: launch dropped, upload path
+    std::atomic<int> host_fast_unpaired{0};  // no pairing (other buffers, other counts, another handle in between): upload path
 };
 static DebugOptions g_opt;
 
@@ -121,6 +126,9 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "decode_kn_payload")) return &g_opt.decode_kn_payload;
     if (!strcmp(name, "host_zero_copy")) return &g_opt.host_zero_copy;
     if (!strcmp(name, "host_flag_wait")) return &g_opt.host_flag_wait;
+    if (!strcmp(name, "host_fast_hits")) return &g_opt.host_fast_hits;
+    if (!strcmp(name, "host_fast_edited")) return &g_opt.host_fast_edited;
+    if (!strcmp(name, "host_fast_unpaired")) return &g_opt.host_fast_unpaired;
     return nullptr;
 }
 
@@ -620,7 +628,8 @@ int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_he
             direct = false;
     }
     if (const int o = g_opt.decode_direct.load(); o >= 0)                                  // A/B switch, read at alloc
-        direct = h->R > 1 && o != 0 && (double)L * h->NB * h->R * (double)h->slot_words < 2147483648.0;
+        direct = o != 0 && (h->R > 1 || o == 2) &&     // 2: also at R = 1 (round 5 experiment: one workgroup per head)
+                 (double)L * h->NB * h->R * (double)h->slot_words < 2147483648.0;
     int rc = MP_OK;
     for (int i = 0; i < num_layers && rc == MP_OK; ++i) {
         void* b = nullptr; void* t = nullptr; void* sl = nullptr;
@@ -1357,12 +1366,16 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
             }
             if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) return rc;
             if (same) {
+                g_opt.host_fast_hits.fetch_add(1, std::memory_order_relaxed);
                 h->lastz_host.assign(nnz, nnz + BH);
                 h->lastz = nullptr;
                 memcpy(output, hp + o_out, (size_t)BH * h->D * 2);
                 memcpy(mve, hp + o_mve, (size_t)2 * BH * 4);
                 return MP_OK;
             }
+            g_opt.host_fast_edited.fetch_add(1, std::memory_order_relaxed);
+        } else {
+            g_opt.host_fast_unpaired.fetch_add(1, std::memory_order_relaxed);
         }
     }
     // Zero copy: ONE launch brings (q | qn | nnz) and the first nnz[h] entries of every index row into HBM with

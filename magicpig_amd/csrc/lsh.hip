@@ -87,7 +87,9 @@ constexpr int RT_THREADS = MP_RT_THREADS;  // 16 waves: one workgroup per query 
 constexpr int RT_WAVES = RT_THREADS / 64;
 constexpr int RT_GROUP = 12;               // buckets in flight per wave per round (x 2 chunks of 64 ids)
 #ifndef MP_MERGE_TICKET
-#define MP_MERGE_TICKET 0                  // the waves' states meet behind an LDS ticket instead of a workgroup barrier (A/B)
+#define MP_MERGE_TICKET 1                  // the waves' states meet behind an LDS ticket instead of a workgroup barrier (round 5:
+                                           // -0.07 us per layer at cfg 1 / cfg 4, -0.45 at cfg 0, -0.03 at cfg 3; A/B: -DMP_MERGE_TICKET=0,
+                                           // which the stamp build uses -- its "states met" stamp belongs to wave 0)
 #endif
 #ifndef MP_SETPRIO_WAVE0
 #define MP_SETPRIO_WAVE0 0                 // s_setprio 3 on wave 0 while it normalises the query row (A/B)
@@ -1389,7 +1391,8 @@ __device__ __forceinline__ void lsh_head_body(
                                                       aa.win_M, 0, 0, rank, 1 << clog, none, nullptr, stamp);
     }
 #if MP_MERGE_TICKET
-    // (A/B: no workgroup barrier -- the wave that draws the last LDS ticket merges and goes on to the hand-off)
+    // no workgroup barrier: the wave that draws the last LDS ticket merges and goes on to the hand-off -- ONE wave from
+    // here on, whichever it is (round 5; EXPERIMENTS.md R5-2)
     if (!attn_head_merge_ticket<ADD, RT_WAVES>(st, s_merge, s_tk, m, Z, o0, o1)) return;
 #else
     attn_head_merge<ADD, RT_WAVES, true>(st, s_merge, m, Z, o0, o1);
@@ -1706,7 +1709,7 @@ int lsh_slot_log2(int64_t M, int NB, int R) {
 
 hipError_t launch_lsh_slots(const int32_t* table, const int32_t* bounds, int32_t* slots, int rows, int NB, int R,
                             int64_t M, hipStream_t st) {
-    if (R <= 1 || slots == nullptr) return hipSuccess;
+    if (slots == nullptr) return hipSuccess;          // (R = 1 with slots: the decode_direct = 2 experiment)
     int gx = (NB * R + 31) / 32;
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(lsh_slots_kernel, dim3(gx, rows), dim3(256), 0, st, table, bounds, slots, NB, R, M,

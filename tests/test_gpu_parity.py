@@ -438,6 +438,7 @@ def test_host_fast_path_after_a_replayed_decode_and_checksum_neutral_edits(mp, p
     d_mve = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
     srv.attention_wrapper(0, K, L, d_out, d_mve, q, qn, d_res, d_nnz)
     want_out, want_mve = d_out.cpu(), d_mve.cpu()
+    want_probs = srv.get_score().reshape(BH, M).clone()
     # a captured decode step of the other queries
     g_out = torch.zeros((BH, D), dtype=torch.bfloat16, device="cuda")
     g_mve = torch.zeros((2, BH), dtype=torch.float32, device="cuda")
@@ -477,10 +478,20 @@ def test_host_fast_path_after_a_replayed_decode_and_checksum_neutral_edits(mp, p
     e_res = d_res.clone()
     e_res[r, :z] = h_res[r, :z].cuda()
     srv.attention_wrapper(0, K, L, d_out, d_mve, q, qn, e_res, d_nnz)
-    assert not torch.equal(d_out.cpu(), want_out)
+    # (three tokens of a few hundred: the bf16 output may not move; the probabilities of the three positions do)
+    e_probs = srv.get_score().reshape(BH, M)[r, :z].clone()
+    assert not torch.equal(e_probs[j:j + 3], want_probs[r, j:j + 3])
+    for name in ("host_fast_hits", "host_fast_edited", "host_fast_unpaired"):
+        L_.set_option(name, 0)
     h_out, h_mve = mk(torch.zeros((BH, D), dtype=torch.bfloat16)), mk(torch.zeros((2, BH), dtype=torch.float32))
     srv.attention_wrapper(0, K, L, h_out, h_mve, mk(q.cpu()), qn.cpu(), h_res, h_nnz)
     assert torch.equal(h_out, d_out.cpu()) and torch.equal(h_mve, d_mve.cpu())
+    assert torch.equal(srv.get_score().reshape(BH, M)[r, :z], e_probs)           # the EDITED rows were attended over
+    assert (L_.get_option("host_fast_hits"), L_.get_option("host_fast_edited")) == (0, 1)
+    # and the unedited rows of a fresh retrieve take the fast path again (pinned: the checksums agree; pageable: memcmp)
+    lsh.batch_retrieve(0, mk(codes.cpu()), h_res, h_nnz)
+    srv.attention_wrapper(0, K, L, h_out, h_mve, mk(q.cpu()), qn.cpu(), h_res, h_nnz)
+    assert torch.equal(h_out, want_out) and L_.get_option("host_fast_hits") == 1
     del graph
 
 
