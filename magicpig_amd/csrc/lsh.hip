@@ -419,19 +419,57 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
             }
         }
         __syncthreads();
-        if (kn == nullptr) {
-            for (int p = tid; p < tile_count; p += blockDim.x) dst[p + s_gdelta[s_b[p]]] = s_id[p];
-        } else {
-            const float* knr = kn + (row / L) * M;               // a tile's 8 192 norms: 32 KB, read once per table row
+        // Written out by position, TPL entries per thread, in straight-line batches of 8 (round 5): all stage reads, then all
+        // norm gathers, then all stores.  As a rolled loop (the trip count is tile_count / blockDim) every entry was a
+        // dependent chain of its own -- LDS read -> L2 gather of the norm -> store -- and a tile paid TPL of them in turn.
+        if constexpr (TPL >= 32) {        // (K = 12, 13: 32 codes per lane live in registers -- the rolled form, no batch arrays)
+            const float* knr = kn ? kn + (row / L) * M : nullptr;
             bool refused = false;
             for (int p = tid; p < tile_count; p += blockDim.x) {
                 const int id = s_id[p];
-                uint32_t u = __float_as_uint(knr[id]);
+                uint32_t u = knr ? __float_as_uint(knr[id]) : 0u;
                 if ((u & 0x8000ffffu) != 0u || (u & 0x7f800000u) == 0x7f800000u) {   // not bf16, negative, inf / nan
                     refused = true;
                     u = 0u;
                 }
-                dst[p + s_gdelta[s_b[p]]] = (int32_t)((uint32_t)id | ((u >> 16) << idbits));
+                dst[p + s_gdelta[s_b[p]]] = knr ? (int32_t)((uint32_t)id | ((u >> 16) << idbits)) : id;
+            }
+            if (refused) atomicOr(bad + row / L, 1);
+        } else {
+            constexpr int OB = 8;                                // entries per batch (TPL is 8 or 16)
+            const float* knr = kn ? kn + (row / L) * M : nullptr;    // a tile's 8 192 norms: 32 KB, read once per table row
+            bool refused = false;
+#pragma unroll
+            for (int j0 = 0; j0 < TPL; j0 += OB) {
+                if (tid + j0 * (int)blockDim.x >= tile_count) break;     // (not uniform: the usual per-lane exit)
+                int idv[OB], pos[OB];
+#pragma unroll
+                for (int j = 0; j < OB; ++j) {
+                    const int p = tid + (j0 + j) * (int)blockDim.x;
+                    const int pc = p < tile_count ? p : tid;            // (tid < tile_count here: a valid entry)
+                    idv[j] = s_id[pc];
+                    pos[j] = pc + s_gdelta[s_b[pc]];
+                }
+                if (kn == nullptr) {
+#pragma unroll
+                    for (int j = 0; j < OB; ++j)
+                        if (tid + (j0 + j) * (int)blockDim.x < tile_count) dst[pos[j]] = idv[j];
+                } else {
+                    uint32_t nu[OB];
+#pragma unroll
+                    for (int j = 0; j < OB; ++j) nu[j] = __float_as_uint(knr[idv[j]]);
+#pragma unroll
+                    for (int j = 0; j < OB; ++j) {
+                        if (tid + (j0 + j) * (int)blockDim.x < tile_count) {
+                            uint32_t u = nu[j];
+                            if ((u & 0x8000ffffu) != 0u || (u & 0x7f800000u) == 0x7f800000u) {   // not bf16, negative, inf / nan
+                                refused = true;
+                                u = 0u;
+                            }
+                            dst[pos[j]] = (int32_t)((uint32_t)idv[j] | ((u >> 16) << idbits));
+                        }
+                    }
+                }
             }
             if (refused) atomicOr(bad + row / L, 1);
         }

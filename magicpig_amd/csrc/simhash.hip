@@ -237,14 +237,22 @@ __global__ __launch_bounds__(1024) void simhash_query_kernel(
 //     barrier): they are queued in LDS and resolved together at the end, one 16-lane group per
 //     candidate (exact f64 dot product of the row and the plane, both re-read from L2), patching
 //     the bit matrix before the codes are cut out.
-// What bounds it is VALU issue, not the matrix pipe: ~200 vector instructions per wave and tile
-// against 8 MFMAs, which is why the epilogue is written the way it is.
-constexpr int SK_CH_MAX = 32;             // 32-row tiles per workgroup: chosen per launch (keys_chunk_tiles)
+// What bounds it is VALU issue and the per-tile barrier, not the matrix pipe (round 4: ~150 vector instructions per wave
+// and 32-row tile against 8 MFMAs, one barrier per tile: 19 % of the dense bf16 peak).  Round 5:
+//   * the product is taken TRANSPOSED -- C' = W X^T: lane <-> row of X, accumulator register <-> plane -- so a lane holds
+//     16 sign bits of ITS OWN row: they are packed per lane (one v_alignbit per accumulator, a byte permute, one
+//     v_permlane32_swap to join the two half-waves) instead of 16 ballots + 32 v_writelane transposing through SGPRs;
+//   * the guard band is tested against the lane's own row norm, not the tile's largest;
+//   * a phase stages and multiplies TWO 32-row tiles: one barrier, one pass of address arithmetic and one round of LDS
+//     traffic per 16 MFMAs instead of 8, two independent accumulator chains interleaved on the matrix pipe;
+//   * the rows' sums of squares come from v_dot2c (4 instructions per 16-byte chunk instead of 8 converts + 8 FMAs).
+constexpr int SK_CH_MAX = 32;             // 32-row tiles per workgroup: chosen per launch (keys_chunk_tiles), even
 constexpr int SK_QCAP = 1024;             // deferred exact-sign candidates per workgroup
 
 constexpr int SK_WAVES = 8;               // waves per workgroup: two workgroups fill the 16 wave slots
                                           // a CU has at 128 VGPRs (5-wave blocks left 6 of them empty)
 constexpr int SK_MAX_TABLES = 32;
+constexpr int SK_PT = 2;                  // 32-row tiles per phase (one barrier per phase)
 
 template <int D>
 __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void simhash_keys_kernel(
@@ -258,12 +266,14 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
     constexpr int KSTEPS = D / 16;
     constexpr int STRIDE = D + 8;
     constexpr int CPR = D / 8;            // 16-byte chunks per row
-    constexpr int NCH = SH_ROWS * CPR;    // chunks per 32-row tile
+    constexpr int PROWS = SH_ROWS * SK_PT;   // rows staged per phase
+    constexpr int NCH = PROWS * CPR;      // chunks per phase
     constexpr int NTHR = 64 * SK_WAVES;
     constexpr int QN = (NCH + NTHR - 1) / NTHR;   // chunks per thread
     const int CROWS = chunk_tiles * SH_ROWS;
-    __shared__ __attribute__((aligned(16))) uint16_t s_x[2][SH_ROWS * STRIDE];
-    __shared__ float s_rn[2][SH_ROWS];
+    __shared__ __attribute__((aligned(16))) uint16_t s_x[2][PROWS * STRIDE];
+    __shared__ float s_rn[2][PROWS];
+    __shared__ float s_wn[SK_WAVES][32];  // guard-band half-widths of the wave's 32 planes (-1: not this workgroup's)
     constexpr int BW = SK_WAVES + 1;      // words of the sign matrix per row: one per wave + one of slack
     __shared__ uint32_t s_queue[SK_QCAP];
     __shared__ int s_qn;
@@ -295,41 +305,41 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
     const bool has_tile = wave < tiles_per_wg;
     const int ncol = col0 + wave * 32 + (lane & 31);
     bf16x8 bfrag[KSTEPS];
-    float wn = -1.f;
+    float wcoarse = -1.f;                                 // uniform: the widest guard band among the wave's planes
     if (has_tile) {
         const uint16_t* wrow = Wt + (int64_t)ncol * D + (lane >> 5) * 8;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) bfrag[kk] = *reinterpret_cast<const bf16x8*>(wrow + kk * 16);
         // planes past this workgroup's tables (the tail of its last tile) belong to the next one
-        wn = (ncol < KL && ncol - col0 < tables_per_wg * K) ? wnorm[ncol] * SH_EPS : -1.f;
+        const float wn = (ncol < KL && ncol - col0 < tables_per_wg * K) ? wnorm[ncol] * SH_EPS : -1.f;
+        if (lane < 32) s_wn[wave][lane] = wn;
+        const float w16 = row16_max_nonneg(fmaxf(wn, 0.f));
+        wcoarse = __int_as_float(max(__builtin_amdgcn_readlane(__float_as_int(w16), 0),
+                                     __builtin_amdgcn_readlane(__float_as_int(w16), 16)));
     }
 
-    // Loads are unconditional (addresses clamped to the last row / last chunk): a load under a branch
-    // is followed by s_waitcnt vmcnt(0) at the join, which would serialise the prefetch.  Rows past n
-    // and chunks past NCH compute on duplicates whose results are never stored.
-    auto tile_load = [&](int t, u32x4 (&st)[QN]) {
+    // Loads are unconditional (row index clamped to the last row): a load under a branch is followed by
+    // s_waitcnt vmcnt(0) at the join, which would serialise the prefetch.  Rows past n compute on duplicates
+    // whose results are never stored.  Thread tid takes chunk tid % CPR of rows tid / CPR + q * (nthr / CPR).
+    static_assert(NCH % NTHR == 0, "a phase's chunks divide over the threads");
+    const int64_t last_row = n - 1;
+    const uint16_t* xcol = x + (tid % CPR) * 8;
+    auto tile_load = [&](int ph, u32x4 (&st)[QN]) {
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
-            int c = tid + q * nthr;
-            c = c < NCH ? c : NCH - 1;
-            int64_t gr = row_base + (int64_t)t * SH_ROWS + c / CPR;
-            gr = gr < n ? gr : n - 1;
-            st[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + gr * row_stride + (c % CPR) * 8));
+            int64_t gr = row_base + (int64_t)ph * PROWS + (tid / CPR) + q * (NTHR / CPR);
+            gr = gr < last_row ? gr : last_row;
+            st[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xcol + gr * row_stride));
         }
     };
     auto tile_store = [&](int buf, const u32x4 (&st)[QN]) {
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
-            const int c = tid + q * nthr;
+            const int row = (tid / CPR) + q * (NTHR / CPR);
+            *reinterpret_cast<u32x4*>(&s_x[buf][row * STRIDE + (tid % CPR) * 8]) = st[q];
             float ss = 0.f;
-            if (c < NCH) {
-                *reinterpret_cast<u32x4*>(&s_x[buf][(c / CPR) * STRIDE + (c % CPR) * 8]) = st[q];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float lo = bf16_lo(st[q][j]), hi = bf16_hi(st[q][j]);
-                    ss = fmaf(lo, lo, fmaf(hi, hi, ss));
-                }
-            }
+            dot8_bf16_chain(ss, st[q], st[q]);            // sum of squares of the chunk's 8 elements
+            dot_settle(ss);
             // the CPR chunks of a row sit in CPR consecutive lanes (nthr is a multiple of 64)
             if (CPR == 16) ss = row16_sum(ss);
             else if (CPR == 32) { ss = row16_sum(ss); ss += __shfl_xor(ss, 16); }
@@ -337,67 +347,61 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
                 for (int sft = 1; sft < CPR; sft <<= 1) ss += __shfl_xor(ss, sft);
             }
-            if (c < NCH && (c % CPR) == 0)     // upper bound of ||row|| (v_sqrt_f32 is good to 1 ulp)
-                s_rn[buf][c / CPR] = __builtin_amdgcn_sqrtf(ss) * 1.0001f;
+            if ((tid % CPR) == 0)              // upper bound of ||row|| (v_sqrt_f32 is good to 1 ulp)
+                s_rn[buf][row] = __builtin_amdgcn_sqrtf(ss) * 1.0001f;
         }
     };
-    // The epilogue of a tile is what the kernel is bound by (VALU issue, not the matrix pipe), so
-    // it is kept to ~70 instructions per wave: 16 compares give the 32x32 sign matrix in SGPR pairs,
-    // v_writelane moves dword r of it into lane r for ONE LDS store, and the guard band is tested on
-    // min_i |acc_i| against the largest row norm of the tile; only lanes that fail that coarse test
-    // look at their 16 values one by one.
-    auto compute = [&](int t) {                           // MFMA + signs of tile t (LDS half t&1)
+    // MFMA + signs of the phase's tiles (LDS half ph & 1).  C' = W X^T: lane l holds, for row (l & 31) of the
+    // tile, the 16 planes (i & 3) + 8 (i >> 2) + 4 (l >> 5), i = 0 .. 15, of the wave's 32.
+    auto compute = [&](int ph) {
         if (!has_tile) return;
-        const int buf = t & 1;
-        const uint16_t* arow = &s_x[buf][(lane & 31) * STRIDE + (lane >> 5) * 8];
-        f32x16 acc;
+        const int buf = ph & 1;
+        f32x16 acc[SK_PT];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int u = 0; u < SK_PT; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[u][i] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + kk * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[kk], acc, 0, 0, 0);
-        }
-        // largest row norm of the tile: lanes 0..15 hold rows 0..15, lanes 16..31 rows 16..31
-        const float rn16 = row16_max_nonneg(s_rn[buf][lane & 31]);
-        const float rnmax = __int_as_float(max(__builtin_amdgcn_readlane(__float_as_int(rn16), 0),
-                                               __builtin_amdgcn_readlane(__float_as_int(rn16), 16)));
-        // sign matrix: ballot i holds rows r_i (lanes 0..31) and r_i + 4 (lanes 32..63) of the tile.
-        // v_writelane is issued from inline asm, so the wait states between the compare that writes
-        // an SGPR and the v_writelane that reads it are placed by hand (s_nop 3 per group of 8).
-        uint32_t rowbits = 0u;
-        float amin = 3.0e38f;
-        unsigned long long bm[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            bm[i] = __ballot(acc[i] > 0.f);
-            amin = fminf(amin, fabsf(acc[i]));
+            for (int u = 0; u < SK_PT; ++u) {             // independent chains, interleaved on the matrix pipe
+                const uint16_t* brow = &s_x[buf][(u * SH_ROWS + (lane & 31)) * STRIDE + (lane >> 5) * 8];
+                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(brow + kk * 16);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag[kk], xb, acc[u], 0, 0, 0);
+            }
         }
-#define MP_WL4(I)                                                                                  \
-        asm volatile("s_nop 3\n\t"                                                                 \
-                     "v_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %10\n\t"               \
-                     "v_writelane_b32 %0, %3, %11\n\tv_writelane_b32 %0, %4, %12\n\t"              \
-                     "v_writelane_b32 %0, %5, %13\n\tv_writelane_b32 %0, %6, %14\n\t"              \
-                     "v_writelane_b32 %0, %7, %15\n\tv_writelane_b32 %0, %8, %16"                   \
-                     : "+v"(rowbits)                                                               \
-                     : "s"((uint32_t)bm[I]), "s"((uint32_t)(bm[I] >> 32)), "s"((uint32_t)bm[I + 1]), \
-                       "s"((uint32_t)(bm[I + 1] >> 32)), "s"((uint32_t)bm[I + 2]),                 \
-                       "s"((uint32_t)(bm[I + 2] >> 32)), "s"((uint32_t)bm[I + 3]),                 \
-                       "s"((uint32_t)(bm[I + 3] >> 32)),                                           \
-                       "n"(2 * (I)), "n"(2 * (I) + 4), "n"(2 * (I) + 1), "n"(2 * (I) + 5),         \
-                       "n"(2 * (I) + 2), "n"(2 * (I) + 6), "n"(2 * (I) + 3), "n"(2 * (I) + 7));
-        MP_WL4(0) MP_WL4(4) MP_WL4(8) MP_WL4(12)
-#undef MP_WL4
-        if (lane < 32) s_rowbits[(t * SH_ROWS + lane) * BW + wave] = rowbits;
-        if (amin <= wn * rnmax) {                         // wn < 0 for padding planes: never taken
-            const int64_t r0 = row_base + (int64_t)t * SH_ROWS;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                // guard-band candidate: queue (chunk row, plane offset) for the exact pass at the end
-                if ((r0 + row < n) && fabsf(acc[i]) <= wn * s_rn[buf][row]) {
-                    const int slot = atomicAdd(&s_qn, 1);
-                    if (slot < SK_QCAP) s_queue[slot] = ((uint32_t)(t * SH_ROWS + row) << 16) | (uint32_t)(ncol - col0);
+        for (int u = 0; u < SK_PT; ++u) {
+            const int t = ph * SK_PT + u;
+            if (t >= nt) break;                            // uniform
+            // 16 sign bits of this lane's row: b = (b << 1) | sign, last accumulator first, then inverted (bit = acc > 0;
+            // an exact zero is inside every guard band and is decided by the exact pass)
+            uint32_t b = 0u;
+            float amin = 3.0e38f;
+#pragma unroll
+            for (int i = 15; i >= 0; --i) {
+                b = __builtin_amdgcn_alignbit(b, __float_as_uint(acc[u][i]), 31);
+                amin = fminf(amin, fabsf(acc[u][i]));
+            }
+            b = ~b;
+            // nibble j of b = planes 8 j + 4 (lane >> 5) + (0 .. 3): nibbles to bytes, the upper half-wave 4 bits up
+            const uint32_t lo = b & 0x0f0fu, hi = (b >> 4) & 0x0f0fu;
+            uint32_t w = __builtin_amdgcn_perm(hi, lo, 0x05010400u) << ((lane >> 5) * 4);
+            const auto sw = __builtin_amdgcn_permlane32_swap(w, w, false, false);   // the other half-wave's 16 planes
+            w = sw[0] | sw[1];
+            if (lane < 32) s_rowbits[(t * SH_ROWS + lane) * BW + wave] = w;
+            const float rn = s_rn[buf][u * SH_ROWS + (lane & 31)];
+            if (amin <= wcoarse * rn) {                   // rare: this lane looks at its 16 values one by one
+                const int64_t gr = row_base + (int64_t)t * SH_ROWS + (lane & 31);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int pl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    // guard-band candidate: queue (chunk row, plane offset) for the exact pass at the end
+                    if (gr < n && fabsf(acc[u][i]) <= s_wn[wave][pl] * rn) {
+                        const int slot = atomicAdd(&s_qn, 1);
+                        if (slot < SK_QCAP)
+                            s_queue[slot] = ((uint32_t)(t * SH_ROWS + (lane & 31)) << 16) | (uint32_t)(wave * 32 + pl);
+                    }
                 }
             }
         }
@@ -411,22 +415,23 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
     // requested while tile t is on the matrix pipe and written to LDS one phase later; with three
     // workgroups resident per CU that is enough to cover the HBM latency, with ONE barrier per tile.
     u32x4 s0[QN], s1[QN];
+    const int nph = (nt + SK_PT - 1) / SK_PT;             // phases of SK_PT tiles
     tile_load(0, s0);
     tile_load(1, s1);
     tile_store(0, s0);
     __syncthreads();
     MP_STAMP(stamp, 41);
-#define MP_SK_PHASE(T, LOADSET, STORESET)                                  \
-    if ((T) < nt) {                                                        \
-        tile_load((T) + 2, LOADSET);                                       \
-        compute(T);                                                        \
-        tile_store(((T) + 1) & 1, STORESET);                               \
+#define MP_SK_PHASE(P, LOADSET, STORESET)                                  \
+    if ((P) < nph) {                                                       \
+        tile_load((P) + 2, LOADSET);                                       \
+        compute(P);                                                        \
+        tile_store(((P) + 1) & 1, STORESET);                               \
         lds_barrier();                                                     \
     }
-    for (int t = 0; t < nt; t += 2) {
-        MP_SK_PHASE(t, s0, s1)
-        MP_SK_PHASE(t + 1, s1, s0)
-        if (t == 2) MP_STAMP(stamp, 45);
+    for (int ph = 0; ph < nph; ph += 2) {
+        MP_SK_PHASE(ph, s0, s1)
+        MP_SK_PHASE(ph + 1, s1, s0)
+        if (ph == 2) MP_STAMP(stamp, 45);
     }
 #undef MP_SK_PHASE
     __syncthreads();
@@ -593,12 +598,12 @@ static int keys_chunk_tiles(int64_t n, int64_t wgs_x, int tables_per_wg) {
         cus = prop.multiProcessorCount;
     const int64_t slots = 2 * (int64_t)cus;
     const int64_t tiles = (n + SH_ROWS - 1) / SH_ROWS;
-    int best = 1;
+    int best = SK_PT;
     double best_cost = 1e300;
-    for (int ch = 1; ch <= SK_CH_MAX; ++ch) {
+    for (int ch = SK_PT; ch <= SK_CH_MAX; ch += SK_PT) {     // whole phases of SK_PT tiles
         if ((size_t)ch * SH_ROWS * (SK_WAVES + 1) * sizeof(uint32_t) > 48u * 1024u) break;
         const int64_t wgs = ((tiles + ch - 1) / ch) * wgs_x;
-        const double cost = (double)((wgs + slots - 1) / slots) * (1.9 * ch + 7.0);
+        const double cost = (double)((wgs + slots - 1) / slots) * (1.2 * ch + 7.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = ch; }
     }
     return best;
