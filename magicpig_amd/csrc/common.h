@@ -218,20 +218,26 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// A workgroup barrier that orders LDS traffic only: global loads and stores stay in flight across it (__syncthreads() also
+// waits for vmcnt(0): every outstanding global access of the wave).  Use where the barrier protects LDS data and nothing
+// read back from global memory (HIP guide, "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Exclusive prefix sum over the block's threads; `total` gets the block sum.
-// s_tmp: LDS scratch of >= blockDim.x/64 + 1 ints.  Contains two __syncthreads().
+// s_tmp: LDS scratch of >= blockDim.x/64 + 1 ints.  Contains two workgroup barriers (LDS_ONLY: lds_barrier()).
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ int block_excl_scan(int v, int* s_tmp, int& total) {
     const int l = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + WAVE - 1) >> 6;
     const int inc = wave_incl_scan(v);
     if (l == WAVE - 1) s_tmp[w] = inc;
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     if (w == 0) {
         int x = (l < nw) ? s_tmp[l] : 0;
         int xi = wave_incl_scan(x);
         if (l < nw) s_tmp[l] = xi - x;
         if (l == nw - 1) s_tmp[nw] = xi;
     }
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     total = s_tmp[nw];
     return s_tmp[w] + inc - v;
 }

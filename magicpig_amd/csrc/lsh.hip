@@ -357,22 +357,39 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
     build_row_histogram(c, n, NB, s_cnt, s_tmp, bounds + row * NB * RS, RS, err,
                         [&](int i, int ex, int) { s_gbase[i] = ex; });
     int* mine = s_cnt + wave * NB;
-    for (int t0 = 0; t0 < n; t0 += T) {
-        // this wave's slice of the tile: tokens w0 + j*64 + lane, j < TPL, kept in registers
+    // Round 5: every barrier of the tile loop orders LDS only (lds_barrier): the stores of tile t -- never read back here --
+    // drain while tile t + 1 is counted and ranked, and the codes of tile t + 1 are requested before tile t is written out
+    // (with __syncthreads() each tile waited for its own 32 KB of scattered stores at the next tile's first barrier).
+    auto load_codes = [&](int t0, int (&vq)[TPL]) {
         const int w0 = t0 + wave * (WAVE * TPL);
-        int vq[TPL];
 #pragma unroll
         for (int j = 0; j < TPL; ++j) {
             const int kk = w0 + j * WAVE + lane;
-            const int v = (kk < n) ? (int)c[kk] : -1;
-            vq[j] = (v >= 0 && v < NB) ? v : -1;
+            vq[j] = (int)c[kk < n ? kk : n - 1];              // unconditional (clamped): validated where it is used
         }
+    };
+    constexpr bool PREFETCH = TPL < 32;                       // (32 codes per lane: no registers for a second set)
+    int vq[TPL], vnext[PREFETCH ? TPL : 1];
+    if (PREFETCH) load_codes(0, vq);
+    for (int t0 = 0; t0 < n; t0 += T) {
+        if (!PREFETCH) load_codes(t0, vq);
+        // this wave's slice of the tile: tokens w0 + j*64 + lane, j < TPL, kept in registers
+        const int w0 = t0 + wave * (WAVE * TPL);
         for (int i = tid; i < nw * NB; i += blockDim.x) s_cnt[i] = 0;
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TPL; ++j) {
+            const int kk = w0 + j * WAVE + lane;
+            const int v = vq[j];
+            vq[j] = (kk < n && v >= 0 && v < NB) ? v : -1;
+        }
+        lds_barrier();
 #pragma unroll
         for (int j = 0; j < TPL; ++j)
             if (vq[j] >= 0) atomicAdd(&mine[vq[j]], 1);
-        __syncthreads();
+        if constexpr (PREFETCH) {
+            if (t0 + T < n) load_codes(t0 + T, vnext);         // uniform; consumed by the next iteration
+        }
+        lds_barrier();
         // per-wave cursors inside the tile's sorted order; where the tile's run of a bucket goes
         int carry = 0;
         for (int base = 0; base < NB; base += blockDim.x) {
@@ -385,8 +402,8 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
                 v += cw[w];
             }
             int total;
-            __syncthreads();
-            const int ex = block_excl_scan(v, s_tmp, total) + carry;
+            lds_barrier();
+            const int ex = block_excl_scan<true>(v, s_tmp, total) + carry;
             if (i < NB) {
                 int run = ex;
 #pragma unroll
@@ -400,7 +417,7 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
             }
             carry += total;
         }
-        __syncthreads();
+        lds_barrier();
         const int tile_count = carry;                   // valid tokens of the tile
 #pragma unroll
         for (int j = 0; j < TPL; ++j) {
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
                 s_b[start + rank] = (uint16_t)v;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // Written out by position, TPL entries per thread, in straight-line batches of 8 (round 5): all stage reads, then all
         // norm gathers, then all stores.  As a rolled loop (the trip count is tile_count / blockDim) every entry was a
         // dependent chain of its own -- LDS read -> L2 gather of the norm -> store -- and a tile paid TPL of them in turn.
@@ -473,8 +490,12 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
             }
             if (refused) atomicOr(bad + row / L, 1);
         }
-        // the next tile's zeroing of s_cnt is ordered after this loop's LDS reads by its barrier;
-        // s_id / s_b are rewritten only after two more barriers
+        // the next tile's zeroing of s_cnt is ordered after this loop's LDS reads by its barrier (lgkmcnt(0) in front of
+        // it: the reads have landed in registers); s_id / s_b / s_gdelta are rewritten only after two more barriers
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int j = 0; j < TPL; ++j) vq[j] = vnext[j];
+        }
     }
 }
 

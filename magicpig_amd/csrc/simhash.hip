@@ -225,37 +225,35 @@ __global__ __launch_bounds__(1024) void simhash_query_kernel(
 
 // ---------------------------------------------------------------- key hashing at prefill
 // models/attnserver.py:159-168: keys [heads][n][D] -> codes int16 [heads][L][n]; the one place of
-// the path where MFMA throughput matters (37.6 GFLOP per kv head at cfg 1).  A workgroup of eight
-// waves owns floor(256 / K) tables -- wave w keeps the B fragments of planes 32w .. 32w+31 of that
-// span in registers for the whole kernel -- and walks chunk_tiles consecutive 32-row tiles:
-//   * the rows of tile t+2 are requested while tile t is on the matrix pipe and tile t+1 is being
-//     written to the other half of a double-buffered LDS stage: ONE barrier per tile;
-//   * the 32x32 sign matrix of a tile leaves the wave as one LDS store (see `compute`) into the
-//     chunk's bit matrix [32 * chunk_tiles rows][9 words]; the K-bit codes are cut out of it at
-//     the end and stored as long runs of every [L][n] row;
-//   * guard-band candidates are NOT resolved inline (any stall would hold all waves at the
-//     barrier): they are queued in LDS and resolved together at the end, one 16-lane group per
-//     candidate (exact f64 dot product of the row and the plane, both re-read from L2), patching
-//     the bit matrix before the codes are cut out.
-// What bounds it is VALU issue and the per-tile barrier, not the matrix pipe (round 4: ~150 vector instructions per wave
-// and 32-row tile against 8 MFMAs, one barrier per tile: 19 % of the dense bf16 peak).  Round 5:
+// the path where MFMA throughput matters (37.6 GFLOP per kv head at cfg 1).
+//
+// What bounded it through round 4 (19 % of the dense bf16 peak) was neither the matrix pipe nor, as believed, VALU issue
+// alone: every wave read the whole 32-row x D tile out of LDS (1 KB per MFMA) to multiply it with its 32 planes --
+// 128 B per clock and CU, which IS the LDS's peak rate; at the ~55 % of it that ds_read_b128 sustains next to the
+// staging stores the matrix pipe cannot get past a quarter of its peak.  Round 5:
+//   * REGISTER BLOCKING: a wave keeps the fragments of SETS x 32 planes (SETS = 4 at head_dim <= 128: 128 VGPRs) and every
+//     fragment of the row tile it reads from LDS feeds two MFMAs on independent accumulators -- 512 B of LDS per MFMA,
+//     SETS column tiles per barrier.
+//     Workgroups of four waves at two waves per SIMD (256 registers each); a workgroup owns floor(128 SETS / K) tables;
 //   * the product is taken TRANSPOSED -- C' = W X^T: lane <-> row of X, accumulator register <-> plane -- so a lane holds
 //     16 sign bits of ITS OWN row: they are packed per lane (one v_alignbit per accumulator, a byte permute, one
 //     v_permlane32_swap to join the two half-waves) instead of 16 ballots + 32 v_writelane transposing through SGPRs;
-//   * the guard band is tested against the lane's own row norm, not the tile's largest;
-//   * a phase stages and multiplies TWO 32-row tiles: one barrier, one pass of address arithmetic and one round of LDS
-//     traffic per 16 MFMAs instead of 8, two independent accumulator chains interleaved on the matrix pipe;
-//   * the rows' sums of squares come from v_dot2c (4 instructions per 16-byte chunk instead of 8 converts + 8 FMAs).
-constexpr int SK_CH_MAX = 32;             // 32-row tiles per workgroup: chosen per launch (keys_chunk_tiles), even
+//   * the guard band is tested against the lane's own row norm, not the tile's largest; the rows' sums of squares come
+//     from v_dot2c (4 instructions per 16-byte chunk instead of 8 converts + 8 FMAs).
+// As before: the rows of tile t+2 are requested while tile t is on the matrix pipe and tile t+1 is written to the other
+// half of a double-buffered LDS stage (ONE barrier per tile, ordering LDS only); the tile's sign words go into the chunk's
+// bit matrix [32 * chunk_tiles rows][tiles + 1 words], from which the K-bit codes are cut at the end and stored as long
+// runs of every [L][n] row; guard-band candidates are queued and resolved together at the end (exact f64 dot product,
+// one 16-lane group per candidate), patching the bit matrix before the codes are cut out.
+constexpr int SK_CH_MAX = 32;             // 32-row tiles per workgroup, at most (keys_chunk_tiles picks; LDS caps it)
 constexpr int SK_QCAP = 1024;             // deferred exact-sign candidates per workgroup
-
-constexpr int SK_WAVES = 8;               // waves per workgroup: two workgroups fill the 16 wave slots
-                                          // a CU has at 128 VGPRs (5-wave blocks left 6 of them empty)
-constexpr int SK_MAX_TABLES = 32;
-constexpr int SK_PT = 2;                  // 32-row tiles per phase (one barrier per phase)
+constexpr int SK_WAVES = 4;               // waves per workgroup; two workgroups per CU = two waves per SIMD
+constexpr int SK_MAX_SETS = 4;            // plane sets (32 planes each) per wave, at most
+constexpr int SK_MAX_TABLES = 64;
+__host__ __device__ constexpr int sk_sets(int D) { return D <= 128 ? 4 : 2; }   // 128 VGPRs of plane fragments either way
 
 template <int D>
-__global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void simhash_keys_kernel(
+__global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void simhash_keys_kernel(
     const uint16_t* __restrict__ x,       // bf16 (centred keys): row r of head h at x + h*head_stride + r*row_stride
     int64_t head_stride, int64_t row_stride,   // elements: n*D, D for keys [heads][n][D]; M*2D, 2D for the K|V store
     const uint16_t* __restrict__ Wt,      // [KLpad][D]
@@ -266,15 +264,16 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
     constexpr int KSTEPS = D / 16;
     constexpr int STRIDE = D + 8;
     constexpr int CPR = D / 8;            // 16-byte chunks per row
-    constexpr int PROWS = SH_ROWS * SK_PT;   // rows staged per phase
-    constexpr int NCH = PROWS * CPR;      // chunks per phase
+    constexpr int SETS = sk_sets(D);
+    constexpr int NCH = SH_ROWS * CPR;    // chunks per 32-row tile
     constexpr int NTHR = 64 * SK_WAVES;
-    constexpr int QN = (NCH + NTHR - 1) / NTHR;   // chunks per thread
+    constexpr int QN = NCH / NTHR;        // chunks per thread
+    static_assert(NCH % NTHR == 0 && QN >= 1, "a tile's chunks divide over the threads");
     const int CROWS = chunk_tiles * SH_ROWS;
-    __shared__ __attribute__((aligned(16))) uint16_t s_x[2][PROWS * STRIDE];
-    __shared__ float s_rn[2][PROWS];
-    __shared__ float s_wn[SK_WAVES][32];  // guard-band half-widths of the wave's 32 planes (-1: not this workgroup's)
-    constexpr int BW = SK_WAVES + 1;      // words of the sign matrix per row: one per wave + one of slack
+    __shared__ __attribute__((aligned(16))) uint16_t s_x[2][SH_ROWS * STRIDE];
+    __shared__ float s_rn[2][SH_ROWS];
+    __shared__ float s_wn[SK_WAVES * SETS][32];   // guard-band half-widths of a column tile's planes (-1: not this workgroup's)
+    constexpr int BW = SK_WAVES * SETS + 1;       // words of the sign matrix per row: one per column tile + one of slack
     __shared__ uint32_t s_queue[SK_QCAP];
     __shared__ int s_qn;
     extern __shared__ uint32_t s_rowbits[];               // sign matrix of the whole chunk: [CROWS][BW] (bit c of
@@ -302,43 +301,47 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
     if (tid == 0) s_qn = 0;
     MP_STAMP(stamp, 40);
 
-    const bool has_tile = wave < tiles_per_wg;
-    const int ncol = col0 + wave * 32 + (lane & 31);
-    bf16x8 bfrag[KSTEPS];
-    float wcoarse = -1.f;                                 // uniform: the widest guard band among the wave's planes
-    if (has_tile) {
-        const uint16_t* wrow = Wt + (int64_t)ncol * D + (lane >> 5) * 8;
+    // column tile wave * SETS + st of the workgroup's span: planes col0 + 32 (wave SETS + st) + (lane & 31).  Tiles past
+    // tiles_per_wg (a K whose span does not fill all sixteen) multiply zero rows of Wt's padding: their words are never read.
+    bf16x8 bfrag[SETS][KSTEPS];
+    float wcoarse[SETS];                                  // uniform: the widest guard band among the tile's planes
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) bfrag[kk] = *reinterpret_cast<const bf16x8*>(wrow + kk * 16);
+    for (int st = 0; st < SETS; ++st) {
+        const int ctile = wave * SETS + st;
+        const int ncol = col0 + ctile * 32 + (lane & 31);
+        const bool live = ctile < tiles_per_wg;           // uniform
+        const uint16_t* wrow = Wt + (int64_t)(live ? ncol : col0) * D + (lane >> 5) * 8;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) bfrag[st][kk] = *reinterpret_cast<const bf16x8*>(wrow + kk * 16);
         // planes past this workgroup's tables (the tail of its last tile) belong to the next one
-        const float wn = (ncol < KL && ncol - col0 < tables_per_wg * K) ? wnorm[ncol] * SH_EPS : -1.f;
-        if (lane < 32) s_wn[wave][lane] = wn;
+        const float wn = (live && ncol < KL && ncol - col0 < tables_per_wg * K) ? wnorm[ncol] * SH_EPS : -1.f;
+        if (lane < 32) s_wn[ctile][lane] = wn;
         const float w16 = row16_max_nonneg(fmaxf(wn, 0.f));
-        wcoarse = __int_as_float(max(__builtin_amdgcn_readlane(__float_as_int(w16), 0),
-                                     __builtin_amdgcn_readlane(__float_as_int(w16), 16)));
+        const float wmax = __int_as_float(max(__builtin_amdgcn_readlane(__float_as_int(w16), 0),
+                                              __builtin_amdgcn_readlane(__float_as_int(w16), 16)));
+        wcoarse[st] = live ? wmax : -1.f;
     }
 
     // Loads are unconditional (row index clamped to the last row): a load under a branch is followed by
     // s_waitcnt vmcnt(0) at the join, which would serialise the prefetch.  Rows past n compute on duplicates
     // whose results are never stored.  Thread tid takes chunk tid % CPR of rows tid / CPR + q * (nthr / CPR).
-    static_assert(NCH % NTHR == 0, "a phase's chunks divide over the threads");
     const int64_t last_row = n - 1;
     const uint16_t* xcol = x + (tid % CPR) * 8;
-    auto tile_load = [&](int ph, u32x4 (&st)[QN]) {
+    auto tile_load = [&](int t, u32x4 (&sreg)[QN]) {
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
-            int64_t gr = row_base + (int64_t)ph * PROWS + (tid / CPR) + q * (NTHR / CPR);
+            int64_t gr = row_base + (int64_t)t * SH_ROWS + (tid / CPR) + q * (NTHR / CPR);
             gr = gr < last_row ? gr : last_row;
-            st[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xcol + gr * row_stride));
+            sreg[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xcol + gr * row_stride));
         }
     };
-    auto tile_store = [&](int buf, const u32x4 (&st)[QN]) {
+    auto tile_store = [&](int buf, const u32x4 (&sreg)[QN]) {
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
             const int row = (tid / CPR) + q * (NTHR / CPR);
-            *reinterpret_cast<u32x4*>(&s_x[buf][row * STRIDE + (tid % CPR) * 8]) = st[q];
+            *reinterpret_cast<u32x4*>(&s_x[buf][row * STRIDE + (tid % CPR) * 8]) = sreg[q];
             float ss = 0.f;
-            dot8_bf16_chain(ss, st[q], st[q]);            // sum of squares of the chunk's 8 elements
+            dot8_bf16_chain(ss, sreg[q], sreg[q]);        // sum of squares of the chunk's 8 elements
             dot_settle(ss);
             // the CPR chunks of a row sit in CPR consecutive lanes (nthr is a multiple of 64)
             if (CPR == 16) ss = row16_sum(ss);
@@ -351,56 +354,67 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
                 s_rn[buf][row] = __builtin_amdgcn_sqrtf(ss) * 1.0001f;
         }
     };
-    // MFMA + signs of the phase's tiles (LDS half ph & 1).  C' = W X^T: lane l holds, for row (l & 31) of the
-    // tile, the 16 planes (i & 3) + 8 (i >> 2) + 4 (l >> 5), i = 0 .. 15, of the wave's 32.
-    auto compute = [&](int ph) {
-        if (!has_tile) return;
-        const int buf = ph & 1;
-        f32x16 acc[SK_PT];
+    // MFMA + signs of tile t (LDS half t & 1).  C' = W X^T: lane l holds, for row (l & 31) of the tile, the 16 planes
+    // (i & 3) + 8 (i >> 2) + 4 (l >> 5), i = 0 .. 15, of a column tile's 32.
+    auto compute = [&](int t) {
+        const int buf = t & 1;
+        const uint16_t* brow = &s_x[buf][(lane & 31) * STRIDE + (lane >> 5) * 8];
+        const float rn = s_rn[buf][lane & 31];
+        // two column tiles at a time: 32 accumulator registers next to the 128 of the plane fragments (all SETS at once
+        // spilled 45 registers at head_dim 128); a fragment of the row tile read from LDS feeds two MFMAs on independent
+        // accumulators, which also keeps the matrix pipe issuing back to back
 #pragma unroll
-        for (int u = 0; u < SK_PT; ++u)
+        for (int s0 = 0; s0 < SETS; s0 += 2) {
+            if (s0 > 0) __builtin_amdgcn_sched_barrier(0);   // the halves must not be interleaved: their accumulators would all be live
+            f32x16 acc[2];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[u][i] = 0.f;
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
+                for (int i = 0; i < 16; ++i) acc[u][i] = 0.f;
 #pragma unroll
-            for (int u = 0; u < SK_PT; ++u) {             // independent chains, interleaved on the matrix pipe
-                const uint16_t* brow = &s_x[buf][(u * SH_ROWS + (lane & 31)) * STRIDE + (lane >> 5) * 8];
+            for (int kk = 0; kk < KSTEPS; ++kk) {
                 const bf16x8 xb = *reinterpret_cast<const bf16x8*>(brow + kk * 16);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag[kk], xb, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag[s0 + u][kk], xb, acc[u], 0, 0, 0);
             }
-        }
 #pragma unroll
-        for (int u = 0; u < SK_PT; ++u) {
-            const int t = ph * SK_PT + u;
-            if (t >= nt) break;                            // uniform
-            // 16 sign bits of this lane's row: b = (b << 1) | sign, last accumulator first, then inverted (bit = acc > 0;
-            // an exact zero is inside every guard band and is decided by the exact pass)
-            uint32_t b = 0u;
-            float amin = 3.0e38f;
+            for (int u = 0; u < 2; ++u) {
+                const int st = s0 + u;
+                const int ctile = wave * SETS + st;
+                // 16 sign bits of this lane's row: b = (b << 1) | sign, last accumulator first, then inverted (bit = acc > 0;
+                // an exact zero is inside every guard band and is decided by the exact pass)
+                uint32_t b = 0u;
+                float amin = 3.0e38f;
 #pragma unroll
-            for (int i = 15; i >= 0; --i) {
-                b = __builtin_amdgcn_alignbit(b, __float_as_uint(acc[u][i]), 31);
-                amin = fminf(amin, fabsf(acc[u][i]));
-            }
-            b = ~b;
-            // nibble j of b = planes 8 j + 4 (lane >> 5) + (0 .. 3): nibbles to bytes, the upper half-wave 4 bits up
-            const uint32_t lo = b & 0x0f0fu, hi = (b >> 4) & 0x0f0fu;
-            uint32_t w = __builtin_amdgcn_perm(hi, lo, 0x05010400u) << ((lane >> 5) * 4);
-            const auto sw = __builtin_amdgcn_permlane32_swap(w, w, false, false);   // the other half-wave's 16 planes
-            w = sw[0] | sw[1];
-            if (lane < 32) s_rowbits[(t * SH_ROWS + lane) * BW + wave] = w;
-            const float rn = s_rn[buf][u * SH_ROWS + (lane & 31)];
-            if (amin <= wcoarse * rn) {                   // rare: this lane looks at its 16 values one by one
-                const int64_t gr = row_base + (int64_t)t * SH_ROWS + (lane & 31);
+                for (int i = 15; i >= 0; --i) {
+                    b = __builtin_amdgcn_alignbit(b, __float_as_uint(acc[u][i]), 31);
+                    amin = fminf(amin, fabsf(acc[u][i]));
+                }
+                b = ~b;
+                // nibble j of b = planes 8 j + 4 (lane >> 5) + (0 .. 3): nibbles to bytes, the upper half-wave 4 bits up
+                const uint32_t lo = b & 0x0f0fu, hi = (b >> 4) & 0x0f0fu;
+                uint32_t w = __builtin_amdgcn_perm(hi, lo, 0x05010400u) << ((lane >> 5) * 4);
+                const auto sw = __builtin_amdgcn_permlane32_swap(w, w, false, false);   // the other half-wave's 16 planes
+                w = sw[0] | sw[1];
+                if (lane < 32) s_rowbits[(t * SH_ROWS + lane) * BW + ctile] = w;
+                if (amin <= wcoarse[st] * rn) {           // rare: this lane looks at its 16 values one by one
+                    const int64_t gr = row_base + (int64_t)t * SH_ROWS + (lane & 31);
+                    // plane offset of accumulator i inside the workgroup's span: pb + (i & 3) + 8 (i >> 2).  Opaque to the
+                    // optimiser on purpose: as a loop invariant it hoisted all 16 SETS sums out of the tile loop -- 64
+                    // registers for a path that is almost never taken, spilled to scratch
+                    int pb = ctile * 32 + 4 * (lane >> 5);
+                    asm volatile("" : "+v"(pb));
+                    const float* wn_flat = &s_wn[0][0];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int pl = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                    // guard-band candidate: queue (chunk row, plane offset) for the exact pass at the end
-                    if (gr < n && fabsf(acc[u][i]) <= s_wn[wave][pl] * rn) {
-                        const int slot = atomicAdd(&s_qn, 1);
-                        if (slot < SK_QCAP)
-                            s_queue[slot] = ((uint32_t)(t * SH_ROWS + (lane & 31)) << 16) | (uint32_t)(wave * 32 + pl);
+                    for (int i = 0; i < 16; ++i) {
+                        const int po = pb + (i & 3) + 8 * (i >> 2);
+                        // guard-band candidate: queue (chunk row, plane offset) for the exact pass at the end
+                        if (gr < n && fabsf(acc[u][i]) <= wn_flat[po] * rn) {
+                            const int slot = atomicAdd(&s_qn, 1);
+                            if (slot < SK_QCAP)
+                                s_queue[slot] = ((uint32_t)(t * SH_ROWS + (lane & 31)) << 16) | (uint32_t)po;
+                        }
                     }
                 }
             }
@@ -410,28 +424,25 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(4
     // __syncthreads() also drains every outstanding global load (s_waitcnt vmcnt(0)), which would
     // serialise the prefetched tiles behind each barrier; inside the loop only LDS traffic has to be
     // complete before the barrier (HIP guide, "Pipelining across barriers").
-    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     // prologue: tile 0 staged, tile 1 in registers.  Two register sets: the rows of tile t+2 are
-    // requested while tile t is on the matrix pipe and written to LDS one phase later; with three
-    // workgroups resident per CU that is enough to cover the HBM latency, with ONE barrier per tile.
+    // requested while tile t is on the matrix pipe and written to LDS one phase later.
     u32x4 s0[QN], s1[QN];
-    const int nph = (nt + SK_PT - 1) / SK_PT;             // phases of SK_PT tiles
     tile_load(0, s0);
     tile_load(1, s1);
     tile_store(0, s0);
     __syncthreads();
     MP_STAMP(stamp, 41);
-#define MP_SK_PHASE(P, LOADSET, STORESET)                                  \
-    if ((P) < nph) {                                                       \
-        tile_load((P) + 2, LOADSET);                                       \
-        compute(P);                                                        \
-        tile_store(((P) + 1) & 1, STORESET);                               \
+#define MP_SK_PHASE(T, LOADSET, STORESET)                                  \
+    if ((T) < nt) {                                                        \
+        tile_load((T) + 2, LOADSET);                                       \
+        compute(T);                                                        \
+        tile_store(((T) + 1) & 1, STORESET);                               \
         lds_barrier();                                                     \
     }
-    for (int ph = 0; ph < nph; ph += 2) {
-        MP_SK_PHASE(ph, s0, s1)
-        MP_SK_PHASE(ph + 1, s1, s0)
-        if (ph == 2) MP_STAMP(stamp, 45);
+    for (int t = 0; t < nt; t += 2) {
+        MP_SK_PHASE(t, s0, s1)
+        MP_SK_PHASE(t + 1, s1, s0)
+        if (t == 2) MP_STAMP(stamp, 45);
     }
 #undef MP_SK_PHASE
     __syncthreads();
@@ -527,7 +538,7 @@ static void simhash_geometry(int K, int& tables_per_wg, int& tiles_per_wg) {
     tiles_per_wg = tiles;
 }
 
-static void simhash_keys_geometry(int K, int& tables_per_wg, int& tiles_per_wg);
+static void simhash_keys_geometry(int K, int sets, int& tables_per_wg, int& tiles_per_wg);
 
 // rows of Wt / entries of wnorm: every plane any workgroup of either kernel can touch
 int simhash_padded_cols(int K, int L) {
@@ -535,9 +546,12 @@ int simhash_padded_cols(int K, int L) {
     simhash_geometry(K, tp, tiles);
     const int wgs = (L + tp - 1) / tp;
     int cols = wgs * tiles * 32;
-    simhash_keys_geometry(K, tp, tiles);
-    const int kcols = ((L + tp - 1) / tp - 1) * tp * K + tiles * 32;
-    return cols > kcols ? cols : kcols;
+    for (int sets = 2; sets <= SK_MAX_SETS; sets += 2) {     // the key kernel's span per head_dim class (sk_sets): whole tiles
+        simhash_keys_geometry(K, sets, tp, tiles);           // of the LAST workgroup, live or not, must exist in Wt
+        const int kcols = ((L + tp - 1) / tp - 1) * tp * K + SK_WAVES * sets * 32;
+        cols = cols > kcols ? cols : kcols;
+    }
+    return cols;
 }
 
 int simhash_supported(int D, int K) {
@@ -576,10 +590,10 @@ hipError_t launch_simhash_query(const uint16_t* q, const uint16_t* Wt, const flo
     return hipErrorInvalidValue;
 }
 
-// key-side geometry: a workgroup hashes floor(256 / K) tables (at most SK_MAX_TABLES) with one
-// wave per 32 planes; its plane span starts at table0 * K whatever the alignment.
-static void simhash_keys_geometry(int K, int& tables_per_wg, int& tiles_per_wg) {
-    int tp = (32 * SK_WAVES) / K;
+// key-side geometry: a workgroup hashes floor(32 waves sets / K) tables (at most SK_MAX_TABLES), `sets` column tiles of
+// 32 planes per wave; its plane span starts at table0 * K whatever the alignment.
+static void simhash_keys_geometry(int K, int sets, int& tables_per_wg, int& tiles_per_wg) {
+    int tp = (32 * SK_WAVES * sets) / K;
     if (tp > SK_MAX_TABLES) tp = SK_MAX_TABLES;
     tables_per_wg = tp;
     tiles_per_wg = (tp * K + 31) / 32;
@@ -590,7 +604,7 @@ static void simhash_keys_geometry(int K, int& tables_per_wg, int& tiles_per_wg) 
 // that product (the constants are the measured 1.9 us per tile and 7 us per workgroup; only their
 // ratio matters).  The chunk's sign matrix [32 * tiles][9] words has to fit in LDS next to a second
 // workgroup.
-static int keys_chunk_tiles(int64_t n, int64_t wgs_x, int tables_per_wg) {
+static int keys_chunk_tiles(int64_t n, int64_t wgs_x, int tables_per_wg, int sets) {
     int cus = 256;
     hipDeviceProp_t prop;
     int dev = 0;
@@ -598,12 +612,14 @@ static int keys_chunk_tiles(int64_t n, int64_t wgs_x, int tables_per_wg) {
         cus = prop.multiProcessorCount;
     const int64_t slots = 2 * (int64_t)cus;
     const int64_t tiles = (n + SH_ROWS - 1) / SH_ROWS;
-    int best = SK_PT;
+    int best = 1;
     double best_cost = 1e300;
-    for (int ch = SK_PT; ch <= SK_CH_MAX; ch += SK_PT) {     // whole phases of SK_PT tiles
-        if ((size_t)ch * SH_ROWS * (SK_WAVES + 1) * sizeof(uint32_t) > 48u * 1024u) break;
+    for (int ch = 1; ch <= SK_CH_MAX; ++ch) {
+        // the chunk's sign matrix next to a second workgroup's: 52 KB of the CU's 160 (the static stage, queue and norms
+        // of a workgroup are ~24 KB at head_dim 128)
+        if ((size_t)ch * SH_ROWS * (SK_WAVES * sets + 1) * sizeof(uint32_t) > 52u * 1024u) break;
         const int64_t wgs = ((tiles + ch - 1) / ch) * wgs_x;
-        const double cost = (double)((wgs + slots - 1) / slots) * (1.2 * ch + 7.0);
+        const double cost = (double)((wgs + slots - 1) / slots) * (1.9 * ch + 7.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = ch; }
     }
     return best;
@@ -615,13 +631,14 @@ hipError_t launch_simhash_keys_strided(const uint16_t* keys, int64_t head_stride
                                        const uint16_t* Wt, const float* wnorm, int heads, int64_t n, int D, int K,
                                        int L, int16_t* codes, hipStream_t st) {
     int tp, tiles;
-    simhash_keys_geometry(K, tp, tiles);
+    const int sets = sk_sets(D);
+    simhash_keys_geometry(K, sets, tp, tiles);
     const int wgs_x = (L + tp - 1) / tp;
     if (heads < 1 || heads > 65535) return hipErrorInvalidValue;
     static thread_local int64_t memo_n = -1;
     static thread_local int memo_x = 0, memo_tp = 0, memo_ch = 0;
     if (memo_n != n || memo_x != wgs_x * heads || memo_tp != tp) {
-        memo_ch = keys_chunk_tiles(n, (int64_t)wgs_x * heads, tp);
+        memo_ch = keys_chunk_tiles(n, (int64_t)wgs_x * heads, tp, sets);
         memo_n = n; memo_x = wgs_x * heads; memo_tp = tp;
     }
     const int ch = memo_ch;
@@ -632,7 +649,7 @@ hipError_t launch_simhash_keys_strided(const uint16_t* keys, int64_t head_stride
     if (chunks > INT32_MAX || blocks > INT32_MAX) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks);
     dim3 block(64 * SK_WAVES);
-    const size_t lds = (size_t)crows * (SK_WAVES + 1) * sizeof(uint32_t);   // the chunk's sign matrix
+    const size_t lds = (size_t)crows * (SK_WAVES * sets + 1) * sizeof(uint32_t);   // the chunk's sign matrix
 #define MP_SK_CASE(DD)                                                                              \
     if (D == DD) {                                                                                  \
         hipLaunchKernelGGL((simhash_keys_kernel<DD>), grid, block, lds, st, keys, head_stride,      \
