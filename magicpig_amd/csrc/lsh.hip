@@ -332,7 +332,13 @@ __device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ 
 }
 
 // LDS: cnt [nw][NB] | gbase [NB] | gdelta [NB] | s_tmp [32] | stage_id [T] | stage_b [T] (u16)
-template <int TPL>   // tokens per lane and tile: T = TPL * blockDim.x
+// PACK (round 5, NB <= 1024: the BASELINE configurations at K = 10): the tile's per-wave counters are 16 bits wide, two to
+// a word -- a tile holds at most T = 8 192 tokens, so a count or a cursor never carries into its neighbour -- and the row
+// histogram's 32-bit counters (whole-row counts) borrow the stage, which is idle during that pass: 72 KB per workgroup
+// of eight waves instead of 123 KB for sixteen, so TWO workgroups share a CU.  The tile loop is a chain of short phases
+// between barriers (count, scan, rank, write out); with one workgroup per CU nothing filled the waits, and a launch of
+// 1 200 rows ran in five rounds of 256 (cfg 4: 300 rows in two rounds, the second 17 % full).
+template <int TPL, bool PACK = false>   // tokens per lane and tile: T = TPL * blockDim.x
 __global__ __launch_bounds__(1024) void lsh_build_kernel(
     const int16_t* __restrict__ codes,   // [Hkv*L][n] unsorted
     int n, int NB, int nbits, int64_t M, int RS, int32_t* __restrict__ bounds, int32_t* __restrict__ table,
@@ -345,18 +351,30 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
     extern __shared__ int s_mem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int T = TPL * blockDim.x;
-    int* s_cnt = s_mem;
-    int* s_gbase = s_cnt + nw * NB;
+    int* s_cnt = s_mem;                                       // PACK: nw * NB / 2 words of two 16-bit counters
+    int* s_gbase = s_cnt + (PACK ? (nw * NB) / 2 : nw * NB);
     int* s_gdelta = s_gbase + NB;
     int* s_tmp = s_gdelta + NB;
     int* s_id = s_tmp + 32;
     uint16_t* s_b = reinterpret_cast<uint16_t*>(s_id + T);
+    uint16_t* s_cnt16 = reinterpret_cast<uint16_t*>(s_cnt);
     const int64_t row = blockIdx.x;
     const int16_t* c = codes + row * n;
     int32_t* dst = table + row * M;
-    build_row_histogram(c, n, NB, s_cnt, s_tmp, bounds + row * NB * RS, RS, err,
+    // (PACK: the whole-row histogram counts up to n per bucket -- 32-bit counters [nw][NB], in the stage's T words; the
+    // host launches PACK only where nw * NB <= T)
+    build_row_histogram(c, n, NB, PACK ? s_id : s_cnt, s_tmp, bounds + row * NB * RS, RS, err,
                         [&](int i, int ex, int) { s_gbase[i] = ex; });
-    int* mine = s_cnt + wave * NB;
+    int* mine = s_cnt + wave * NB;                            // (not PACK)
+    const int wbase = wave * NB;                              // PACK: this wave's counters are cnt16[wbase + v]
+    auto count_add = [&](int v, int k) -> int {               // += k on this wave's counter of bucket v; returns the old value
+        if (PACK) {
+            const int sh = (v & 1) * 16;
+            const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(s_cnt) + ((wbase + v) >> 1), (unsigned)k << sh);
+            return (int)((old >> sh) & 0xffffu);
+        }
+        return atomicAdd(&mine[v], k);
+    };
     // Round 5: every barrier of the tile loop orders LDS only (lds_barrier): the stores of tile t -- never read back here --
     // drain while tile t + 1 is counted and ranked, and the codes of tile t + 1 are requested before tile t is written out
     // (with __syncthreads() each tile waited for its own 32 KB of scattered stores at the next tile's first barrier).
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
         if (!PREFETCH) load_codes(t0, vq);
         // this wave's slice of the tile: tokens w0 + j*64 + lane, j < TPL, kept in registers
         const int w0 = t0 + wave * (WAVE * TPL);
-        for (int i = tid; i < nw * NB; i += blockDim.x) s_cnt[i] = 0;
+        for (int i = tid; i < (PACK ? (nw * NB) / 2 : nw * NB); i += blockDim.x) s_cnt[i] = 0;
 #pragma unroll
         for (int j = 0; j < TPL; ++j) {
             const int kk = w0 + j * WAVE + lane;
@@ -385,7 +403,7 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
         lds_barrier();
 #pragma unroll
         for (int j = 0; j < TPL; ++j)
-            if (vq[j] >= 0) atomicAdd(&mine[vq[j]], 1);
+            if (vq[j] >= 0) (void)count_add(vq[j], 1);
         if constexpr (PREFETCH) {
             if (t0 + T < n) load_codes(t0 + T, vnext);         // uniform; consumed by the next iteration
         }
@@ -398,7 +416,7 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
             int cw[16];                                   // the waves' counts of bucket i: ONE batch of LDS reads
 #pragma unroll
             for (int w = 0; w < 16; ++w) {
-                cw[w] = (i < NB && w < nw) ? s_cnt[w * NB + i] : 0;
+                cw[w] = (i < NB && w < nw) ? (PACK ? (int)s_cnt16[w * NB + i] : s_cnt[w * NB + i]) : 0;
                 v += cw[w];
             }
             int total;
@@ -408,7 +426,10 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
                 int run = ex;
 #pragma unroll
                 for (int w = 0; w < 16; ++w) {
-                    if (w < nw) s_cnt[w * NB + i] = run;
+                    if (w < nw) {
+                        if (PACK) s_cnt16[w * NB + i] = (uint16_t)run;      // (a 16-bit store: the neighbour's half is another thread's)
+                        else s_cnt[w * NB + i] = run;
+                    }
                     run += cw[w];
                 }
                 const int g = s_gbase[i];
@@ -429,7 +450,7 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
                 const int rank = __popcll(peers & ((1ull << lane) - 1ull));
                 const int leader = __ffsll((long long)peers) - 1;
                 int start = 0;
-                if (lane == leader) start = atomicAdd(&mine[v], __popcll(peers));
+                if (lane == leader) start = count_add(v, __popcll(peers));
                 start = __shfl(start, leader);
                 s_id[start + rank] = w0 + j * WAVE + lane;
                 s_b[start + rank] = (uint16_t)v;
@@ -1793,14 +1814,17 @@ hipError_t launch_lsh_unsort(const int16_t* codes, const int32_t* ids, int rows,
 }
 
 // staged layout per NB (LDS <= 160 KB): waves per row, tokens per lane and tile
-static bool build_staged_geometry(int NB, int& nw, int& tpl, size_t& lds) {
-    if (NB <= 1024)      { nw = 16; tpl = 8; }
+static bool build_staged_geometry(int NB, int& nw, int& tpl, size_t& lds, bool& pack) {
+    pack = false;
+    if (NB <= 1024)      { nw = 8;  tpl = 16; pack = true; }      // 72 KB: two workgroups per CU (16-bit tile counters)
     else if (NB <= 2048) { nw = 8;  tpl = 16; }
     else if (NB <= 4096) { nw = 4;  tpl = 32; }
     else if (NB <= 8192) { nw = 2;  tpl = 32; }
     else return false;
     const size_t T = (size_t)tpl * 64 * nw;
-    lds = ((size_t)nw * NB + 2 * (size_t)NB + 32 + T) * 4 + T * 2;
+    // PACK: nw * NB 16-bit counters; the row histogram's nw * NB 32-bit counters sit in the stage's T words
+    lds = ((pack ? (size_t)nw * NB / 2 : (size_t)nw * NB) + 2 * (size_t)NB + 32 + T) * 4 + T * 2;
+    if (pack && (size_t)nw * NB > T) return false;
     return lds <= 160u * 1024u;
 }
 
@@ -1812,7 +1836,7 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     if (packed) *packed = false;
     static DeviceOnce once;
     const hipError_t attr_err = once.run([] {
-        const void* fns[] = {reinterpret_cast<const void*>(lsh_build_kernel<8>),
+        const void* fns[] = {reinterpret_cast<const void*>(lsh_build_kernel<16, true>),
                              reinterpret_cast<const void*>(lsh_build_kernel<16>),
                              reinterpret_cast<const void*>(lsh_build_kernel<32>),
                              reinterpret_cast<const void*>(lsh_build_direct_kernel)};
@@ -1828,13 +1852,14 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     while ((1 << nbits) < NB) ++nbits;
     int nw, tpl;
     size_t lds;
+    bool pack;
     const int RS = R + 1;
-    if (build_staged_geometry(NB, nw, tpl, lds)) {
-#define MP_BUILD_CASE(TPL)                                                                         \
-        if (tpl == TPL)                                                                            \
-            hipLaunchKernelGGL(lsh_build_kernel<TPL>, dim3(rows), dim3(64 * nw), lds, st, codes,   \
+    if (build_staged_geometry(NB, nw, tpl, lds, pack)) {
+#define MP_BUILD_CASE(TPL, PK)                                                                         \
+        if (tpl == TPL && pack == PK)                                                                  \
+            hipLaunchKernelGGL((lsh_build_kernel<TPL, PK>), dim3(rows), dim3(64 * nw), lds, st, codes, \
                                (int)n, NB, nbits, M, RS, bounds, table, err, kn, L, idbits, bad);
-        MP_BUILD_CASE(8) MP_BUILD_CASE(16) MP_BUILD_CASE(32)
+        MP_BUILD_CASE(16, true) MP_BUILD_CASE(16, false) MP_BUILD_CASE(32, false)
 #undef MP_BUILD_CASE
         if (packed) *packed = kn != nullptr;
         return hipGetLastError();

@@ -272,7 +272,6 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const int CROWS = chunk_tiles * SH_ROWS;
     __shared__ __attribute__((aligned(16))) uint16_t s_x[2][SH_ROWS * STRIDE];
     __shared__ float s_rn[2][SH_ROWS];
-    __shared__ float s_wn[SK_WAVES * SETS][32];   // guard-band half-widths of a column tile's planes (-1: not this workgroup's)
     constexpr int BW = SK_WAVES * SETS + 1;       // words of the sign matrix per row: one per column tile + one of slack
     __shared__ uint32_t s_queue[SK_QCAP];
     __shared__ int s_qn;
@@ -305,6 +304,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     // tiles_per_wg (a K whose span does not fill all sixteen) multiply zero rows of Wt's padding: their words are never read.
     bf16x8 bfrag[SETS][KSTEPS];
     float wcoarse[SETS];                                  // uniform: the widest guard band among the tile's planes
+    uint32_t mine[SETS];                                  // per lane: bit i = the plane of accumulator i is this workgroup's
+    float wn_s[SETS];
+    // every load of the prologue first (as one loop per tile the use of a tile's plane norm put an s_waitcnt vmcnt(0)
+    // between the tiles' fragment loads: four dependent round trips, 8 us per workgroup under the stamps)
 #pragma unroll
     for (int st = 0; st < SETS; ++st) {
         const int ctile = wave * SETS + st;
@@ -313,9 +316,22 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
         const uint16_t* wrow = Wt + (int64_t)(live ? ncol : col0) * D + (lane >> 5) * 8;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) bfrag[st][kk] = *reinterpret_cast<const bf16x8*>(wrow + kk * 16);
+        wn_s[st] = wnorm[live ? ncol : col0];             // (Wt and wnorm are padded to whole tiles of the last workgroup)
+    }
+#pragma unroll
+    for (int st = 0; st < SETS; ++st) {
+        const int ctile = wave * SETS + st;
+        const int ncol = col0 + ctile * 32 + (lane & 31);
+        const bool live = ctile < tiles_per_wg;           // uniform
         // planes past this workgroup's tables (the tail of its last tile) belong to the next one
-        const float wn = (live && ncol < KL && ncol - col0 < tables_per_wg * K) ? wnorm[ncol] * SH_EPS : -1.f;
-        if (lane < 32) s_wn[ctile][lane] = wn;
+        const float wn = (live && ncol < KL && ncol - col0 < tables_per_wg * K) ? wn_s[st] * SH_EPS : -1.f;
+        // lane l < 32 knows whether plane l of the tile is ours; a lane's accumulator i is plane (i & 3) + 8 (i >> 2) +
+        // 4 (lane >> 5): gather those 16 bits out of the tile's 32-bit validity word
+        const uint32_t vw = (uint32_t)__ballot(wn >= 0.f);              // (both half-waves hold the same 32 planes)
+        uint32_t mbits = 0u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mbits |= ((vw >> ((i & 3) + 8 * (i >> 2) + 4 * (lane >> 5))) & 1u) << i;
+        mine[st] = mbits;
         const float w16 = row16_max_nonneg(fmaxf(wn, 0.f));
         const float wmax = __int_as_float(max(__builtin_amdgcn_readlane(__float_as_int(w16), 0),
                                               __builtin_amdgcn_readlane(__float_as_int(w16), 16)));
@@ -398,22 +414,29 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
                 const auto sw = __builtin_amdgcn_permlane32_swap(w, w, false, false);   // the other half-wave's 16 planes
                 w = sw[0] | sw[1];
                 if (lane < 32) s_rowbits[(t * SH_ROWS + lane) * BW + ctile] = w;
-                if (amin <= wcoarse[st] * rn) {           // rare: this lane looks at its 16 values one by one
+                // Guard band, tested against the widest band of the tile's planes (plane norms differ by a few per cent: a
+                // handful of candidates more, each decided exactly at the end).  NOT rare per wave: one lane in ~450 holds
+                // a candidate, so one wave-tile in seven runs this block -- it must not wait for anything: round 4's form
+                // read every plane's own band from LDS inside the loop (16 dependent LDS round trips, ~2 500 cycles per
+                // execution, half a tile's time on average).  Which of a lane's 16 planes belong to this workgroup at all
+                // (the last tile's tail, Wt's zero padding) is a per-lane bit mask made once, `mine`.
+                const float thr = wcoarse[st] * rn;
+                if (amin <= thr) {
                     const int64_t gr = row_base + (int64_t)t * SH_ROWS + (lane & 31);
                     // plane offset of accumulator i inside the workgroup's span: pb + (i & 3) + 8 (i >> 2).  Opaque to the
                     // optimiser on purpose: as a loop invariant it hoisted all 16 SETS sums out of the tile loop -- 64
-                    // registers for a path that is almost never taken, spilled to scratch
+                    // registers, spilled to scratch
                     int pb = ctile * 32 + 4 * (lane >> 5);
                     asm volatile("" : "+v"(pb));
-                    const float* wn_flat = &s_wn[0][0];
+                    const uint32_t ok = gr < n ? mine[st] : 0u;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const int po = pb + (i & 3) + 8 * (i >> 2);
                         // guard-band candidate: queue (chunk row, plane offset) for the exact pass at the end
-                        if (gr < n && fabsf(acc[u][i]) <= wn_flat[po] * rn) {
+                        if (((ok >> i) & 1u) && fabsf(acc[u][i]) <= thr) {
                             const int slot = atomicAdd(&s_qn, 1);
                             if (slot < SK_QCAP)
-                                s_queue[slot] = ((uint32_t)(t * SH_ROWS + (lane & 31)) << 16) | (uint32_t)po;
+                                s_queue[slot] = ((uint32_t)(t * SH_ROWS + (lane & 31)) << 16) |
+                                                (uint32_t)(pb + (i & 3) + 8 * (i >> 2));
                         }
                     }
                 }
