@@ -166,6 +166,8 @@ def parse():
                     help="A/B: hyperplanes split over the workgroups of a head's cluster (0 never, 1 always; default: auto)")
     ap.add_argument("--direct-slots", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="A/B: direct piece slots: 0 never, 1 always (where R > 1); default: auto")
+    ap.add_argument("--slot-log2", type=int, default=0, choices=[0, 3, 4, 5],
+                    help="A/B: width of the direct slots forced to 32 / 64 / 128 bytes (default: by the mean piece length)")
     ap.add_argument("--kn-payload", type=int, default=-1, choices=[-1, 0, 1],
                     help="A/B: key norms as a payload of the table entries (default: the library's choice)")
     ap.add_argument("--mfma-hash", action="store_true",
@@ -784,6 +786,8 @@ def main():
         L.set_option("decode_cluster", args.cluster)
     if args.split_hash >= 0:
         L.set_option("decode_split_hash", args.split_hash)
+    if args.slot_log2:
+        L.set_option("decode_slot_log2", args.slot_log2)
     if args.no_direct_slots:
         L.set_option("decode_direct", 0)
     elif args.direct_slots >= 0:

@@ -250,6 +250,10 @@ int mp_debug_xcd_round_robin(void);
  *   "decode_direct"      -1 = auto, 0 = never, 1 = always (where R > 1): keep direct slots (length, position + the first
  *                        ids: 128, 64 or 32 bytes by the mean piece length) for every (table, bucket, token range)
  *                        piece; read by mp_lsh_alloc
+ *                        (2 = also at R = 1, one workgroup per head: measured -0.5 us of 28.9 per layer at cfg 3 for
+ *                        +1.26 GB per layer, not taken by default)
+ *   "decode_slot_log2"   0 = slot width by the mean piece length (default), 3 / 4 / 5 = 32- / 64- / 128-byte slots forced;
+ *                        process-wide, read at alloc, table build and launch: set it before the handles are allocated
  *   "attn_head_kernel"   -1 = auto, 0 = split-KV kernel with the in-launch ticket merge, 1 = one workgroup per head
  *   "attn_gx"            0 = auto, n = split-KV workgroups per head
  *   "attn_dense_grouped" 1 = mp_attn_full reads K/V once per kv group (default), 0 = once per query head

@@ -33,6 +33,7 @@ hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, co
                              const unsigned int*, hipStream_t);
 hipError_t set_stamp_stride(int);
 void set_exact_norm(int);
+void set_slot_log2(int);
 hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, int, int64_t, hipStream_t);
 int lsh_slot_log2(int64_t M, int NB, int R);
 hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
@@ -1506,6 +1507,10 @@ int mp_debug_set_option(const char* name, int value) {
     }
     if (name && !strcmp(name, "simhash_exact_norm")) {   // 1: the fused hash normalises the query row by the exact sequence always
         set_exact_norm(value);
+        return MP_OK;
+    }
+    if (name && !strcmp(name, "decode_slot_log2")) {     // 3 / 4 / 5: 32- / 64- / 128-byte direct slots whatever the mean piece; 0 = auto.
+        set_slot_log2(value);                            // Process-wide and read at alloc, build and launch: set it before the handles exist
         return MP_OK;
     }
     std::atomic<int>* o = debug_option(name);

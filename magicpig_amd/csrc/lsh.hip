@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void lsh_slots_kernel(const int32_t* __restric
     int32_t* s = slots + row * NB * R * SW;
     const int sl = threadIdx.x & (SW - 1);
     const int gpb = 256 >> swl;                          // groups of SW lanes per block: one group writes a slot
-    constexpr int U = 4;                                 // pieces in flight per group
+    constexpr int U = 8;                                 // pieces in flight per group (round 5: 4 -> 8, stores non-temporal)
     const int total = NB * R;
     for (int p0 = (blockIdx.x * gpb + (threadIdx.x >> swl)) * U; p0 < total; p0 += gridDim.x * gpb * U) {
         int lo[U], hi[U], v[U];
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256) void lsh_slots_kernel(const int32_t* __restric
             else if (sl - 2 < hi[u] - lo[u]) v[u] = t[lo[u] + sl - 2];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (p0 + u < total) s[(int64_t)(p0 + u) * SW + sl] = v[u];
+        for (int u = 0; u < U; ++u)      // 1.26 GB per layer at cfg 1, written once, read by the decode launches much later
+            if (p0 + u < total) __builtin_nontemporal_store(v[u], s + (int64_t)(p0 + u) * SW + sl);
     }
 }
 
@@ -339,7 +339,7 @@ __device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ 
 // between barriers (count, scan, rank, write out); with one workgroup per CU nothing filled the waits, and a launch of
 // 1 200 rows ran in five rounds of 256 (cfg 4: 300 rows in two rounds, the second 17 % full).
 template <int TPL, bool PACK = false>   // tokens per lane and tile: T = TPL * blockDim.x
-__global__ __launch_bounds__(1024) void lsh_build_kernel(
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsh_build_kernel(   // 16 waves per CU either way: 128 VGPRs
     const int16_t* __restrict__ codes,   // [Hkv*L][n] unsorted
     int n, int NB, int nbits, int64_t M, int RS, int32_t* __restrict__ bounds, int32_t* __restrict__ table,
     int* __restrict__ err,
@@ -413,9 +413,10 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
         for (int base = 0; base < NB; base += blockDim.x) {
             const int i = base + tid;
             int v = 0;
-            int cw[16];                                   // the waves' counts of bucket i: ONE batch of LDS reads
+            constexpr int NWX = PACK ? 8 : 16;            // waves per workgroup, at most (PACK is launched with eight)
+            int cw[NWX];                                  // the waves' counts of bucket i: ONE batch of LDS reads
 #pragma unroll
-            for (int w = 0; w < 16; ++w) {
+            for (int w = 0; w < NWX; ++w) {
                 cw[w] = (i < NB && w < nw) ? (PACK ? (int)s_cnt16[w * NB + i] : s_cnt[w * NB + i]) : 0;
                 v += cw[w];
             }
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
             if (i < NB) {
                 int run = ex;
 #pragma unroll
-                for (int w = 0; w < 16; ++w) {
+                for (int w = 0; w < NWX; ++w) {
                     if (w < nw) {
                         if (PACK) s_cnt16[w * NB + i] = (uint16_t)run;      // (a 16-bit store: the neighbour's half is another thread's)
                         else s_cnt[w * NB + i] = run;
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(1024) void lsh_build_kernel(
             }
             if (refused) atomicOr(bad + row / L, 1);
         } else {
-            constexpr int OB = 8;                                // entries per batch (TPL is 8 or 16)
+            constexpr int OB = TPL >= 16 ? 4 : 8;                // entries per batch (TPL is 8 or 16; 16 keeps two sets of codes in registers)
             const float* knr = kn ? kn + (row / L) * M : nullptr;    // a tile's 8 192 norms: 32 KB, read once per table row
             bool refused = false;
 #pragma unroll
@@ -1782,7 +1783,10 @@ hipError_t launch_lsh_subbounds(const int32_t* table, int32_t* bounds, int rows,
 // words per direct slot (log2) for a head split over R token ranges: 128-byte slots (30 ids) while the mean piece
 // M / (NB R) is above 5 ids, 64-byte slots (14 ids) above 2.5, 32-byte slots (6 ids) below -- a slot should hold a piece
 // of ~2.5x the mean (SimHash buckets are wider than Poisson: p99 of a probed piece at cfg 1 is 2.3x its mean)
+static int g_slot_log2 = 0;   // mp_debug_set_option("decode_slot_log2"): 3 / 4 / 5 forces 32- / 64- / 128-byte slots (A/B), 0 = by the mean piece
+void set_slot_log2(int v) { g_slot_log2 = (v >= 3 && v <= 5) ? v : 0; }
 int lsh_slot_log2(int64_t M, int NB, int R) {
+    if (g_slot_log2) return g_slot_log2;
     const double mean = (double)M / ((double)NB * (double)R);
     return mean > 5.0 ? 5 : (mean > 2.5 ? 4 : 3);
 }

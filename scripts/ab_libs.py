@@ -26,7 +26,8 @@ def worker_cmd(cfg, lib, data, steps, warmup):
     """`lib` = a build (product | variant name | path), optionally followed by `@` and comma-separated extra bench.py
     arguments for that side (round 5: settings read at alloc time, e.g. product@--direct-slots=1 against product)."""
     lib, _, extra = lib.partition("@")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--data", data, "--steps", str(steps),
+    cfg_args = ["--config-json", cfg] if cfg.lstrip().startswith("{") else ["--config", cfg]      # a shape as JSON works too
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *cfg_args, "--data", data, "--steps", str(steps),
            "--warmup", str(warmup), "--ab-worker", "--no-cpu-baseline", "--no-host-mode", "--no-clustered-leg"]
     p = lib_path(lib)
     return cmd + (["--lib", p] if p else []) + [a for a in extra.split(",") if a]
