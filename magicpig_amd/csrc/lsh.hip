@@ -94,6 +94,14 @@ constexpr int RT_GROUP = 12;               // buckets in flight per wave per rou
 #ifndef MP_SETPRIO_WAVE0
 #define MP_SETPRIO_WAVE0 0                 // s_setprio 3 on wave 0 while it normalises the query row (A/B)
 #endif
+#ifndef MP_LDS_BARRIERS
+#define MP_LDS_BARRIERS 1                  // round 5: the barriers of the decode chain that protect LDS data only wait for LDS only
+#endif                                     // (__syncthreads() also waits for vmcnt(0): the acknowledgement of every by-product
+#if MP_LDS_BARRIERS                        // store -- codes, result rows -- issued in front of it); A/B: -DMP_LDS_BARRIERS=0
+#define MP_CHAIN_BARRIER() lds_barrier()
+#else
+#define MP_CHAIN_BARRIER() __syncthreads()
+#endif
 #ifndef MP_STREAM_ONE_TRIP
 #define MP_STREAM_ONE_TRIP 1               // sub-bounds path: every load of a wave's pieces in ONE round trip (A/B: -DMP_STREAM_ONE_TRIP=0)
 #endif
@@ -1157,7 +1165,7 @@ __device__ __forceinline__ void lsh_head_body(
         else if (L > RT_WAVES * 2 * 6) direct_pass(std::integral_constant<int, 10>{}, std::integral_constant<int, 5>{});
         else direct_pass(std::integral_constant<int, 6>{}, std::integral_constant<int, 5>{});
         MP_STAMP(stamp, 45);                                            // this wave's pieces counted
-        __syncthreads();
+        MP_CHAIN_BARRIER();
         MP_STAMP(stamp, 17);
         if (s_tmp[30] > 0) {                                            // uniform; pieces longer than 30 + 96 ids
             for (int l = tid; l < L; l += RT_THREADS) {
@@ -1202,7 +1210,7 @@ __device__ __forceinline__ void lsh_head_body(
                 s_tail[base + c] = ((uint32_t)l << 16) | (uint32_t)(c + 2);
         }
     }
-    __syncthreads();
+    MP_CHAIN_BARRIER();
     MP_STAMP(stamp, 17);
     MP_STAMP(stamp, 18);
 
@@ -1356,7 +1364,7 @@ __device__ __forceinline__ void lsh_head_body(
         }
     }
     // (direct pass without pooled chunks: nothing was counted since the barrier behind the pass)
-    if (!(AD > 0 && HASH != 0 && slots != nullptr && ntail == 0)) __syncthreads();
+    if (!(AD > 0 && HASH != 0 && slots != nullptr && ntail == 0)) MP_CHAIN_BARRIER();
     MP_STAMP(stamp, 19);
 
     // sweep B: contiguous words per thread, block-wide exclusive scan, ascending emission
@@ -1370,7 +1378,7 @@ __device__ __forceinline__ void lsh_head_body(
     for (int k = 0; k < wpt; ++k)
         if (w0 + k < nsw) cnt += __popc(bmB[w0 + k]);
     int total;
-    int off = block_excl_scan(cnt, s_tmp, total);
+    int off = block_excl_scan<MP_LDS_BARRIERS != 0>(cnt, s_tmp, total);
     MP_STAMP(stamp, 20);
     // AD: the member's ids stay in LDS; a list longer than the stage (cap ids) is read back from HBM
     const bool spill = AD > 0 && total > aa.cap;
@@ -1433,7 +1441,11 @@ __device__ __forceinline__ void lsh_head_body(
         MP_STAMP_FLUSH(stamp);
         return;
     }
-    __syncthreads();                        // s_ids complete; the spilled list drained (vmcnt) and visible in L2
+    // s_ids complete.  Only a SPILLED list is read back from HBM by other waves (ids_hbm): only then must the stores have
+    // drained (vmcnt) and be visible in L2; otherwise the barrier orders LDS alone -- the by-product rows' stores are
+    // acknowledged ~0.5 us after they were issued, and this barrier sits on the path to the first row request
+    if (spill || !MP_LDS_BARRIERS) __syncthreads();
+    else lds_barrier();
     MP_STAMP(stamp, 33);
     // two instantiations of the sparse fold: the LDS path carries no global load ahead of its gathers
     float m, Z, o0, o1;
