@@ -303,11 +303,13 @@ __device__ __forceinline__ unsigned long long match_any_bits(int v, bool ok, int
 template <typename F>
 __device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ c, int n, int NB,
                                                     int* s_cnt, int* s_tmp, int32_t* __restrict__ b, int RS,
-                                                    int* __restrict__ err, F&& start_of) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+                                                    int* __restrict__ err, F&& start_of, int copies = 0) {
+    // copies: sets of counters [copies][NB] the waves are spread over (0 = one per wave)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nw = copies > 0 ? copies : (int)(blockDim.x >> 6);
     for (int i = tid; i < nw * NB; i += blockDim.x) s_cnt[i] = 0;
     __syncthreads();
-    int* mine = s_cnt + wave * NB;
+    int* mine = s_cnt + (wave % nw) * NB;
     bool bad = false;
 #pragma unroll 4
     for (int k = tid; k < n; k += blockDim.x) {
@@ -340,10 +342,11 @@ __device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ 
 }
 
 // LDS: cnt [nw][NB] | gbase [NB] | gdelta [NB] | s_tmp [32] | stage_id [T] | stage_b [T] (u16)
-// PACK (round 5, NB <= 1024: the BASELINE configurations at K = 10): the tile's per-wave counters are 16 bits wide, two to
-// a word -- a tile holds at most T = 8 192 tokens, so a count or a cursor never carries into its neighbour -- and the row
-// histogram's 32-bit counters (whole-row counts) borrow the stage, which is idle during that pass: 72 KB per workgroup
-// of eight waves instead of 123 KB for sixteen, so TWO workgroups share a CU.  The tile loop is a chain of short phases
+// PACK (round 5, NB <= 2048: the BASELINE configurations, K = 10 and 11): the tile's per-wave counters are 16 bits wide,
+// two to a word -- a tile holds at most T = 8 192 tokens, so a count or a cursor never carries into its neighbour -- and
+// the row histogram (whole-row counts: 32 bits) uses the same words as nw / 2 sets of counters, two waves to a set: 72 KB
+// per workgroup of eight waves (NB = 1024: T = 8 192; NB = 2048: T = 4 096) instead of 123 - 128 KB, so TWO workgroups
+// share a CU.  The tile loop is a chain of short phases
 // between barriers (count, scan, rank, write out); with one workgroup per CU nothing filled the waits, and a launch of
 // 1 200 rows ran in five rounds of 256 (cfg 4: 300 rows in two rounds, the second 17 % full).
 template <int TPL, bool PACK = false>   // tokens per lane and tile: T = TPL * blockDim.x
@@ -369,10 +372,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int64_t row = blockIdx.x;
     const int16_t* c = codes + row * n;
     int32_t* dst = table + row * M;
-    // (PACK: the whole-row histogram counts up to n per bucket -- 32-bit counters [nw][NB], in the stage's T words; the
-    // host launches PACK only where nw * NB <= T)
-    build_row_histogram(c, n, NB, PACK ? s_id : s_cnt, s_tmp, bounds + row * NB * RS, RS, err,
-                        [&](int i, int ex, int) { s_gbase[i] = ex; });
+    // (PACK: the whole-row histogram counts up to n per bucket -- 32-bit counters, nw / 2 sets in the nw * NB / 2 words)
+    build_row_histogram(c, n, NB, s_cnt, s_tmp, bounds + row * NB * RS, RS, err,
+                        [&](int i, int ex, int) { s_gbase[i] = ex; }, PACK ? nw / 2 : 0);
     int* mine = s_cnt + wave * NB;                            // (not PACK)
     const int wbase = wave * NB;                              // PACK: this wave's counters are cnt16[wbase + v]
     auto count_add = [&](int v, int k) -> int {               // += k on this wave's counter of bucket v; returns the old value
@@ -1833,14 +1835,13 @@ hipError_t launch_lsh_unsort(const int16_t* codes, const int32_t* ids, int rows,
 static bool build_staged_geometry(int NB, int& nw, int& tpl, size_t& lds, bool& pack) {
     pack = false;
     if (NB <= 1024)      { nw = 8;  tpl = 16; pack = true; }      // 72 KB: two workgroups per CU (16-bit tile counters)
-    else if (NB <= 2048) { nw = 8;  tpl = 16; }
+    else if (NB <= 2048) { nw = 8;  tpl = 8;  pack = true; }      // 72 KB with tiles of 4 096 tokens
     else if (NB <= 4096) { nw = 4;  tpl = 32; }
     else if (NB <= 8192) { nw = 2;  tpl = 32; }
     else return false;
     const size_t T = (size_t)tpl * 64 * nw;
-    // PACK: nw * NB 16-bit counters; the row histogram's nw * NB 32-bit counters sit in the stage's T words
+    // PACK: nw * NB 16-bit counters (the row histogram's 32-bit counters: nw / 2 sets in the same words)
     lds = ((pack ? (size_t)nw * NB / 2 : (size_t)nw * NB) + 2 * (size_t)NB + 32 + T) * 4 + T * 2;
-    if (pack && (size_t)nw * NB > T) return false;
     return lds <= 160u * 1024u;
 }
 
@@ -1853,7 +1854,7 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     static DeviceOnce once;
     const hipError_t attr_err = once.run([] {
         const void* fns[] = {reinterpret_cast<const void*>(lsh_build_kernel<16, true>),
-                             reinterpret_cast<const void*>(lsh_build_kernel<16>),
+                             reinterpret_cast<const void*>(lsh_build_kernel<8, true>),
                              reinterpret_cast<const void*>(lsh_build_kernel<32>),
                              reinterpret_cast<const void*>(lsh_build_direct_kernel)};
         for (const void* f : fns) {
@@ -1875,7 +1876,7 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
         if (tpl == TPL && pack == PK)                                                                  \
             hipLaunchKernelGGL((lsh_build_kernel<TPL, PK>), dim3(rows), dim3(64 * nw), lds, st, codes, \
                                (int)n, NB, nbits, M, RS, bounds, table, err, kn, L, idbits, bad);
-        MP_BUILD_CASE(16, true) MP_BUILD_CASE(16, false) MP_BUILD_CASE(32, false)
+        MP_BUILD_CASE(16, true) MP_BUILD_CASE(8, true) MP_BUILD_CASE(32, false)
 #undef MP_BUILD_CASE
         if (packed) *packed = kn != nullptr;
         return hipGetLastError();
