@@ -41,7 +41,7 @@ hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, in
 hipError_t launch_lsh_unsort(const int16_t*, const int32_t*, int, int64_t, int16_t*, int*, hipStream_t);
 hipError_t launch_lsh_subbounds(const int32_t*, int32_t*, int, int, int, int64_t, int, hipStream_t);
 hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int, int32_t*, int32_t*, int*, const float*, int,
-                            int, int*, bool*, hipStream_t);
+                            int, int*, bool*, bool*, hipStream_t);
 hipError_t launch_lsh_retrieve(const int32_t*, const int32_t*, const int32_t*, int32_t*, int32_t*, int,
                                int, int, int, int64_t, int, const int*, int32_t*, int32_t*, uint32_t*, hipStream_t);
 hipError_t launch_lsh_attach_norms(int32_t*, const float*, int, int, int64_t, int, int*, hipStream_t);
@@ -781,7 +781,7 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
         MP_HIP_CHECK(hipMemsetAsync(tok.p, 0xff, (size_t)rows * n * 2, st));      // code -1: a token no id named
         MP_HIP_CHECK(launch_lsh_unsort((const int16_t*)c, (const int32_t*)i, rows, n, tok.as<int16_t>(), h->err, st));
         MP_HIP_CHECK(launch_lsh_build(tok.as<int16_t>(), rows, n, h->NB, h->M, h->R, b, t, h->err, nullptr, h->L, 0,
-                                      nullptr, nullptr, st));
+                                      nullptr, nullptr, nullptr, st));
         // an id outside [0, n) is flagged by the unsort, a token missing from the id list shows up as code -1
         if (lsh_read_err(h, st, "mp_lsh_fill") != MP_OK)
             return fail(MP_ERR_DATA, "mp_lsh_fill: a bucket's ids do not ascend (unstable sort) and the ids of a row are "
@@ -1617,9 +1617,10 @@ static int lsh_build_entry(mp_lsh_t* h, mp_attn_t* attn, int layer_id, int reque
             kn = attn->kn[layer_id] + (size_t)request_id * attn->Hkv * attn->M;
     }
     if (kn != nullptr) MP_HIP_CHECK(hipMemsetAsync(flag, 0, (size_t)h->Hkv * 4, st));
-    bool packed = false;
-    MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, h->R, b, t, h->err, kn, h->L, 17, flag, &packed, st));
-    MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, packed ? 17 : 0, st));
+    bool packed = false, cut = false;
+    MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, h->R, b, t, h->err, kn, h->L, 17, flag, &packed, &cut, st));
+    // (the staged build writes the sub-bounds itself, round 5; the direct variant for K >= 14 leaves them to the search)
+    if (!cut) MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, packed ? 17 : 0, st));
     if (!h->slots.empty())
         MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * h->slot_words, rows,
                                       h->NB, h->R, h->M, st));

@@ -358,7 +358,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     // is written as  id | bf16 bits 14..0 of the token's norm << idbits  in the SAME pass -- what lsh_attach_norms_kernel
     // does to a finished table (a second sweep over 472 MB at cfg 1, plus a second build of the direct slots) when the
     // first decode finds plain ids.  bad[kv head] is set for a norm that is not a non-negative bf16 number.
-    const float* __restrict__ kn, int L, int idbits, int* __restrict__ bad) {
+    const float* __restrict__ kn, int L, int idbits, int* __restrict__ bad,
+    // round 5: the sub-bounds (entries 1 .. R-1 of a bucket's record: first position whose token id >= r * range_len) are
+    // written HERE -- tiles never straddle a range boundary, so when the tile that starts at token r * range_len begins,
+    // a bucket's running write position IS its sub-bound r.  lsh_subbounds_kernel did it afterwards by 7 (R - 1) binary
+    // searches per bucket over a 472-MB table that had left the L2: 196 dependent HBM reads per thread, 0.19 ms per layer
+    // at cfg 1 and 0.30 at cfg 4.  range_len = 0: leave the entries to that kernel.
+    int range_len) {
     extern __shared__ int s_mem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int T = TPL * blockDim.x;
@@ -374,7 +380,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     int32_t* dst = table + row * M;
     // (PACK: the whole-row histogram counts up to n per bucket -- 32-bit counters, nw / 2 sets in the nw * NB / 2 words)
     build_row_histogram(c, n, NB, s_cnt, s_tmp, bounds + row * NB * RS, RS, err,
-                        [&](int i, int ex, int) { s_gbase[i] = ex; }, PACK ? nw / 2 : 0);
+                        [&](int i, int ex, int v) { s_gbase[i] = v > 0 ? ex : -1; },   // -1: a bucket without tokens (it
+                        PACK ? nw / 2 : 0);                                             // never moves: every tile adds 0)
     int* mine = s_cnt + wave * NB;                            // (not PACK)
     const int wbase = wave * NB;                              // PACK: this wave's counters are cnt16[wbase + v]
     auto count_add = [&](int v, int k) -> int {               // += k on this wave's counter of bucket v; returns the old value
@@ -399,7 +406,27 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     constexpr bool PREFETCH = TPL < 32;                       // (32 codes per lane: no registers for a second set)
     int vq[TPL], vnext[PREFETCH ? TPL : 1];
     if (PREFETCH) load_codes(0, vq);
-    for (int t0 = 0; t0 < n; t0 += T) {
+    const int R = RS - 1;
+    int32_t* brow = bounds + row * NB * RS;
+    // sub-bound r of every bucket <- its running write position (0 for a bucket without tokens, as the search gives it)
+    auto dump_subbound = [&](int r) {
+        for (int i = tid; i < NB; i += blockDim.x) {
+            const int g = s_gbase[i];
+            brow[i * RS + r] = g < 0 ? 0 : g;
+        }
+    };
+    const bool cuts = TPL < 32 && range_len > 0 && R > 1;     // uniform (the 32-codes-per-lane form, K = 12 / 13, has no
+                                                              // register to spare: its sub-bounds stay with the search kernel)
+    int t0 = 0;
+    while (t0 < n) {
+        // the tile: [t0, tend), at most T tokens, never across a range boundary
+        int tend = t0 + T;
+        if (cuts) {
+            const int nb = (t0 / range_len + 1) * range_len;   // the next boundary behind t0
+            tend = tend < nb ? tend : nb;
+            if (t0 > 0 && t0 % range_len == 0 && t0 / range_len <= R - 1) dump_subbound(t0 / range_len);
+        }
+        tend = tend < n ? tend : n;
         if (!PREFETCH) load_codes(t0, vq);
         // this wave's slice of the tile: tokens w0 + j*64 + lane, j < TPL, kept in registers
         const int w0 = t0 + wave * (WAVE * TPL);
@@ -408,14 +435,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         for (int j = 0; j < TPL; ++j) {
             const int kk = w0 + j * WAVE + lane;
             const int v = vq[j];
-            vq[j] = (kk < n && v >= 0 && v < NB) ? v : -1;
+            vq[j] = (kk < tend && v >= 0 && v < NB) ? v : -1;
         }
         lds_barrier();
 #pragma unroll
         for (int j = 0; j < TPL; ++j)
             if (vq[j] >= 0) (void)count_add(vq[j], 1);
         if constexpr (PREFETCH) {
-            if (t0 + T < n) load_codes(t0 + T, vnext);         // uniform; consumed by the next iteration
+            if (tend < n) load_codes(tend, vnext);             // uniform; consumed by the next iteration
         }
         lds_barrier();
         // per-wave cursors inside the tile's sorted order; where the tile's run of a bucket goes
@@ -528,6 +555,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
             for (int j = 0; j < TPL; ++j) vq[j] = vnext[j];
         }
+        t0 = tend;
+    }
+    if (cuts) {   // boundaries at or behind the last token: the bucket's end (its final write position)
+        lds_barrier();                                         // (the last tile's s_gbase)
+        for (int r = (n + range_len - 1) / range_len; r <= R - 1; ++r)
+            if (r >= 1) dump_subbound(r);
     }
 }
 
@@ -1849,8 +1882,9 @@ static bool build_staged_geometry(int NB, int& nw, int& tpl, size_t& lds, bool& 
 // kn != nullptr: the packed build (only the staged kernels pack; *packed says whether they ran)
 hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, int64_t M, int R,
                             int32_t* bounds, int32_t* table, int* err, const float* kn, int L, int idbits, int* bad,
-                            bool* packed, hipStream_t st) {
+                            bool* packed, bool* subbounds_done, hipStream_t st) {
     if (packed) *packed = false;
+    if (subbounds_done) *subbounds_done = false;
     static DeviceOnce once;
     const hipError_t attr_err = once.run([] {
         const void* fns[] = {reinterpret_cast<const void*>(lsh_build_kernel<16, true>),
@@ -1875,10 +1909,12 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
 #define MP_BUILD_CASE(TPL, PK)                                                                         \
         if (tpl == TPL && pack == PK)                                                                  \
             hipLaunchKernelGGL((lsh_build_kernel<TPL, PK>), dim3(rows), dim3(64 * nw), lds, st, codes, \
-                               (int)n, NB, nbits, M, RS, bounds, table, err, kn, L, idbits, bad);
+                               (int)n, NB, nbits, M, RS, bounds, table, err, kn, L, idbits, bad,       \
+                               R > 1 ? lsh_range_len(M, R) : 0);
         MP_BUILD_CASE(16, true) MP_BUILD_CASE(8, true) MP_BUILD_CASE(32, false)
 #undef MP_BUILD_CASE
         if (packed) *packed = kn != nullptr;
+        if (subbounds_done) *subbounds_done = tpl < 32;        // (R = 1 has none; R > 1: written by the kernel itself)
         return hipGetLastError();
     }
     nw = BUILD_LDS_COUNTERS / NB;
