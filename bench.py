@@ -754,7 +754,8 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: start it as `python bench.py --gpus N` or under "
                  "`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (one rank per GPU)")
     if args.shard is None:     # cfg 4 IS the TP = 8 layout of the 70B model: on several GPUs its kv heads are what is sharded
-        args.shard = "head" if (args.config == "cfg4" and world > 1) else "batch"
+        emu_world = int(args.emulate_rank.split("/")[1]) if args.emulate_rank else 1
+        args.shard = "head" if (args.config == "cfg4" and max(world, emu_world) > 1) else "batch"
     if args.dry_run:
         return dry_run(args, rank, world)
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0

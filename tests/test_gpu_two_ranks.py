@@ -36,7 +36,7 @@ def _bench(extra, nproc=1, timeout=1500):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     base = [os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-host-mode",
-            "--no-clustered-leg"] + extra
+            "--no-clustered-leg", "--no-legs"] + extra
     if nproc == 1:
         cmd = [sys.executable] + base + ["--gpus", "1"]
     else:
@@ -79,3 +79,38 @@ def test_emulated_ranks_partition_the_single_process_result():
     # additivity of the int16 checksum: sum over heads of the full run == sum of the two halves
     s = lambda o: o["head_shard_gather"]["checksum"]          # noqa: E731
     assert s(outs["full"]) == s(outs["r0"]) + s(outs["r1"])
+
+
+def _plain(extra, timeout=1500):
+    """bench.py started PLAINLY -- no launcher, no RANK / WORLD_SIZE in the environment -- as the round-end driver starts it."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-host-mode",
+           "--no-clustered-leg", "--no-legs"] + extra
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="no GPU")
+def test_plain_start_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` on a node with fewer than N GPUs must not print a line labelled with
+    fewer -- it ends with a message and a non-zero status.  Runs on every GPU box (one more rank than there are GPUs)."""
+    n = torch.cuda.device_count() + 1
+    r = _plain(["--gpus", str(n), "--config", "cfg0"], timeout=300)
+    assert r.returncode != 0 and f"--gpus {n} asked for" in r.stderr and not [x for x in r.stdout.splitlines() if x.startswith("{")]
+
+
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs >= 2 GPUs")
+def test_plain_start_runs_two_ranks_over_rccl():
+    """`python bench.py --gpus 2` with a clean environment re-executes itself under torch.distributed.run: two processes, two
+    devices, `nccl x2`, one checksum per rank equal to the emulated single-process run of that rank's units; cfg 4 shards
+    the model's kv heads by default (strong scaling)."""
+    two = _line(_plain(["--gpus", "2", "--config", "cfg3"]))
+    assert two["n_gpus"] == 2 and two["config"]["process_group"] == "nccl x2" and len(two["rank_checksums"]) == 2
+    assert two["config"]["global_batch"] == 16 and two["scaling"] == "weak"
+    for r in range(2):
+        one = _bench(["--config", "cfg3", "--shard", "batch", "--emulate-rank", f"{r}/2"])
+        assert one["rank_checksums"] == [two["rank_checksums"][r]], r
+    four = _line(_plain(["--gpus", "2", "--config", "cfg4"]))
+    assert four["scaling"] == "strong" and four["config"]["process_group"] == "nccl x2"
+    assert four["head_shard_gather"]["shape"] == [1, 64, 128]

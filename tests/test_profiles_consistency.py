@@ -64,3 +64,28 @@ def test_bench_lines_close(path):
         m = re.search(r"\|\s*void mp::lsh_decode_kernel[^|]*\|\s*\d+\s*\|\s*([\d.]+)\s*\|", stats)
         assert m and abs(float(m.group(1)) - r["avg_launch_us"]) <= 0.03 * r["avg_launch_us"], (m and m.group(1), r["avg_launch_us"])
         assert key and cfg
+
+
+def test_default_line_carries_the_other_configurations():
+    """the default single-GPU line (what the round-end driver runs) holds a second and a third
+    CONFIGURATION -- cfg 2 and cfg 4's per-GPU share -- each with its own roofline arithmetic, footprint and the
+    full-size first layer against the CPU path; the HBM footprint of the headline configuration; no failed leg."""
+    path = os.path.join(PROF, f"{_latest_tag()}_bench_driver_style.json")
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    assert "cfg1" in d["config"]["workload"] and d["n_gpus"] == 1 and "failed_legs" not in d
+    legs = d["legs"]
+    assert set(legs) == {"cfg2", "cfg4_share"}
+    for name, leg in legs.items():
+        r = leg["roofline"]
+        assert abs(r["achieved"] - r["bytes_per_launch"] / r["avg_launch_us"] / 1e3) <= 1e-6 * r["achieved"], name
+        assert abs(r["frac"] - r["achieved"] / 8000.0) <= 1e-9, name
+        assert leg["tokens_per_s"] > 0 and abs(leg["us_per_layer"] * 1e-3 * (30 if name == "cfg2" else 75) - leg["ms_per_step"]) < 1e-6
+        g = leg["cpu_baseline"]["gpu_matches"]
+        assert g["nnz_equal"] is True and g["max_abs_out_diff"] <= 1e-2, name
+        f = leg["hbm_bytes_per_layer"]
+        assert f["total"] == f["kv"] + f["key_norms"] + f["bounds"] + f["table"] + f["slots"]
+    f1 = d["observed"]["hbm_bytes_per_layer"]
+    assert f1["slots"] == 32 * 1024 * 8 * 150 * 8 * 4 and f1["slot_bytes"] == 128     # cfg 1: 8 kv groups x L x 2^K x R slots of 128 bytes
+    assert legs["cfg2"]["hbm_bytes_per_layer"]["slots"] == 0                             # one workgroup per head: no slots
+    for k in ("host_mode", "host_mode_pinned_results"):
+        assert d[k]["matches_device_entry"] is True and d[k]["attention_calls_served"]["hits"] >= d[k]["reps"]
