@@ -103,7 +103,8 @@ constexpr int RT_GROUP = 12;               // buckets in flight per wave per rou
 #define MP_CHAIN_BARRIER() __syncthreads()
 #endif
 #ifndef MP_STREAM_ONE_TRIP
-#define MP_STREAM_ONE_TRIP 1               // sub-bounds path: every load of a wave's pieces in ONE round trip (A/B: -DMP_STREAM_ONE_TRIP=0)
+#define MP_STREAM_ONE_TRIP 2               // sub-bounds path: both 64-id chunks of every piece of a wave requested together (2);
+                                           // 1 = the pool's first round with them too (measured slower), 0 = round 4's form
 #endif
 // Table-side loads -- direct slots, bucket records, table ids: every line of them is read once per launch, by one CU -- are
 // non-temporal (`nt`: no claim on the L2 the K / V rows and the hyperplanes live in).  Round 4, same instruction schedule with
@@ -1253,16 +1254,18 @@ __device__ __forceinline__ void lsh_head_body(
     // flight, then applies them.  Straight-line rounds: all (start, length) pairs out of LDS, then all loads, then all
     // applies.  As one loop body per piece with the loads under lane-divergent branches the compiler put an
     // s_waitcnt vmcnt(0) between the pieces: two, not twelve, were in flight.
-    // Round 5 -- ONE round trip for the whole stream (MP_STREAM_ONE_TRIP).  Until round 4 the second 64 ids of a piece were
-    // requested only behind the first chunks' applies, and the pooled chunks (ids beyond 128) behind those: SimHash buckets
-    // are wide (p99 of a probed piece = 2.3 x its mean; mean 32 ids at cfg 2 / 3), so ~4 % of the pieces are longer than 64
-    // ids, almost every workgroup holds a wave with such a piece, one in six a pooled chunk -- and the launch waits for the
-    // workgroup that paid THREE dependent round trips between "pieces in" and "counted" (the 4.4 us of VERDICT r04 weak 4).
-    // Now every load of a wave's pieces -- both chunks and its share of the pool's first round -- is issued before anything
-    // is applied.  The loads go through ONE buffer descriptor over the KV group's table rows: a lane past its piece gets
-    // an offset beyond num_records, for which the hardware returns 0 WITHOUT a memory request -- the second-chunk loads
-    // of the 96 % short pieces cost an instruction slot and no line (clamped addresses, the form used where a pointer is
-    // needed, would re-request the piece's first line 12 times per wave).
+    // Round 5 -- both chunks of every piece in ONE round trip (MP_STREAM_ONE_TRIP = 2).  Until round 4 the second 64 ids of a
+    // piece were requested only behind the first chunks' applies: SimHash buckets are wide (p99 of a probed piece = 2.3 x
+    // its mean; mean 32 ids at cfg 2 / 3), so ~4 % of the pieces are longer than 64 ids, almost every workgroup holds a
+    // wave with such a piece, and the launch waits for the workgroup that paid the second dependent round trip.  Now both
+    // chunks of all of a wave's pieces are requested before anything is applied: cfg 3 29.06 -> 28.43 us per layer, cfg 2
+    // 32.36 -> 31.71, cfg 2 on clustered keys 41.42 -> 40.70 (same box, alternating regions: profiles/r05_ab_stream_variants.txt).
+    // The loads go through ONE buffer descriptor over the KV group's table rows: a lane past its piece gets an offset
+    // beyond num_records, for which the hardware returns 0 WITHOUT a memory request -- the second-chunk loads of the 96 %
+    // short pieces cost an instruction slot and no line (clamped addresses, the form used where a pointer is needed,
+    // would re-request the piece's first line 12 times per wave).  Measured and not taken (= 1): the pool's first round
+    // (ids beyond 128) in the same batch -- its descriptors come out of LDS in three dependent reads per chunk, in front of
+    // the applies of everybody's first chunk: cfg 3 28.90, cfg 2 32.07, clustered 41.46 -- no better than round 4's form.
     {
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 #if MP_STREAM_ONE_TRIP
@@ -1298,7 +1301,8 @@ __device__ __forceinline__ void lsh_head_body(
                 id1[b] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(
                     rt, lane + 64 < ln[b] ? (wb[b] + (uint32_t)lane + 64u) << 2 : kOut, 0, kNt);
             // the pool's first round rides along (this wave's chunks wave, wave + 16, ...): descriptors out of LDS
-            const bool tails_now = l0 == wave_s && ntail0 > 0 && ntail0 <= RT_TAIL_CAP;   // uniform
+            const bool tails_now = MP_STREAM_ONE_TRIP == 1 && l0 == wave_s && ntail0 > 0 && ntail0 <= RT_TAIL_CAP;   // uniform
+            // (-DMP_STREAM_ONE_TRIP=2: both chunks of every piece together, the pool behind them as before)
             uint32_t tin = 0u;                                               // per lane: bit u = chunk u holds an id for it
             if (tails_now) {
 #pragma unroll
