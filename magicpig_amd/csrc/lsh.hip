@@ -420,14 +420,26 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                                                               // register to spare: its sub-bounds stay with the search kernel)
     int t0 = 0;
     while (t0 < n) {
-        // the tile: [t0, tend), at most T tokens, never across a range boundary
+        // the tile: [t0, tend), at most T tokens.  A range boundary inside it is taken in the tile's stride where it falls
+        // between two waves' slices (cfg 1: range_len = 12 288 = 12 slices of 1 024): the cursor the scan hands the first
+        // wave behind the boundary IS the bucket's sub-bound -- one store per bucket, no extra tile.  Elsewhere (cfg 4:
+        // range_len = 8 224 against slices of 512) the tile ends at the boundary.
         int tend = t0 + T;
-        if (cuts) {
-            const int nb = (t0 / range_len + 1) * range_len;   // the next boundary behind t0
-            tend = tend < nb ? tend : nb;
-            if (t0 > 0 && t0 % range_len == 0 && t0 / range_len <= R - 1) dump_subbound(t0 / range_len);
-        }
         tend = tend < n ? tend : n;
+        int cut_wave = -1, cut_r = 0;                           // uniform
+        if (cuts) {
+            if (t0 > 0 && t0 % range_len == 0 && t0 / range_len <= R - 1) dump_subbound(t0 / range_len);
+            const int nb = (t0 / range_len + 1) * range_len;   // the next boundary behind t0
+            if (nb < tend) {
+                const int off = nb - t0;
+                if (off % (WAVE * TPL) == 0 && nb + range_len >= tend && nb / range_len <= R - 1) {
+                    cut_wave = off / (WAVE * TPL);
+                    cut_r = nb / range_len;
+                } else {
+                    tend = nb;
+                }
+            }
+        }
         if (!PREFETCH) load_codes(t0, vq);
         // this wave's slice of the tile: tokens w0 + j*64 + lane, j < TPL, kept in registers
         const int w0 = t0 + wave * (WAVE * TPL);
@@ -463,15 +475,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const int ex = block_excl_scan<true>(v, s_tmp, total) + carry;
             if (i < NB) {
                 int run = ex;
+                const int g = s_gbase[i];
 #pragma unroll
                 for (int w = 0; w < NWX; ++w) {
                     if (w < nw) {
                         if (PACK) s_cnt16[w * NB + i] = (uint16_t)run;      // (a 16-bit store: the neighbour's half is another thread's)
                         else s_cnt[w * NB + i] = run;
+                        // the boundary in front of wave w's slice: its cursor, as a position of the row, is the sub-bound
+                        if (w == cut_wave) brow[i * RS + cut_r] = g < 0 ? 0 : run + (g - ex);
                     }
                     run += cw[w];
                 }
-                const int g = s_gbase[i];
                 s_gdelta[i] = g - ex;
                 s_gbase[i] = g + v;
             }
