@@ -372,73 +372,86 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     };
     // MFMA + signs of tile t (LDS half t & 1).  C' = W X^T: lane l holds, for row (l & 31) of the tile, the 16 planes
     // (i & 3) + 8 (i >> 2) + 4 (l >> 5), i = 0 .. 15, of a column tile's 32.
+    // signs + guard band of one column tile's accumulators (the epilogue): ~45 vector instructions and one LDS store
+    auto epilogue = [&](const f32x16& acc, int st, int t, float rn) {
+        const int ctile = wave * SETS + st;
+        // 16 sign bits of this lane's row: b = (b << 1) | sign, last accumulator first, then inverted (bit = acc > 0;
+        // an exact zero is inside every guard band and is decided by the exact pass)
+        uint32_t b = 0u;
+        float amin = 3.0e38f;
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            b = __builtin_amdgcn_alignbit(b, __float_as_uint(acc[i]), 31);
+            amin = fminf(amin, fabsf(acc[i]));
+        }
+        b = ~b;
+        // nibble j of b = planes 8 j + 4 (lane >> 5) + (0 .. 3): nibbles to bytes, the upper half-wave 4 bits up
+        const uint32_t lo = b & 0x0f0fu, hi = (b >> 4) & 0x0f0fu;
+        uint32_t w = __builtin_amdgcn_perm(hi, lo, 0x05010400u) << ((lane >> 5) * 4);
+        const auto sw = __builtin_amdgcn_permlane32_swap(w, w, false, false);   // the other half-wave's 16 planes
+        w = sw[0] | sw[1];
+        if (lane < 32) s_rowbits[(t * SH_ROWS + lane) * BW + ctile] = w;
+        // Guard band, tested against the widest band of the tile's planes (plane norms differ by a few per cent: a
+        // handful of candidates more, each decided exactly at the end).  NOT rare per wave: one lane in ~450 holds
+        // a candidate, so one wave-tile in seven runs this block -- it must not wait for anything: round 4's form
+        // read every plane's own band from LDS inside the loop (16 dependent LDS round trips, ~2 500 cycles per
+        // execution, half a tile's time on average).  Which of a lane's 16 planes belong to this workgroup at all
+        // (the last tile's tail, Wt's zero padding) is a per-lane bit mask made once, `mine`.
+        const float thr = wcoarse[st] * rn;
+        if (amin <= thr) {
+            const int64_t gr = row_base + (int64_t)t * SH_ROWS + (lane & 31);
+            // plane offset of accumulator i inside the workgroup's span: pb + (i & 3) + 8 (i >> 2).  Opaque to the
+            // optimiser on purpose: as a loop invariant it hoisted all 16 SETS sums out of the tile loop -- 64
+            // registers, spilled to scratch
+            int pb = ctile * 32 + 4 * (lane >> 5);
+            asm volatile("" : "+v"(pb));
+            const uint32_t ok = gr < n ? mine[st] : 0u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                // guard-band candidate: queue (chunk row, plane offset) for the exact pass at the end
+                if (((ok >> i) & 1u) && fabsf(acc[i]) <= thr) {
+                    const int slot = atomicAdd(&s_qn, 1);
+                    if (slot < SK_QCAP)
+                        s_queue[slot] = ((uint32_t)(t * SH_ROWS + (lane & 31)) << 16) |
+                                        (uint32_t)(pb + (i & 3) + 8 * (i >> 2));
+                }
+            }
+        }
+    };
+    // MFMA + signs of tile t (LDS half t & 1).  C' = W X^T: lane l holds, for row (l & 31) of the tile, the 16 planes
+    // (i & 3) + 8 (i >> 2) + 4 (l >> 5), i = 0 .. 15, of a column tile's 32.
+    // The row tile's fragments are read from LDS ONCE (KSTEPS x 16 bytes per lane: 32 VGPRs) and the SETS column tiles
+    // follow one another on two alternating accumulators: the eight MFMAs of tile st -- a dependent chain, each waiting
+    // ~32 cycles for its predecessor -- are interleaved with the epilogue of tile st - 1 (sched_group_barrier: one MFMA,
+    // then six vector instructions), so the vector pipe works in the matrix pipe's shadow instead of behind it.
     auto compute = [&](int t) {
         const int buf = t & 1;
         const uint16_t* brow = &s_x[buf][(lane & 31) * STRIDE + (lane >> 5) * 8];
         const float rn = s_rn[buf][lane & 31];
-        // two column tiles at a time: 32 accumulator registers next to the 128 of the plane fragments (all SETS at once
-        // spilled 45 registers at head_dim 128); a fragment of the row tile read from LDS feeds two MFMAs on independent
-        // accumulators, which also keeps the matrix pipe issuing back to back
+        constexpr bool KEEP = KSTEPS <= 8;                 // head_dim 256: 64 registers of fragments do not fit next to the planes'
+        bf16x8 xb[KEEP ? KSTEPS : 1];
+        if constexpr (KEEP) {
 #pragma unroll
-        for (int s0 = 0; s0 < SETS; s0 += 2) {
-            if (s0 > 0) __builtin_amdgcn_sched_barrier(0);   // the halves must not be interleaved: their accumulators would all be live
-            f32x16 acc[2];
+            for (int kk = 0; kk < KSTEPS; ++kk) xb[kk] = *reinterpret_cast<const bf16x8*>(brow + kk * 16);
+        }
+        f32x16 acc[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+        for (int st = 0; st <= SETS; ++st) {
+            if (st < SETS) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[u][i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[st & 1][i] = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) {
-                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(brow + kk * 16);
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag[s0 + u][kk], xb, acc[u], 0, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int st = s0 + u;
-                const int ctile = wave * SETS + st;
-                // 16 sign bits of this lane's row: b = (b << 1) | sign, last accumulator first, then inverted (bit = acc > 0;
-                // an exact zero is inside every guard band and is decided by the exact pass)
-                uint32_t b = 0u;
-                float amin = 3.0e38f;
-#pragma unroll
-                for (int i = 15; i >= 0; --i) {
-                    b = __builtin_amdgcn_alignbit(b, __float_as_uint(acc[u][i]), 31);
-                    amin = fminf(amin, fabsf(acc[u][i]));
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    const bf16x8 xk = KEEP ? xb[KEEP ? kk : 0] : *reinterpret_cast<const bf16x8*>(brow + kk * 16);
+                    acc[st & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag[st][kk], xk, acc[st & 1], 0, 0, 0);
                 }
-                b = ~b;
-                // nibble j of b = planes 8 j + 4 (lane >> 5) + (0 .. 3): nibbles to bytes, the upper half-wave 4 bits up
-                const uint32_t lo = b & 0x0f0fu, hi = (b >> 4) & 0x0f0fu;
-                uint32_t w = __builtin_amdgcn_perm(hi, lo, 0x05010400u) << ((lane >> 5) * 4);
-                const auto sw = __builtin_amdgcn_permlane32_swap(w, w, false, false);   // the other half-wave's 16 planes
-                w = sw[0] | sw[1];
-                if (lane < 32) s_rowbits[(t * SH_ROWS + lane) * BW + ctile] = w;
-                // Guard band, tested against the widest band of the tile's planes (plane norms differ by a few per cent: a
-                // handful of candidates more, each decided exactly at the end).  NOT rare per wave: one lane in ~450 holds
-                // a candidate, so one wave-tile in seven runs this block -- it must not wait for anything: round 4's form
-                // read every plane's own band from LDS inside the loop (16 dependent LDS round trips, ~2 500 cycles per
-                // execution, half a tile's time on average).  Which of a lane's 16 planes belong to this workgroup at all
-                // (the last tile's tail, Wt's zero padding) is a per-lane bit mask made once, `mine`.
-                const float thr = wcoarse[st] * rn;
-                if (amin <= thr) {
-                    const int64_t gr = row_base + (int64_t)t * SH_ROWS + (lane & 31);
-                    // plane offset of accumulator i inside the workgroup's span: pb + (i & 3) + 8 (i >> 2).  Opaque to the
-                    // optimiser on purpose: as a loop invariant it hoisted all 16 SETS sums out of the tile loop -- 64
-                    // registers, spilled to scratch
-                    int pb = ctile * 32 + 4 * (lane >> 5);
-                    asm volatile("" : "+v"(pb));
-                    const uint32_t ok = gr < n ? mine[st] : 0u;
+            }
+            if (st > 0) epilogue(acc[(st - 1) & 1], st - 1, t, rn);
+            if (st > 0 && st < SETS) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        // guard-band candidate: queue (chunk row, plane offset) for the exact pass at the end
-                        if (((ok >> i) & 1u) && fabsf(acc[u][i]) <= thr) {
-                            const int slot = atomicAdd(&s_qn, 1);
-                            if (slot < SK_QCAP)
-                                s_queue[slot] = ((uint32_t)(t * SH_ROWS + (lane & 31)) << 16) |
-                                                (uint32_t)(pb + (i & 3) + 8 * (i >> 2));
-                        }
-                    }
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA of tile st ...
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     // ... then six VALU instructions of tile st - 1's epilogue
                 }
             }
         }
