@@ -81,3 +81,22 @@ def test_bench_takes_the_distributed_path_with_one_rank(shard):
     assert line["config"]["process_group"] == "nccl x1" and line["n_gpus"] == 1 and line["value"] > 0
     if shard == "head":
         assert line["head_shard_gather"]["shape"] == [1, 1, 128]
+
+
+def test_default_line_carries_a_second_configuration_and_the_footprint():
+    """VERDICT r04 item 2 on the GPU box: the default single-GPU line (cfg 1) holds another CONFIGURATION as a leg (here
+    cfg 4's per-GPU share only, short CPU samples: ~40 s) with its roofline, its HBM footprint and the full-size first
+    layer matched against the CPU path; the headline's footprint per layer is what the shapes say; nothing failed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-clustered-leg", "--no-host-mode",
+           "--cpu-steps", "64", "--leg-cpu-steps", "32", "--legs", "cfg4"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "cfg1" in d["config"]["workload"] and "failed_legs" not in d
+    f = d["observed"]["hbm_bytes_per_layer"]
+    assert f["kv"] == 8 * 98304 * 2 * 128 * 2 and f["table"] == 8 * 150 * 98304 * 4 and f["total"] == sum(f[k] for k in ("kv", "key_norms", "bounds", "table", "slots"))
+    leg = d["legs"]["cfg4_share"]
+    assert leg["ranges_per_head"] == 16 and leg["tokens_per_s"] > 0 and 0 < leg["roofline"]["frac"] < 1
+    assert leg["cpu_baseline"]["gpu_matches"]["nnz_equal"] is True and leg["cpu_baseline"]["gpu_matches"]["max_abs_out_diff"] <= 1e-2
+    assert d["cpu_baseline"]["gpu_matches"]["nnz_equal"] is True
