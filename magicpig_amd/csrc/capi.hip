@@ -41,7 +41,7 @@ hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, in
 hipError_t launch_lsh_unsort(const int16_t*, const int32_t*, int, int64_t, int16_t*, int*, hipStream_t);
 hipError_t launch_lsh_subbounds(const int32_t*, int32_t*, int, int, int, int64_t, int, hipStream_t);
 hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int, int32_t*, int32_t*, int*, const float*, int,
-                            int, int*, bool*, bool*, hipStream_t);
+                            int, int*, bool*, bool*, bool, hipStream_t);
 hipError_t launch_lsh_retrieve(const int32_t*, const int32_t*, const int32_t*, int32_t*, int32_t*, int,
                                int, int, int, int64_t, int, const int*, int32_t*, int32_t*, uint32_t*, hipStream_t);
 hipError_t launch_lsh_attach_norms(int32_t*, const float*, int, int, int64_t, int, int*, hipStream_t);
@@ -107,6 +107,8 @@ struct DebugOptions {
                                              // writes to pinned memory instead of hipStreamSynchronize (A/B, EXPERIMENTS.md R4-5)
     // counters (read with mp_debug_get_option, reset with mp_debug_set_option(name, 0)): how the MP_MEM_HOST attention
     // entry served its calls -- a fast path that silently stops hitting shows here (fallbacks must be observable)
+    std::atomic<int> build_rank_exact{0};    // 1: the table build ranks by match-any ballots always (A/B, tests); 0: by the LDS's lane order, verified
+    std::atomic<int> build_rank_fallbacks{0};// counter: builds redone with the exact ranking because a bucket run did not ascend
     std::atomic<int> host_fast_hits{0};      // the rows batch_retrieve had just handed out were recognised: no index upload
     std::atomic<int> host_fast_edited{0};    // pairing found, but a row differed from what was handed out: launch dropped, upload path
     std::atomic<int> host_fast_unpaired{0};  // no pairing (other buffers, other counts, another handle in between): upload path
@@ -127,6 +129,8 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "decode_kn_payload")) return &g_opt.decode_kn_payload;
     if (!strcmp(name, "host_zero_copy")) return &g_opt.host_zero_copy;
     if (!strcmp(name, "host_flag_wait")) return &g_opt.host_flag_wait;
+    if (!strcmp(name, "build_rank_exact")) return &g_opt.build_rank_exact;
+    if (!strcmp(name, "build_rank_fallbacks")) return &g_opt.build_rank_fallbacks;
     if (!strcmp(name, "host_fast_hits")) return &g_opt.host_fast_hits;
     if (!strcmp(name, "host_fast_edited")) return &g_opt.host_fast_edited;
     if (!strcmp(name, "host_fast_unpaired")) return &g_opt.host_fast_unpaired;
@@ -705,13 +709,15 @@ static int lsh_check_slot(mp_lsh_t* h, int layer_id, int request_id, int64_t n, 
 
 // reads and clears the device flag: bit 0 -> MP_ERR_DATA; *unsorted (optional) <- bit 2 (a bucket whose ids
 // do not ascend: not an error, the caller re-sorts)
-static int lsh_read_err(mp_lsh_t* h, hipStream_t st, const char* who, bool* unsorted = nullptr, bool* wide = nullptr) {
+static int lsh_read_err(mp_lsh_t* h, hipStream_t st, const char* who, bool* unsorted = nullptr, bool* wide = nullptr,
+                        bool* misranked = nullptr) {
     int flag = 0;
     MP_HIP_CHECK(hipMemcpyAsync(&flag, h->err, 4, hipMemcpyDeviceToHost, st));
     MP_HIP_CHECK(hipStreamSynchronize(st));
     if (flag) MP_HIP_CHECK(hipMemsetAsync(h->err, 0, 4, st));
     if (unsorted) *unsorted = (flag & 4) != 0;
     if (wide) *wide = (flag & 32) != 0;
+    if (misranked) *misranked = (flag & 64) != 0;        // the build's fast ranking saw a bucket run that does not ascend
     if (flag & 1)
         return fail(MP_ERR_DATA, std::string(who) + ": device-side validation failed (codes not sorted / "
                                                     "out of [0, 2^K) or token id out of [0, max_length))");
@@ -781,7 +787,7 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
         MP_HIP_CHECK(hipMemsetAsync(tok.p, 0xff, (size_t)rows * n * 2, st));      // code -1: a token no id named
         MP_HIP_CHECK(launch_lsh_unsort((const int16_t*)c, (const int32_t*)i, rows, n, tok.as<int16_t>(), h->err, st));
         MP_HIP_CHECK(launch_lsh_build(tok.as<int16_t>(), rows, n, h->NB, h->M, h->R, b, t, h->err, nullptr, h->L, 0,
-                                      nullptr, nullptr, nullptr, st));
+                                      nullptr, nullptr, nullptr, /*exact_rank=*/true, st));
         // an id outside [0, n) is flagged by the unsort, a token missing from the id list shows up as code -1
         if (lsh_read_err(h, st, "mp_lsh_fill") != MP_OK)
             return fail(MP_ERR_DATA, "mp_lsh_fill: a bucket's ids do not ascend (unstable sort) and the ids of a row are "
@@ -1616,16 +1622,28 @@ static int lsh_build_entry(mp_lsh_t* h, mp_attn_t* attn, int layer_id, int reque
         if (h->idbits_of[layer_id] != 0 && ver != KN_VERSION_UNKNOWN && g_opt.decode_kn_payload.load() != 0)
             kn = attn->kn[layer_id] + (size_t)request_id * attn->Hkv * attn->M;
     }
-    if (kn != nullptr) MP_HIP_CHECK(hipMemsetAsync(flag, 0, (size_t)h->Hkv * 4, st));
-    bool packed = false, cut = false;
-    MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, h->R, b, t, h->err, kn, h->L, 17, flag, &packed, &cut, st));
-    // (the staged build writes the sub-bounds itself, round 5; the direct variant for K >= 14 leaves them to the search)
-    if (!cut) MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, packed ? 17 : 0, st));
-    if (!h->slots.empty())
-        MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * h->slot_words, rows,
-                                      h->NB, h->R, h->M, st));
-    if (packed && (rc = lsh_set_version(h, layer_id, request_id, ver, st)) != MP_OK) return rc;
-    return lsh_read_err(h, st, who);
+    // The build ranks the tokens of a bucket by the order in which the LDS serves the lanes of one atomic instruction -- lane
+    // order on gfx950, observed, not promised -- and VERIFIES every bucket run it writes (err bit 64).  A run that does not ascend
+    // means: rebuild the request with the exact ranking (once; counted in `build_rank_fallbacks`).
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool exact = attempt == 1 || g_opt.build_rank_exact.load() != 0;
+        bool packed = false, cut = false, misranked = false;
+        if (kn != nullptr) MP_HIP_CHECK(hipMemsetAsync(flag, 0, (size_t)h->Hkv * 4, st));
+        MP_HIP_CHECK(launch_lsh_build((const int16_t*)c, rows, n, h->NB, h->M, h->R, b, t, h->err, kn, h->L, 17, flag, &packed, &cut,
+                                      exact, st));
+        // (the staged build writes the sub-bounds itself, round 5; the direct variant for K >= 14 leaves them to the search)
+        if (!cut) MP_HIP_CHECK(launch_lsh_subbounds(t, b, rows, h->NB, h->R, h->M, packed ? 17 : 0, st));
+        if (!h->slots.empty())
+            MP_HIP_CHECK(launch_lsh_slots(t, b, h->slots[layer_id] + (size_t)request_id * rows * h->NB * h->R * h->slot_words, rows,
+                                          h->NB, h->R, h->M, st));
+        if (packed && (rc = lsh_set_version(h, layer_id, request_id, ver, st)) != MP_OK) return rc;
+        rc = lsh_read_err(h, st, who, nullptr, nullptr, &misranked);
+        if (rc != MP_OK || !misranked) return rc;
+        MP_REQUIRE(!exact, MP_ERR_DATA, std::string(who) + ": the exact table build reported a mis-ranked bucket");
+        g_opt.build_rank_fallbacks.fetch_add(1, std::memory_order_relaxed);
+        if ((rc = lsh_set_version(h, layer_id, request_id, 0, st)) != MP_OK) return rc;     // rewritten again
+    }
+    return MP_OK;
 }
 
 int mp_lsh_build_with_norms(mp_lsh_t* h, mp_attn_t* attn, int layer_id, int request_id, const int16_t* codes, int64_t n,

@@ -350,7 +350,13 @@ __device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ 
 // share a CU.  The tile loop is a chain of short phases
 // between barriers (count, scan, rank, write out); with one workgroup per CU nothing filled the waits, and a launch of
 // 1 200 rows ran in five rounds of 256 (cfg 4: 300 rows in two rounds, the second 17 % full).
-template <int TPL, bool PACK = false>   // tokens per lane and tile: T = TPL * blockDim.x
+// FAST (round 5): the rank of a token inside its bucket's run comes from ONE returning LDS atomic on the wave's cursor --
+// the hardware serialises the lanes of an instruction that hit the same word, and on gfx950 it was observed to do so in lane
+// order, which is token order.  That order is not architecturally promised, so it is VERIFIED: the write-out checks that
+// neighbouring entries of a bucket's run ascend and raises err bit 64 otherwise; the host then rebuilds the request with the
+// exact ranking (match-any ballots over the code's bits: ~75 vector instructions per token -- the kernel was bound by VALU
+// issue: 319 M wave-instructions per launch at cfg 1 = 0.52 ms of issue slots alone, profiles/r05_pmc_sq_insts_cfg1.md).
+template <int TPL, bool PACK = false, bool FAST = false>   // tokens per lane and tile: T = TPL * blockDim.x
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsh_build_kernel(   // 16 waves per CU either way: 128 VGPRs
     const int16_t* __restrict__ codes,   // [Hkv*L][n] unsorted
     int n, int NB, int nbits, int64_t M, int RS, int32_t* __restrict__ bounds, int32_t* __restrict__ table,
@@ -493,6 +499,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         }
         lds_barrier();
         const int tile_count = carry;                   // valid tokens of the tile
+        if constexpr (FAST) {
+#pragma unroll
+            for (int j = 0; j < TPL; ++j) {
+                const int v = vq[j];
+                if (v >= 0) {
+                    const int pos = count_add(v, 1);          // lanes of one instruction on one word: served in lane order (verified below)
+                    s_id[pos] = w0 + j * WAVE + lane;
+                    s_b[pos] = (uint16_t)v;
+                }
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < TPL; ++j) {
             const int v = vq[j];
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         } else {
             constexpr int OB = TPL >= 16 ? 4 : 8;                // entries per batch (TPL is 8 or 16; 16 keeps two sets of codes in registers)
             const float* knr = kn ? kn + (row / L) * M : nullptr;    // a tile's 8 192 norms: 32 KB, read once per table row
-            bool refused = false;
+            bool refused = false, misordered = false;
 #pragma unroll
             for (int j0 = 0; j0 < TPL; j0 += OB) {
                 if (tid + j0 * (int)blockDim.x >= tile_count) break;     // (not uniform: the usual per-lane exit)
@@ -539,7 +556,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     const int p = tid + (j0 + j) * (int)blockDim.x;
                     const int pc = p < tile_count ? p : tid;            // (tid < tile_count here: a valid entry)
                     idv[j] = s_id[pc];
-                    pos[j] = pc + s_gdelta[s_b[pc]];
+                    const int bk = s_b[pc];
+                    pos[j] = pc + s_gdelta[bk];
+                    if (FAST) {    // the run of a bucket must ascend: this entry against its right neighbour
+                        const int pn = pc + 1 < tile_count ? pc + 1 : pc;
+                        if (pn != pc && (int)s_b[pn] == bk && s_id[pn] <= idv[j]) misordered = true;
+                    }
                 }
                 if (kn == nullptr) {
 #pragma unroll
@@ -563,6 +585,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 }
             }
             if (refused) atomicOr(bad + row / L, 1);
+            if (FAST && misordered) atomicOr(err, 64);
         }
         // the next tile's zeroing of s_cnt is ordered after this loop's LDS reads by its barrier (lgkmcnt(0) in front of
         // it: the reads have landed in registers); s_id / s_b / s_gdelta are rewritten only after two more barriers
@@ -1900,13 +1923,15 @@ static bool build_staged_geometry(int NB, int& nw, int& tpl, size_t& lds, bool& 
 // kn != nullptr: the packed build (only the staged kernels pack; *packed says whether they ran)
 hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, int64_t M, int R,
                             int32_t* bounds, int32_t* table, int* err, const float* kn, int L, int idbits, int* bad,
-                            bool* packed, bool* subbounds_done, hipStream_t st) {
+                            bool* packed, bool* subbounds_done, bool exact_rank, hipStream_t st) {
     if (packed) *packed = false;
     if (subbounds_done) *subbounds_done = false;
     static DeviceOnce once;
     const hipError_t attr_err = once.run([] {
         const void* fns[] = {reinterpret_cast<const void*>(lsh_build_kernel<16, true>),
                              reinterpret_cast<const void*>(lsh_build_kernel<8, true>),
+                             reinterpret_cast<const void*>(lsh_build_kernel<16, true, true>),
+                             reinterpret_cast<const void*>(lsh_build_kernel<8, true, true>),
                              reinterpret_cast<const void*>(lsh_build_kernel<32>),
                              reinterpret_cast<const void*>(lsh_build_direct_kernel)};
         for (const void* f : fns) {
@@ -1924,12 +1949,14 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     bool pack;
     const int RS = R + 1;
     if (build_staged_geometry(NB, nw, tpl, lds, pack)) {
-#define MP_BUILD_CASE(TPL, PK)                                                                         \
-        if (tpl == TPL && pack == PK)                                                                  \
-            hipLaunchKernelGGL((lsh_build_kernel<TPL, PK>), dim3(rows), dim3(64 * nw), lds, st, codes, \
-                               (int)n, NB, nbits, M, RS, bounds, table, err, kn, L, idbits, bad,       \
+        const bool fast = pack && !exact_rank;                 // (the 32-codes-per-lane form keeps the exact ranking)
+#define MP_BUILD_CASE(TPL, PK, FA)                                                                         \
+        if (tpl == TPL && pack == PK && fast == FA)                                                        \
+            hipLaunchKernelGGL((lsh_build_kernel<TPL, PK, FA>), dim3(rows), dim3(64 * nw), lds, st, codes, \
+                               (int)n, NB, nbits, M, RS, bounds, table, err, kn, L, idbits, bad,           \
                                R > 1 ? lsh_range_len(M, R) : 0);
-        MP_BUILD_CASE(16, true) MP_BUILD_CASE(8, true) MP_BUILD_CASE(32, false)
+        MP_BUILD_CASE(16, true, true) MP_BUILD_CASE(8, true, true)
+        MP_BUILD_CASE(16, true, false) MP_BUILD_CASE(8, true, false) MP_BUILD_CASE(32, false, false)
 #undef MP_BUILD_CASE
         if (packed) *packed = kn != nullptr;
         if (subbounds_done) *subbounds_done = tpl < 32;        // (R = 1 has none; R > 1: written by the kernel itself)

@@ -1374,6 +1374,44 @@ def test_table_build_is_a_stable_sort(mp, K, n):
     assert torch.equal(ta[..., :n], tb[..., :n])
 
 
+@pytest.mark.parametrize("K", [4, 10, 11])
+def test_table_build_ranking_fast_equals_exact_and_never_falls_back(mp, K):
+    """Round 5: the build ranks a bucket's tokens by the order in which the LDS serves the lanes of one returning atomic (lane order
+    on gfx950: observed, verified per written run, exact rebuild otherwise).  The same tables, bit for bit, as the exact ranking
+    (`build_rank_exact = 1`: match-any ballots) -- with R = 8 token ranges, so the sub-bounds the sort writes are compared too --
+    and NO fallback, on codes that put many lanes of one instruction on one counter (K = 4: 16 buckets; one row with a single
+    bucket; a few heavy buckets)."""
+    import magicpig_amd._lib as L_
+
+    Hkv, L, H, B, n = 2, 6, 8, 1, 21000
+    M = n + 40
+    NB = 1 << K
+    codes_np = synth.randint(900 + K, 0, NB, (Hkv, L, n)).astype(np.int16)
+    codes_np[0, 0, :] = codes_np[0, 0, 0]
+    codes_np[1, 1, :] = np.arange(n) % min(NB, 5)
+    codes_np[1, 2, :] = (np.arange(n) // 3) % NB          # runs of three equal codes inside every 64-token group
+    codes = torch.from_numpy(codes_np).cuda()
+    tabs = {}
+    try:
+        for exact in (0, 1):
+            L_.set_option("build_rank_exact", exact)
+            L_.set_option("build_rank_fallbacks", 0)
+            x = mp.LSH()
+            x.alloc(K, L, 1, H, Hkv, B, M)
+            assert x.R == 8
+            x.fastfill(0, 0, codes)
+            torch.cuda.synchronize()
+            assert L_.get_option("build_rank_fallbacks") == 0
+            bnd, tab = x.get_tables(0, raw=True)
+            tabs[exact] = (bnd.clone(), tab[..., :n].clone())
+            del x
+    finally:
+        L_.set_option("build_rank_exact", 0)
+    assert torch.equal(tabs[0][0], tabs[1][0]) and torch.equal(tabs[0][1], tabs[1][1])
+    sv, si = codes.sort(dim=-1, stable=True)
+    assert torch.equal(tabs[0][1], si.int())             # the stable order: ids ascend inside every bucket
+
+
 @pytest.mark.parametrize("H,Hkv,B", [(32, 8, 1), (8, 2, 2), (32, 8, 8)])
 def test_token_range_sub_bounds_and_unstable_fill(mp, H, Hkv, B):
     """The tables of a decode cluster: every bucket's ids ascend and its R + 1 sub-bounds cut it at the
