@@ -559,6 +559,8 @@ class Workload:
                 del kc, vc, ks, vs
         torch.cuda.synchronize()
         self.t_setup = time.time() - t_s
+        import magicpig_amd._lib as _L
+        self.build_rank_fallbacks = _L.get_option("build_rank_fallbacks")    # table builds redone with the exact ranking (expected 0)
         q = torch.empty((NQ, NL, B, H, 1, D), device=dev, dtype=torch.float32)
         hv = queries == "heavy" or (queries == "auto" and data != "randn")
         jj = torch.zeros((NQ, NL, B, H), device=dev, dtype=torch.long)
@@ -959,6 +961,7 @@ def main():
                      "selected_fraction": w.nnz_mean / n, "nnz_max_head": float(w.nnz_all.max()),
                      "probed_pieces": w.piece_stats, "key_distribution": args.data,
                      "queries": "heavy" if w.heavy else "randn", "setup_s": w.t_setup,
+                     "build_rank_fallbacks": w.build_rank_fallbacks,
                      "hbm_bytes_per_layer": w.footprint()},
         "roofline": roof,
     }
