@@ -207,34 +207,38 @@ __global__ __launch_bounds__(256) void lsh_slots_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ bounds,
                                                         int32_t* __restrict__ slots, int NB, int R, int64_t M, int swl) {
     const int64_t row = blockIdx.y;                      // (kv head, table) row of this request
-    const int RS = R + 1;
     const int SW = 1 << swl;                             // words per slot: 32, 16 or 8 (lsh_slot_log2)
     const int32_t* t = table + row * M;
-    const int32_t* b = bounds + row * NB * RS;
+    const int32_t* b = bounds + row * NB * (R + 1);
     int32_t* s = slots + row * NB * R * SW;
     const int sl = threadIdx.x & (SW - 1);
     const int gpb = 256 >> swl;                          // groups of SW lanes per block: one group writes a slot
     constexpr int U = 8;                                 // pieces in flight per group (round 5: 4 -> 8, stores non-temporal)
     const int total = NB * R;
+    // R is a power of two (decode_cluster_size): piece -> (bucket, range) by shift and mask, the bucket's record of R + 1
+    // entries starts at piece + bucket; offsets inside a row fit 32 bits (NB R SW <= 2^31: mp_lsh_alloc).  Round 5: the kernel
+    // issued 230 M vector instructions per launch at cfg 1 -- 0.37 ms of issue slots for a 0.6-ms launch -- most of them the
+    // integer division by R and 64-bit address arithmetic per piece.
+    const int clog = 31 - __builtin_clz((unsigned)R);
     for (int p0 = (blockIdx.x * gpb + (threadIdx.x >> swl)) * U; p0 < total; p0 += gridDim.x * gpb * U) {
         int lo[U], hi[U], v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int piece = p0 + u < total ? p0 + u : total - 1;
-            const int bk = piece / R, r = piece - bk * R;
-            lo[u] = b[bk * RS + r];
-            hi[u] = b[bk * RS + r + 1];
+            const int at = piece + (piece >> clog);
+            lo[u] = b[at];
+            hi[u] = b[at + 1];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            v[u] = 0;
-            if (sl == 0) v[u] = hi[u] - lo[u];
-            else if (sl == 1) v[u] = lo[u];
-            else if (sl - 2 < hi[u] - lo[u]) v[u] = t[lo[u] + sl - 2];
+            const int len = hi[u] - lo[u];
+            v[u] = sl == 0 ? len : lo[u];
+            if (sl >= 2) v[u] = sl - 2 < len ? t[lo[u] + sl - 2] : 0;
         }
+        int32_t* dst = s + ((uint32_t)p0 << swl) + sl;
 #pragma unroll
         for (int u = 0; u < U; ++u)      // 1.26 GB per layer at cfg 1, written once, read by the decode launches much later
-            if (p0 + u < total) __builtin_nontemporal_store(v[u], s + (int64_t)(p0 + u) * SW + sl);
+            if (p0 + u < total) __builtin_nontemporal_store(v[u], dst + ((uint32_t)u << swl));
     }
 }
 
