@@ -101,7 +101,11 @@ int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted
                 const int32_t* sorted_ids, int64_t n, int mem, mp_stream_t stream);
 /* Working replacement of the reference's half-written LSH::fastfill (lsh.cc:93-142): builds
  * the tables on device from UNSORTED codes int16 [Hkv, L, n] (counting sort; ascending token
- * ids inside every bucket). */
+ * ids inside every bucket; the sub-bounds of the R token ranges are written by the same kernel).
+ * Inside a 64-token group the tokens of a bucket are ranked by the order in which the LDS serves the lanes of one
+ * returning atomic -- lane order on gfx950 -- and every bucket run the kernel writes is checked to ascend; a request whose
+ * check fails is rebuilt with the exact (match-any) ranking before the call returns ("build_rank_exact" forces that
+ * form, "build_rank_fallbacks" counts rebuilds: mp_debug_set_option / _get_option).  The result is the stable sort either way. */
 int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes, int64_t n,
                  int mem, mp_stream_t stream);
 /* mp_lsh_build for a caller that has ALREADY filled the attention store of (layer_id, request_id) -- the reference's
