@@ -1910,10 +1910,27 @@ hipError_t launch_lsh_unsort(const int16_t* codes, const int32_t* ids, int rows,
 }
 
 // staged layout per NB (LDS <= 160 KB): waves per row, tokens per lane and tile
-static bool build_staged_geometry(int NB, int& nw, int& tpl, size_t& lds, bool& pack) {
+// tiles a row of n tokens is sorted in: tiles never straddle a range boundary unless it falls between two waves' slices
+static int64_t build_tiles(int64_t n, int R, int range_len, int tpl, int nw) {
+    const int64_t T = (int64_t)tpl * 64 * nw, slice = (int64_t)tpl * 64;
+    if (R <= 1 || range_len <= 0 || range_len % slice == 0) return (n + T - 1) / T;
+    int64_t tiles = 0;
+    for (int r = 0; r < R; ++r) {
+        int64_t len = n - (int64_t)r * range_len;
+        len = len < 0 ? 0 : (len > range_len ? range_len : len);
+        tiles += (len + T - 1) / T;
+    }
+    return tiles;
+}
+
+static bool build_staged_geometry(int NB, int64_t n, int R, int range_len, int& nw, int& tpl, size_t& lds, bool& pack) {
     pack = false;
     if (NB <= 1024)      { nw = 8;  tpl = 16; pack = true; }      // 72 KB: two workgroups per CU (16-bit tile counters)
-    else if (NB <= 2048) { nw = 8;  tpl = 8;  pack = true; }      // 72 KB with tiles of 4 096 tokens
+    else if (NB <= 2048) {                                        // 72 - 80 KB: tiles of 4 096, 4 608 or 5 120 tokens -- the one that
+        nw = 8; tpl = 8; pack = true;                             // cuts the row's token ranges into the fewest tiles (cfg 4:
+        for (int cand = 9; cand <= 10; ++cand)                    // range_len 8 224 = 4 096 + 4 096 + 32, but 4 608 + 3 616)
+            if (build_tiles(n, R, range_len, cand, nw) < build_tiles(n, R, range_len, tpl, nw)) tpl = cand;
+    }
     else if (NB <= 4096) { nw = 4;  tpl = 32; }
     else if (NB <= 8192) { nw = 2;  tpl = 32; }
     else return false;
@@ -1934,8 +1951,12 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     const hipError_t attr_err = once.run([] {
         const void* fns[] = {reinterpret_cast<const void*>(lsh_build_kernel<16, true>),
                              reinterpret_cast<const void*>(lsh_build_kernel<8, true>),
+                             reinterpret_cast<const void*>(lsh_build_kernel<9, true>),
+                             reinterpret_cast<const void*>(lsh_build_kernel<10, true>),
                              reinterpret_cast<const void*>(lsh_build_kernel<16, true, true>),
                              reinterpret_cast<const void*>(lsh_build_kernel<8, true, true>),
+                             reinterpret_cast<const void*>(lsh_build_kernel<9, true, true>),
+                             reinterpret_cast<const void*>(lsh_build_kernel<10, true, true>),
                              reinterpret_cast<const void*>(lsh_build_kernel<32>),
                              reinterpret_cast<const void*>(lsh_build_direct_kernel)};
         for (const void* f : fns) {
@@ -1952,15 +1973,16 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     size_t lds;
     bool pack;
     const int RS = R + 1;
-    if (build_staged_geometry(NB, nw, tpl, lds, pack)) {
+    if (build_staged_geometry(NB, n, R, R > 1 ? lsh_range_len(M, R) : 0, nw, tpl, lds, pack)) {
         const bool fast = pack && !exact_rank;                 // (the 32-codes-per-lane form keeps the exact ranking)
 #define MP_BUILD_CASE(TPL, PK, FA)                                                                         \
         if (tpl == TPL && pack == PK && fast == FA)                                                        \
             hipLaunchKernelGGL((lsh_build_kernel<TPL, PK, FA>), dim3(rows), dim3(64 * nw), lds, st, codes, \
                                (int)n, NB, nbits, M, RS, bounds, table, err, kn, L, idbits, bad,           \
                                R > 1 ? lsh_range_len(M, R) : 0);
-        MP_BUILD_CASE(16, true, true) MP_BUILD_CASE(8, true, true)
-        MP_BUILD_CASE(16, true, false) MP_BUILD_CASE(8, true, false) MP_BUILD_CASE(32, false, false)
+        MP_BUILD_CASE(16, true, true) MP_BUILD_CASE(8, true, true) MP_BUILD_CASE(9, true, true) MP_BUILD_CASE(10, true, true)
+        MP_BUILD_CASE(16, true, false) MP_BUILD_CASE(8, true, false) MP_BUILD_CASE(9, true, false) MP_BUILD_CASE(10, true, false)
+        MP_BUILD_CASE(32, false, false)
 #undef MP_BUILD_CASE
         if (packed) *packed = kn != nullptr;
         if (subbounds_done) *subbounds_done = tpl < 32;        // (R = 1 has none; R > 1: written by the kernel itself)
