@@ -172,6 +172,10 @@ def parse():
                     help="A/B: key norms as a payload of the table entries (default: the library's choice)")
     ap.add_argument("--mfma-hash", action="store_true",
                     help="A/B: query SimHash by the MFMA kernel as its own launch, then the decode kernel")
+    ap.add_argument("--by-products", type=int, default=0, choices=[0, 1],
+                    help="0 (default): the timed decode is mp_decode_sparse_layer_ex with MP_DECODE_NO_BYPRODUCTS -- output, LSE "
+                         "and counts only, what a serving loop reads; 1: mp_decode_sparse_layer as in rounds 1-5 (query codes, "
+                         "result rows and logits written for get_mask / get_score).  The line says which form it timed")
     ap.add_argument("--two-launch", action="store_true",
                     help="A/B: the decode entry as (hash + retrieve) then attention instead of one launch")
     ap.add_argument("--end-to-end", action="store_true",
@@ -577,6 +581,7 @@ class Workload:
             for li in range(NL):
                 kc = srv.attn_server.get_key_cache(li)                             # [B, Hkv, M, D] centred keys
                 q[:, li, :, :, 0] = 0.5 * q[:, li, :, :, 0] + 3.0 * kc[bi, gi, jj[:, li]].float()
+        srv.by_products = bool(self.args.by_products)
         self.server, self.qs, self.heavy = srv, q.to(torch.bfloat16), hv
 
     # -- one decode token: every sparse layer once
@@ -729,6 +734,7 @@ def config_leg(mp, sharding, args, name, dev):
            "us_per_layer": dt / args.steps * 1e6 / w.NL, "steps": args.steps, "warmup": args.warmup,
            "nnz_per_head": w.nnz_mean, "candidates_per_head": w.cand_mean, "selected_fraction": w.nnz_mean / w.n,
            "ranges_per_head": w.piece_stats["ranges_per_head"],
+           "decode_form": "by-products on" if args.by_products else "MP_DECODE_NO_BYPRODUCTS",
            "roofline": {k: roof[k] for k in ("bytes_per_launch", "avg_launch_us", "achieved", "frac", "launches_timed")},
            "hbm_bytes_per_layer": w.footprint()}
     if not args.no_cpu_baseline:
@@ -952,6 +958,10 @@ def main():
                                    f"{H} of {cfg.get('H_full', H)} query heads per GPU)") if shard is not None
                                   else f"dp{world} (requests sharded)",
                    "launch": "eager" if w.graph is None else "hipGraph",
+                   "decode_form": ("mp_decode_sparse_layer (by-products on: codes, result rows, logits written)"
+                                   if args.by_products or args.two_launch or args.mfma_hash else
+                                   "mp_decode_sparse_layer_ex(MP_DECODE_NO_BYPRODUCTS): output + LSE + counts only, "
+                                   "selected ids handed to the gather unordered"),
                    "process_group": None if dist is None else f"{dist.get_backend()} x{dist.get_world_size()}"},
         "sparse_attn_us_per_layer": us_per_layer,
         "rank_checksums": rank_checksums,

@@ -303,6 +303,25 @@ int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int 
                            const uint16_t* q, uint16_t* output, float* max_value_expsum,
                            int32_t* nnz_out, mp_stream_t stream);
 
+/* mp_decode_sparse_layer / mp_decode_layer_window with a `flags` argument (0 = exactly the calls above).  No reference
+ * counterpart: the reference's two calls (models/attnserver.py:299-300) hand `results` / `nnz` from one to the other through
+ * the caller, and library/lsh/test.py, library/sparse_attention/test.py read get_mask / get_score back -- the by-products the
+ * one-launch entries keep writing for them.  A serving loop reads neither:
+ *   MP_DECODE_NO_BYPRODUCTS  the launch writes `output`, `max_value_expsum` and the per-head counts (nnz_out) and NOTHING
+ *       else -- no query codes, no ||q||, no result rows, no logits -- and hands its selected ids to the gather through an
+ *       unordered on-chip list (a token joins it the moment its second collision is counted), which takes the popcount
+ *       sweep, the block scan and the ordered emission off the launch's dependent chain.  Same selected SET and counts
+ *       (lsh.cc:266-283), same arithmetic per token (sparse_attention.cc:164-240); the tokens are folded into the softmax in
+ *       the order they were found, so `output` / the LSE agree with the flags = 0 call to f32 summation order (<= 1 bf16
+ *       ulp, 1e-3 on the LSE -- the parity tolerance), not bit for bit, and two runs need not agree bit for bit either.
+ *       After such a call mp_lsh_get_mask and mp_attn_get_score return MP_ERR_STATE until the next call that produces
+ *       their inputs.  Shapes without the one-launch form (and the decode_two_launch / decode_mfma_hash debug options) run
+ *       as flags = 0. */
+#define MP_DECODE_NO_BYPRODUCTS 1u
+int mp_decode_sparse_layer_ex(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int layer_id,
+                              const uint16_t* q, uint16_t* output, float* max_value_expsum,
+                              int32_t* nnz_out, unsigned int flags, mp_stream_t stream);
+
 /* The same launch with the static window of the layer folded in (models/attnserver.py:281-308, after
  * the step's k, v have been appended with mp_attn_append): `window` is a second KV store holding the
  * sink + local + generated tokens, window_len int32 [B*H] (device) the number of its rows that are
@@ -316,6 +335,10 @@ int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int 
 int mp_decode_layer_window(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn_t* window,
                            int layer_id, const uint16_t* q, const int32_t* window_len, uint16_t* output,
                            float* max_value_expsum, int32_t* nnz_out, mp_stream_t stream);
+
+int mp_decode_layer_window_ex(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn_t* window,
+                              int layer_id, const uint16_t* q, const int32_t* window_len, uint16_t* output,
+                              float* max_value_expsum, int32_t* nnz_out, unsigned int flags, mp_stream_t stream);
 
 /* ---------------------------------------------------------------- LSE merge
  * Replaces flashinfer.merge_state as called at models/attnserver.py:308 (base-2 LSEs):

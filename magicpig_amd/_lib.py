@@ -19,6 +19,7 @@ MP_OK = 0
 ERR_UNSUPPORTED = 5
 MEM_HOST, MEM_DEVICE = 0, 1
 DTYPE_BF16, DTYPE_F32 = 0, 1
+DECODE_NO_BYPRODUCTS = 1      # mp_decode_*_ex flag (include/magicpig_hip.h)
 
 _ERR_NAMES = {1: "MP_ERR_INVALID", 2: "MP_ERR_STATE", 3: "MP_ERR_HIP", 4: "MP_ERR_NOMEM",
               5: "MP_ERR_UNSUPPORTED", 6: "MP_ERR_DATA"}
@@ -89,6 +90,8 @@ def lib() -> C.CDLL:
         "mp_attn_invalidate_norms": ([p, i32, i32, p], i32),
         "mp_decode_sparse_layer": ([p, p, p, i32, p, p, p, p, p], i32),
         "mp_decode_layer_window": ([p, p, p, p, i32, p, p, p, p, p, p], i32),
+        "mp_decode_sparse_layer_ex": ([p, p, p, i32, p, p, p, p, C.c_uint, p], i32),
+        "mp_decode_layer_window_ex": ([p, p, p, p, i32, p, p, p, p, p, C.c_uint, p], i32),
         "mp_merge_state": ([p, p, p, p, i32, i32, p, p, p], i32),
     }
     for name, (args, res) in sig.items():

@@ -71,6 +71,10 @@ class LSHSparseAttnServer:
         self.max_value_expsum = torch.zeros((2, BH), dtype=torch.float32, device=self.device)
         self.nnz = torch.zeros((BH,), dtype=torch.int32, device=self.device)
         self.collect_nnz = True     # copy the per-head selected counts into self.nnz every decode
+        # True (default): decode* leave what the reference's two calls leave -- query codes, result rows, logits
+        # (get_mask / get_score work).  False: mp_decode_*_ex with MP_DECODE_NO_BYPRODUCTS -- output, LSE and counts only,
+        # the selected ids handed to the gather unordered (a serving loop's setting; bench.py times this form)
+        self.by_products = True
         # static window (sink + local + generated tokens), attnserver.py:25, 73-78, 97-106
         self.length = num_sink_tokens + num_local_tokens + generation_buffer
         with torch.cuda.device(self.device):
@@ -132,10 +136,11 @@ class LSHSparseAttnServer:
         BH = self.batch_size * self.num_attention_heads
         q = query_states.reshape(BH, self.head_dim)
         L.expect(q, torch.bfloat16, (BH, self.head_dim), "query_states")
-        L.check(L.lib().mp_decode_sparse_layer(
+        L.check(L.lib().mp_decode_sparse_layer_ex(
             self.hasher._h, self.lsh_retriever._h, self.attn_server._h, layer_idx, L.ptr(q),
             L.ptr(self.output), L.ptr(self.max_value_expsum),
-            L.ptr(self.nnz if self.collect_nnz else None), L.current_stream(q)))
+            L.ptr(self.nnz if self.collect_nnz else None), 0 if self.by_products else L.DECODE_NO_BYPRODUCTS,
+            L.current_stream(q)))
         out = self.output.view(self.batch_size, self.num_attention_heads, self.head_dim)
         lse = self.max_value_expsum[1].view(self.batch_size, self.num_attention_heads)
         return out, lse
@@ -210,10 +215,11 @@ class LSHSparseAttnServer:
         v = value_states.reshape(B, Hkv, D).contiguous()
         self.window_server.append_centred(layer_idx, k, v, self.avg_k[layer_idx].view(B, Hkv, D),
                                           self.kv_last_page_len, -1)
-        rc = L.lib().mp_decode_layer_window(
+        rc = L.lib().mp_decode_layer_window_ex(
             self.hasher._h, self.lsh_retriever._h, self.attn_server._h, self.window_server._h, layer_idx,
             L.ptr(q), L.ptr(self.window_nnz), L.ptr(self.output), L.ptr(self.max_value_expsum),
-            L.ptr(self.nnz if self.collect_nnz else None), L.current_stream(q))
+            L.ptr(self.nnz if self.collect_nnz else None), 0 if self.by_products else L.DECODE_NO_BYPRODUCTS,
+            L.current_stream(q))
         if rc == L.ERR_UNSUPPORTED:
             self.window_server.full_attention(layer_idx, self.window_out, self.window_mve, q, self.window_nnz)
             sparse_out, sparse_lse = self.decode(query_states, layer_idx)

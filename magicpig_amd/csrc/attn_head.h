@@ -310,6 +310,129 @@ __device__ __forceinline__ void attn_head_fold(
     }
 }
 
+// The fold of the LEAN decode (lsh.hip: MP_DECODE_NO_BYPRODUCTS).  Same arithmetic per token as attn_head_fold; what differs:
+//   * the list holds RAW table words  id | (bf16 key norm bits 14..0 << idbits)  as the counting step found them -- the
+//     norm of a selected token comes out of its own list entry (word_norm; else one HBM read per token as before), no
+//     per-range norm array in LDS;
+//   * the slices k0, k0 + kstep, ... of the list are folded: (0, 1) for a list that belongs to the calling WAVE alone
+//     (the tokens whose second collision this wave counted: gathered the moment its own counting is done, without waiting
+//     for the workgroup), (wave, waves) for a list shared by the workgroup;
+//   * rows are requested through a buffer descriptor over the KV group's rows: a slot past the end of the list gets an
+//     offset beyond num_records, for which the hardware returns zeros WITHOUT a memory request (attn_head_fold points such
+//     slots at the slice's first token: a wave-owned list of ~12 tokens in a 16-token step would re-request that row four
+//     times -- EXPERIMENTS.md R4-1 (2)).
+template <int D, int SLICE, typename IDS>
+__device__ __forceinline__ void attn_head_fold_lean(
+    AhState& st, const uint16_t* __restrict__ kv_g, const float* __restrict__ kn_g, const u32x4 qv, float qn_h, int nz,
+    int64_t M, int K, int L, int k0, int kstep, IDS&& ids, uint32_t idmask, int idbits, bool word_norm,
+    unsigned long long* __restrict__ stamp) {
+    constexpr int LPR = D / 8, RPL = 64 / LPR, UPS = SLICE / RPL, DUP = LPR / UPS;
+    static_assert(UPS >= 4 && UPS % 4 == 0 && DUP >= 2, "ids are fetched four at a time");
+    const int lane = threadIdx.x & 63;
+    const int r = lane / LPR, c = lane % LPR;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
+    const uint64_t kv_bytes = (uint64_t)M * (uint64_t)(4 * D);                   // <= 2^32 (mp_attn_alloc)
+    const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(kv_g), 0, (int)(uint32_t)(kv_bytes > 0xffffffffull ? 0xffffffffull : kv_bytes), 0x00020000);
+    constexpr int kNt = 2;                                                      // aux bit 1 = nt on gfx940+
+    constexpr uint32_t kOut = 0xffffff00u;                                      // beyond any row: no request, zeros
+    const uint32_t coff = (uint32_t)c * 16u;
+    const uint32_t M32 = (uint32_t)M;
+    for (int k = k0;; k += kstep) {
+        const int jb = k * SLICE;
+        if (jb >= nz) break;
+        u32x4 wv[UPS / 4];
+#pragma unroll
+        for (int v = 0; v < UPS / 4; ++v) wv[v] = ids(jb + r * UPS + v * 4);
+        const int slot_my = r * UPS + c / DUP;
+        const bool valid_my = jb + slot_my < nz;
+        uint32_t ro[UPS];
+        uint32_t w_my = 0u;
+#pragma unroll
+        for (int u = 0; u < UPS; ++u) {
+            const uint32_t w = wv[u / 4][u % 4];
+            const uint32_t id = w & idmask;
+            if (u == c / DUP) w_my = w;
+            ro[u] = ((jb + r * UPS + u) < nz && id < M32) ? id * (uint32_t)(4 * D) + coff : kOut;
+        }
+        float kn_my = 1.f;
+        if (word_norm) kn_my = bf16_bits_to_f32((uint16_t)(w_my >> idbits));
+        else if (valid_my && (w_my & idmask) < M32) kn_my = kn_g[w_my & idmask];
+        u32x4 kreg[UPS], vreg[UPS];
+        if (SLICE < AH_SLICE) {
+#pragma unroll
+            for (int u = 0; u < UPS; ++u) kreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rkv, ro[u], 0, kNt);
+#pragma unroll
+            for (int u = 0; u < UPS; ++u) vreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rkv, ro[u] + 2 * D, 0, kNt);
+        } else {
+#pragma unroll
+            for (int u = 0; u < UPS; ++u) {
+                kreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rkv, ro[u], 0, kNt);
+                vreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rkv, ro[u] + 2 * D, 0, kNt);
+            }
+        }
+        if (k == k0) MP_STAMP(stamp, 34);
+        float part[UPS];
+#pragma unroll
+        for (int u = 0; u < UPS; ++u) {
+            float a = 0.f;
+            dot8_bf16_chain(a, kreg[u], qv);
+            dot_settle(a);
+            part[u] = a;
+        }
+#pragma unroll
+        for (int stp = LPR / 2, vals = UPS; stp >= 1; stp >>= 1) {
+            if (vals > 1) {
+                const int half = vals / 2;
+                const bool upper = (c & stp) != 0;
+#pragma unroll
+                for (int u = 0; u < UPS / 2; ++u) {
+                    if (u < half) {
+                        const float send = upper ? part[u] : part[u + half];
+                        const float keep = upper ? part[u + half] : part[u];
+                        part[u] = keep + __shfl_xor(send, stp);
+                    }
+                }
+                vals = half;
+            } else {
+                part[0] += __shfl_xor(part[0], stp);
+            }
+        }
+        const float sc = part[0];
+        if (k == k0) MP_STAMP(stamp, 35);
+        float z = -INFINITY;
+        if (valid_my) z = importance_logit(sc, qn_h * kn_my, inv_sqrt_d, K, L);
+        const float m_w = wave_max(z);
+        const float p_my = valid_my ? __expf(z - m_w) : 0.f;
+        const float l_w = wave_sum((c % DUP) ? 0.f : p_my);
+        if (k == k0) MP_STAMP(stamp, 36);
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int u = 0; u < UPS; ++u) {
+            const float pu = __shfl(p_my, r * LPR + DUP * u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[2 * i] = fmaf(pu, bf16_lo(vreg[u][i]), acc[2 * i]);
+                acc[2 * i + 1] = fmaf(pu, bf16_hi(vreg[u][i]), acc[2 * i + 1]);
+            }
+        }
+        int doff = 0;
+        rs_step_h<8, 32>(acc, lane, doff);
+        rs_step_h<4, 16>(acc, lane, doff);
+        if (LPR == 8) rs_step_h<2, 8>(acc, lane, doff);
+        st.d0 = c * 8 + doff;
+        if (k == k0) MP_STAMP(stamp, 37);
+        const float m_new = fmaxf(st.m, m_w);
+        const float a = __expf(st.m - m_new), b = __expf(m_w - m_new);
+        st.l = fmaf(a, st.l, b * l_w);
+        st.o0 = fmaf(a, st.o0, b * acc[0]);
+        if (LPR == 16) st.o1 = fmaf(a, st.o1, b * acc[1]);
+        st.m = m_new;
+    }
+}
+
 // The waves' states meet in LDS (one barrier).  On return the lanes of WAVE 0 hold the workgroup's merged
 // state -- m (max logit), Z (sum of exp(z - m)) and, per lane, VPL = D / 64 consecutive elements
 // o[lane * VPL ..] of sum_j exp(z_j - m) V[j] -- and the other waves are done (they have nothing left to do in
@@ -434,6 +557,57 @@ __device__ __forceinline__ bool attn_head_merge_ticket(const AhState& st, float*
     o0_out = o0;
     o1_out = o1;
     return true;
+}
+
+// The two halves of attn_head_merge_ticket for a caller that does more between them (the LEAN decode: the wave that draws
+// the last ticket may still fold the rare leftovers -- pooled chunks, a spill list -- into its own state and publish again).
+template <int D>
+__device__ __forceinline__ void attn_head_publish(const AhState& st, float* s_merge) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mine = s_merge + wave * (D + 2);
+    mine[st.d0] = st.o0;
+    if (D / 8 == 16) mine[st.d0 + 1] = st.o1;
+    if (lane == 0) {
+        mine[D] = st.m;
+        mine[D + 1] = st.l;
+    }
+}
+template <int D, int NW>
+__device__ __forceinline__ void attn_head_merge_read(const float* s_merge, float& m_out, float& Z_out, float& o0_out,
+                                                     float& o1_out) {
+    constexpr int VPL = D / 64;
+    const int lane = threadIdx.x & 63;
+    float mw[NW], lw[NW], oa[NW], ob[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        mw[w] = s_merge[w * (D + 2) + D];
+        lw[w] = s_merge[w * (D + 2) + D + 1];
+        if (VPL == 2) {
+            const float2 tt = *reinterpret_cast<const float2*>(s_merge + w * (D + 2) + lane * 2);
+            oa[w] = tt.x;
+            ob[w] = tt.y;
+        } else {
+            oa[w] = s_merge[w * (D + 2) + lane];
+            ob[w] = 0.f;
+        }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) m = fmaxf(m, mw[w]);
+    float Z = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        if (mw[w] != -INFINITY) {                    // a wave without a slice never wrote its o[]
+            const float e = __expf(mw[w] - m);
+            Z = fmaf(e, lw[w], Z);
+            o0 = fmaf(e, oa[w], o0);
+            o1 = fmaf(e, ob[w], o1);
+        }
+    }
+    m_out = m;
+    Z_out = Z;
+    o0_out = o0;
+    o1_out = o1;
 }
 
 // fold the slices of ONE sparse list, then merge (attn_head_kernel)

@@ -30,7 +30,7 @@ hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, co
                              float*, float2*, int*, int*, uint16_t*, float*, float2*, const int32_t*, float*, int*,
                              int, int, bool, const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t,
                              bool, unsigned long long*, unsigned int*, int, int, int, const int*, const int*, const unsigned int*,
-                             const unsigned int*, hipStream_t);
+                             const unsigned int*, bool, bool*, hipStream_t);
 hipError_t set_stamp_stride(int);
 void set_exact_norm(int);
 void set_slot_log2(int);
@@ -355,6 +355,7 @@ struct mp_lsh {
     const int32_t* lastq = nullptr;// device codes of the last retrieve (for get_mask): last_query,
                                    // `codes`, or the caller's own device buffer (valid until it changes)
     int last_layer = -1;
+    bool last_lean = false;        // the last call was a decode without by-products: no codes to recompute the mask from
     int* err = nullptr;            // device-side validation flag
     // device-resident step buffers of the fused decode path
     int32_t* codes = nullptr;      // [BH][L]
@@ -822,6 +823,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     if (mem == MP_MEM_DEVICE) {
         h->lastq = query;
         h->last_layer = layer_id;
+        h->last_lean = false;
         MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], query, results,
                                          nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, nullptr, nullptr, nullptr, st));
         return MP_OK;
@@ -855,6 +857,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
             memcpy(hp + o_codes, query, qb);
             h->lastq = reinterpret_cast<const int32_t*>(hd + o_codes);      // (get_mask reads them again)
             h->last_layer = layer_id;
+            h->last_lean = false;
             // ONE launch, ONE synchronisation, no copy engine: the kernel reads the codes from the pinned block, writes
             // the ids straight into the caller's rows (where they are pinned) or the pinned mirror and the counts into the
             // pinned block -- and leaves a second copy of the rows in HBM (hr_rows / hr_nnz: buffers no other launch writes)
@@ -893,6 +896,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     MP_HIP_CHECK(hipMemcpyAsync(h->last_query, query, qb, hipMemcpyHostToDevice, st));
     h->lastq = h->last_query;
     h->last_layer = layer_id;
+    h->last_lean = false;
     MP_HIP_CHECK(launch_lsh_retrieve(h->bounds[layer_id], h->table[layer_id], h->last_query,
                                      h->results, h->nnz, BH, h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, nullptr, nullptr, nullptr, st));
     int32_t* d_offs = reinterpret_cast<int32_t*>(h->small.dp) + BH;           // dp: [nnz BH | offs BH + 1]
@@ -934,6 +938,7 @@ int mp_lsh_clear(mp_lsh_t* h, mp_stream_t stream) {
     std::fill(h->idbits_of.begin(), h->idbits_of.end(), 17);
     MP_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->idbits_dev), 17, (size_t)h->layers, st));
     h->last_layer = -1;
+    h->last_lean = false;
     return MP_OK;
 }
 
@@ -969,6 +974,8 @@ int mp_lsh_get_mask(mp_lsh_t* h, int8_t* mask, int mem, mp_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     const int BH = h->B * h->H;
     const size_t bytes = (size_t)BH * h->M;
+    MP_REQUIRE(!h->last_lean, MP_ERR_STATE, "mp_lsh_get_mask: the last call was mp_decode_*_ex with MP_DECODE_NO_BYPRODUCTS: "
+                                            "it left no query codes to recompute the mask from");
     if (h->last_layer < 0) {  // no retrieve since alloc/clear: the reference's mask is all zero
         if (mem == MP_MEM_DEVICE) MP_HIP_CHECK(hipMemsetAsync(mask, 0, bytes, st));
         else memset(mask, 0, bytes);
@@ -1570,6 +1577,8 @@ int mp_attn_get_score(mp_attn_t* h, void** score_dev, mp_stream_t stream) {
     MP_REQUIRE(h && h->allocated, MP_ERR_STATE, "mp_attn_get_score: not allocated");
     MP_REQUIRE(score_dev, MP_ERR_INVALID, "mp_attn_get_score: null argument");
     hipStream_t st = (hipStream_t)stream;
+    MP_REQUIRE(h->score_state != 3, MP_ERR_STATE, "mp_attn_get_score: the last call was mp_decode_*_ex with "
+                                                  "MP_DECODE_NO_BYPRODUCTS: it left no logits");
     if (h->score_state == 1) {
         if (h->seg_cnt != nullptr && h->seg_R > 1) {   // one-launch decode: R per-member segments -> one list
             MP_HIP_CHECK(launch_lsh_compact(reinterpret_cast<uint32_t*>(h->score), h->seg_cnt, h->B * h->H,
@@ -1657,8 +1666,9 @@ int mp_lsh_build_with_norms(mp_lsh_t* h, mp_attn_t* attn, int layer_id, int requ
 // shared by mp_decode_sparse_layer (win == nullptr) and mp_decode_layer_window
 static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn_t* win, int layer_id,
                         const uint16_t* q, const int32_t* win_len, uint16_t* output, float* max_value_expsum,
-                        int32_t* nnz_out, hipStream_t st, const char* who) {
+                        int32_t* nnz_out, unsigned int flags, hipStream_t st, const char* who) {
     const std::string w(who);
+    MP_REQUIRE((flags & ~(unsigned int)MP_DECODE_NO_BYPRODUCTS) == 0u, MP_ERR_INVALID, w + ": unknown flag");
     MP_ON_DEVICE(attn);
     MP_REQUIRE(s && s->Wt, MP_ERR_STATE, w + ": SimHash planes not set");
     MP_REQUIRE(lsh && lsh->allocated && attn && attn->allocated, MP_ERR_STATE, w + ": handles not allocated");
@@ -1675,6 +1685,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
     // by-products -- eager or replayed from a graph -- no longer touch them)
     lsh->lastq = lsh->codes;
     lsh->last_layer = layer_id;
+    lsh->last_lean = false;
     const bool two_launch = g_opt.decode_two_launch.load() != 0;                // A/B switch
     const bool fused = !two_launch && lsh_decode_supported(lsh->M, lsh->L, s->D, lsh->R);
     if (win != nullptr) {
@@ -1717,6 +1728,10 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
             }
         }
         const size_t goff = (size_t)layer_id * lsh->B * lsh->Hkv;
+        // MP_DECODE_NO_BYPRODUCTS: the launch writes `output`, `max_value_expsum` and the counts, nothing else (no codes, no
+        // ||q||, no result rows, no logits) and hands its selected ids to the gather unordered (lsh.hip: LEAN).  The one-launch
+        // form only (the other forms ARE the by-products); the MFMA-hash A/B keeps them too.
+        bool lean = (flags & MP_DECODE_NO_BYPRODUCTS) != 0u && !mfma_hash;   // (what ran comes back: the form needs more LDS)
         MP_HIP_CHECK(launch_lsh_decode(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk, s->wnorm, s->D,
                                        s->K, s->KLpad, lsh->codes, lsh->qnorm, lsh->results, lsh->nnz,
                                        attn->kv[layer_id], attn->kn[layer_id], attn->part_o, attn->part_ml,
@@ -1726,11 +1741,12 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
                                        lsh->L, lsh->NB, lsh->M, mfma_hash, lsh->xw, lsh->xseq, lsh->xwords, xmode, lsh->idbits_of[layer_id], lsh->idbits_dev + layer_id,
                                        kn_payload ? lsh->pay_bad + goff : nullptr, lsh->att_ver_dev + goff,
-                                       attn->kn_ver_dev + goff, st));
+                                       attn->kn_ver_dev + goff, lean, &lean, st));
         attn->lastz = lsh->nnz;
-        attn->score_state = 1;
+        attn->score_state = lean ? 3 : 1;               // 3: the last call left no logits (mp_attn_get_score says so)
         attn->seg_cnt = lsh->R > 1 ? attn->part_cnt : nullptr;
         attn->seg_R = lsh->R;
+        lsh->last_lean = lean;                          // ... and no codes (mp_lsh_get_mask says so)
     } else {
         // two launches: (hash + retrieve), then attention (models/attnserver.py:264-299, :300)
         MP_HIP_CHECK(launch_lsh_hash_retrieve(lsh->bounds[layer_id], lsh->table[layer_id], q, s->Wk,
@@ -1749,16 +1765,31 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
 int mp_decode_sparse_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int layer_id,
                            const uint16_t* q, uint16_t* output, float* max_value_expsum,
                            int32_t* nnz_out, mp_stream_t stream) {
-    return decode_layer(s, lsh, attn, nullptr, layer_id, q, nullptr, output, max_value_expsum, nnz_out,
+    return decode_layer(s, lsh, attn, nullptr, layer_id, q, nullptr, output, max_value_expsum, nnz_out, 0u,
                         (hipStream_t)stream, "mp_decode_sparse_layer");
+}
+
+int mp_decode_sparse_layer_ex(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, int layer_id,
+                              const uint16_t* q, uint16_t* output, float* max_value_expsum,
+                              int32_t* nnz_out, unsigned int flags, mp_stream_t stream) {
+    return decode_layer(s, lsh, attn, nullptr, layer_id, q, nullptr, output, max_value_expsum, nnz_out, flags,
+                        (hipStream_t)stream, "mp_decode_sparse_layer_ex");
 }
 
 int mp_decode_layer_window(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn_t* window,
                            int layer_id, const uint16_t* q, const int32_t* window_len, uint16_t* output,
                            float* max_value_expsum, int32_t* nnz_out, mp_stream_t stream) {
     MP_REQUIRE(window != nullptr, MP_ERR_INVALID, "mp_decode_layer_window: null window store");
-    return decode_layer(s, lsh, attn, window, layer_id, q, window_len, output, max_value_expsum, nnz_out,
+    return decode_layer(s, lsh, attn, window, layer_id, q, window_len, output, max_value_expsum, nnz_out, 0u,
                         (hipStream_t)stream, "mp_decode_layer_window");
+}
+
+int mp_decode_layer_window_ex(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn_t* window,
+                              int layer_id, const uint16_t* q, const int32_t* window_len, uint16_t* output,
+                              float* max_value_expsum, int32_t* nnz_out, unsigned int flags, mp_stream_t stream) {
+    MP_REQUIRE(window != nullptr, MP_ERR_INVALID, "mp_decode_layer_window_ex: null window store");
+    return decode_layer(s, lsh, attn, window, layer_id, q, window_len, output, max_value_expsum, nnz_out, flags,
+                        (hipStream_t)stream, "mp_decode_layer_window_ex");
 }
 
 // =================================================================== LSE merge

@@ -65,9 +65,27 @@ __shared__ unsigned long long s_stampbuf[64];
             }                                                                                \
         }                                                                                    \
     } while (0)
+// behind the merge ONE wave runs, whichever drew the last ticket: its lane 0 stamps and flushes
+#define MP_STAMP_L(stamp, slot)                                                              \
+    do {                                                                                     \
+        if ((stamp) != nullptr && (threadIdx.x & 63) == 0) ::mp::s_stampbuf[(slot)] = wall_clock64(); \
+    } while (0)
+#define MP_STAMP_FLUSH_L(stamp)                                                              \
+    do {                                                                                     \
+        if ((stamp) != nullptr && (threadIdx.x & 63) == 0) {                                 \
+            const int _ss = MP_STAMP_STRIDE;                                                 \
+            if (_ss > 0 || (blockIdx.x | blockIdx.y | blockIdx.z) == 0) {                    \
+                unsigned long long* _d = (stamp) + (_ss > 0 ? (size_t)blockIdx.x * _ss : 0); \
+                for (int _i = 0; _i < 64; ++_i)                                              \
+                    if (::mp::s_stampbuf[_i] != 0ull) _d[_i] = ::mp::s_stampbuf[_i];         \
+            }                                                                                \
+        }                                                                                    \
+    } while (0)
 #else
 #define MP_STAMP_INIT(stamp) do { } while (0)
 #define MP_STAMP_FLUSH(stamp) do { } while (0)
+#define MP_STAMP_L(stamp, slot) do { } while (0)
+#define MP_STAMP_FLUSH_L(stamp) do { } while (0)
 #endif
 
 #include "attn_head.h"
@@ -748,7 +766,17 @@ struct AttnArgs {
 // members of the head's cluster (decode only, clusters on one XCD), 2 = (decode only) codes + ||q|| were written
 // to ha.codes_out / ha.qnorm_out by simhash_query_kernel (the MFMA kernel) in a launch of its own: the A/B
 // variant of the decode entry behind the decode_mfma_hash option.
-template <int HASH, int CH, int AD, bool WIN>    // CH = min(16, D / 8): plane chunks kept in registers (HASH only);
+// LEAN (decode only; mp_decode_*_ex with MP_DECODE_NO_BYPRODUCTS): the launch leaves no by-products -- no codes, no ||q||,
+// no result rows, no logits -- and there is no workgroup-wide list of selected ids at all: every WAVE appends the tokens
+// whose SECOND collision it counted (exactly one lane per selected token sees its counter go 1 -> 2, whatever the
+// interleaving) to a list of its own in LDS and gathers their K / V rows the moment its own counting is done -- no barrier,
+// no popcount sweep, no block scan, no ordered emission, no staging between "counted" and the first row request.  A wave's
+// share is Poisson (~12 tokens at cfg 1): one 16-token step, a 32-token step above 16; the slots past its count request
+// nothing (buffer loads beyond num_records).  What bounds the gather is the number of row requests a CU turns over
+// (EXPERIMENTS.md R3-10), not which wave issues them -- so they should start as early as they can.  Entries beyond a wave's
+// 256-entry list (nearly every token selected: K = 1 tests) and the chunk pool's finds go through a spill list in HBM,
+// folded by the whole workgroup at the end.
+template <int HASH, int CH, int AD, bool WIN, bool LEAN = false>    // CH = min(16, D / 8): plane chunks kept in registers (HASH only);
                                                  // WIN: fold the static window in (its own instantiation, so the
                                                  // plain decode kernel carries none of its code)
 __device__ __forceinline__ void lsh_head_body(
@@ -757,9 +785,15 @@ __device__ __forceinline__ void lsh_head_body(
     int G, int L, int NB, int64_t M, int R, int range_len, int words, int Lpad, int idbits, const HashArgs& ha,
     const AttnArgs& aa, unsigned long long* __restrict__ stamp) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_u32[];
+    // the counting area: two bitmaps of `words` words (A = seen once, B = seen twice or more) -- or, LEAN, one COUNTER per
+    // token of the range (8 bits while L <= 255, else 16; a word holds 4 / 2 of them, incremented by ONE returning 32-bit
+    // atomic add whose result says "this was the token's second hit": no carry can cross a counter, a token is hit at most
+    // L times): 8 / 16 x `words` words
+    const int csh = (L <= 255) ? 3 : 4;                        // LEAN: log2 of the bits per counter
+    const int cw = LEAN ? (words << csh) : 2 * words;          // (32 tokens per bitmap word: 8 / 16 counter words)
     uint32_t* bmA = s_u32;
     uint32_t* bmB = s_u32 + words;
-    int* s_start = reinterpret_cast<int*>(s_u32 + 2 * words);
+    int* s_start = reinterpret_cast<int*>(s_u32 + cw);
     int* s_len = s_start + Lpad;
     uint32_t* s_tail = reinterpret_cast<uint32_t*>(s_len + Lpad);   // (table << 16 | chunk) of ids beyond 128
     int* s_tmp = reinterpret_cast<int*>(s_tail + RT_TAIL_CAP);
@@ -767,7 +801,7 @@ __device__ __forceinline__ void lsh_head_body(
     // HASH only: s_q (normalised query, bf16 pairs) | s_rn | s_bits (sign bits of the K*L planes)
     // (placed by INDEX, rounded up to 16 bytes for ds_read_b128: a uintptr_t round trip would lose the
     // LDS address space and turn every read of the query into a flat_load that waits on vmcnt too)
-    uint32_t* s_q = s_u32 + ((2 * words + 2 * Lpad + RT_TAIL_CAP + 32 + 4 + 3) & ~3);
+    uint32_t* s_q = s_u32 + ((cw + 2 * Lpad + RT_TAIL_CAP + 32 + 4 + 3) & ~3);
     float* s_rn = reinterpret_cast<float*>(s_q + 128);       // [0] guard bound of ||nq||, [1] ||q||
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_rn + 4);
     // AD only: s_ids [cap] (ids of this workgroup's slices) | s_merge | s_tk
@@ -829,9 +863,15 @@ __device__ __forceinline__ void lsh_head_body(
         if (AD > 0) s_tk[0] = 0;                                  // (MP_MERGE_TICKET: the waves' LDS ticket)
         s_tmp[30] = 0;                                            // pieces that overflow their direct slot
         s_tmp[29] = 1;                                            // split hash: every word of the head arrived
+        s_tmp[27] = 0;                                            // LEAN: selected tokens of the workgroup
+        s_tmp[26] = 0;                                            // LEAN: entries of the spill list
     }
     // collision bitmaps and piece lengths start at zero: done here, under the query row's round trip
-    for (int i = tid; i < 2 * words; i += RT_THREADS) s_u32[i] = 0u;
+    if constexpr (LEAN) {                                     // (cw is a multiple of 8: 16-byte stores)
+        for (int i = tid * 4; i < cw; i += RT_THREADS * 4) *reinterpret_cast<u32x4*>(s_u32 + i) = u32x4{0u, 0u, 0u, 0u};
+    } else {
+        for (int i = tid; i < 2 * words; i += RT_THREADS) s_u32[i] = 0u;
+    }
     for (int l = tid; l < Lpad; l += RT_THREADS) s_len[l] = 0;
     // -- the layer's id width and the state of this KV group's payloads, as the device knows them: four words, requested
     //    HERE -- behind the row's request, in front of the hyperplanes -- as VECTOR loads (buffer loads of a uniform
@@ -931,7 +971,7 @@ __device__ __forceinline__ void lsh_head_body(
                 nrm = (float)sqrt((double)(float)ss);          // (__fsqrt_rn measured no faster here, and not bit-identical)
             }
             nb = bf16_bits_to_f32(f32_to_bf16_rne(nrm));
-            if (lane == 0 && lead && ha.qnorm_out != nullptr) ha.qnorm_out[h] = nrm;
+            if (!LEAN && lane == 0 && lead && ha.qnorm_out != nullptr) ha.qnorm_out[h] = nrm;
             uint16_t* dst = reinterpret_cast<uint16_t*>(s_q) + lane * per;
             uint16_t* raw = reinterpret_cast<uint16_t*>(s_qraw) + lane * per;
             float tq[4];
@@ -1087,6 +1127,72 @@ __device__ __forceinline__ void lsh_head_body(
             }
         }
     };
+    // ---- LEAN counting: per-token COUNTERS instead of the two bitmaps, a batch of ids at a time.  Stage 1 (lean_first):
+    // every id's counter is incremented by one returning LDS atomic, issued as the id's load arrives, results left in
+    // registers.  Stage 2 (lean_rest): the lanes whose atomic returned 1 -- this was the token's SECOND hit: exactly one
+    // lane per selected token, whatever the interleaving -- append the token's table word (id | key norm) to the WAVE's own
+    // list: position = the wave's cursor (a scalar) + mbcnt of the ballot; no atomic, nothing shared.
+    // The stage-1 atomics are issued by inline asm under an explicit lane mask: (a) only the lanes that hold an id take
+    // part -- a first form with unconditional atomics (idle lanes ORing 0 into words of their own) cost cfg 3 +2 us per
+    // launch: LDS atomics are paid per active lane; (b) an LDS instruction the COMPILER sees under a branch makes it wait
+    // for every outstanding one at the join, which would serialise the batch again.  The compiler does not count them, so
+    // lean_rest starts with an explicit s_waitcnt; its own waits stay correct (LDS operations return in order: waiting
+    // for its k youngest covers everything older, counted or not).
+    int* s_nsel = s_tmp + 27;                                                // selected tokens of the workgroup (sum of the waves')
+    int* s_nspill = s_tmp + 26;                                              // entries of the spill list in HBM
+    const uint32_t lds0 = (uint32_t)(uintptr_t)s_u32;                        // LDS byte offset of the counting area
+    const uint32_t cmask = (1u << (1u << csh)) - 1u;                         // 0xff / 0xffff
+    const int pcap = (AD > 0 ? aa.cap : 0) / RT_WAVES;                       // entries of a wave's own list (256)
+    int32_t* mylist = s_ids + wave * pcap;
+    int32_t* spill_rows = results + h * M + t0;                              // the member's columns of the head's result row: >= its tokens
+    int cur = 0;                                                             // entries this wave has appended (wave-uniform)
+    auto lean_first = [&](int32_t t, uint32_t& u, uint32_t& old) {
+        const uint32_t uu = ((uint32_t)t & idmask) - T0;
+        const bool ok = t != -1 && uu < tlen;
+        u = uu;
+        old = 0u;
+        const unsigned long long m = __ballot(ok);
+        const uint32_t addr = lds0 + ((uu >> (5 - csh)) << 2);
+        const uint32_t one = 1u << ((uu & ((32u >> csh) - 1u)) << csh);
+        unsigned long long sv;
+        // (m is a subset of exec: plain moves, which leave SCC alone -- s_and_saveexec would clobber a condition the
+        // compiler may hold across the asm)
+        asm volatile("s_mov_b64 %1, exec\n\t"
+                     "s_mov_b64 exec, %2\n\t"
+                     "ds_add_rtn_u32 %0, %3, %4\n\t"
+                     "s_mov_b64 exec, %1"
+                     : "+v"(old), "=&s"(sv)
+                     : "s"(m), "v"(addr), "v"(one)
+                     : "memory");
+    };
+    auto lean_rest = [&](auto& t, auto& u, auto& old, int cap_now) {        // cap_now = 0: everything to the spill list
+        constexpr int N = (int)std::extent<typename std::remove_reference<decltype(old)>::type>::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // every counter of the batch has answered
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+            // the counter stood at 1: this lane's id is its token's second hit (a lane without an id kept old = 0)
+            const bool second = ((old[b] >> ((u[b] & ((32u >> csh) - 1u)) << csh)) & cmask) == 1u;
+            const unsigned long long bal = __ballot(second);
+            if (bal != 0ull) {                                               // uniform
+                const int pos = cur + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (second) {
+                    if (pos < cap_now) {
+                        mylist[pos] = t[b];
+                    } else {                                                 // (rare: K = 1-like data, the chunk pool)
+                        const int sp = atomicAdd(s_nspill, 1);
+                        spill_rows[sp] = t[b];
+                    }
+                }
+                cur += __popcll(bal);
+            }
+        }
+    };
+    auto lean_apply1 = [&](int32_t t, int cap_now) {                         // a batch of one (the rare sweeps)
+        int32_t tt[1] = {t};
+        uint32_t uu[1], oo[1];
+        lean_first(t, uu[0], oo[0]);
+        lean_rest(tt, uu, oo, cap_now);
+    };
     auto code_of = [&](int l) {   // HASH 1: bit i of code l <- plane l*K + i
         if (HASH == 2) return (int)ha.codes_out[h * L + l];
         const int bp = l * ha.K, w = bp >> 5, sh = bp & 31;
@@ -1117,7 +1223,27 @@ __device__ __forceinline__ void lsh_head_body(
     }
     const int32_t* slots = (AD > 0) ? aa.slots : nullptr;
     bool tail_first_done = false;   // uniform: the pool's first round went out with the pieces' own loads (sub-bounds path)
-    if (AD > 0 && HASH != 0 && slots != nullptr) {
+    // direct pieces: the barrier behind the pass, and the chunk pool of what is longer than slot + follow-up (skewed data)
+    // (LEAN: run by ONE wave -- the one that drew the last ticket, behind everybody's counting -- without barriers)
+    auto direct_pool_build = [&]() {
+        if constexpr (!LEAN) MP_CHAIN_BARRIER();
+        MP_STAMP(stamp, 17);
+        if (s_tmp[30] > 0) {                                            // uniform; pieces longer than 30 + 96 ids
+            for (int l = LEAN ? lane : tid; l < L; l += LEAN ? WAVE : RT_THREADS) {
+                const int len = s_len[l];                               // start and length were checked in the pass
+                if (len > 0) {
+                    const int nch = (len + 63) >> 6;
+                    const int base = atomicAdd(s_ntail, nch);
+                    for (int c = 0; c < nch && base + c < RT_TAIL_CAP; ++c)
+                        s_tail[base + c] = ((uint32_t)l << 16) | (uint32_t)c;
+                }
+            }
+            if constexpr (!LEAN) __syncthreads();
+        }
+        MP_STAMP(stamp, 18);
+    };
+    const bool direct_path = AD > 0 && HASH != 0 && slots != nullptr;   // uniform
+    if (direct_path) {
         // ---- DIRECT pieces: the piece (table l, bucket code, range rank) has a 128-byte slot holding its length,
         // position and first 30 ids, so ONE dependent round trip (hash -> slot) replaces two (hash -> sub-bounds ->
         // ids).  Half a wave reads a slot; a wave keeps DG loads = 2 DG pieces in flight.  A piece longer than 30
@@ -1168,7 +1294,7 @@ __device__ __forceinline__ void lsh_head_body(
 #pragma unroll
             for (int b = 0; b < DG; ++b) v[b] = MP_TLOAD(sg + at[b]);
             MP_STAMP(stamp, 42);                                     // slot loads issued
-            if ((HASH == 1 || HASH == 3) && lead && sl == 0) {
+            if (!LEAN && (HASH == 1 || HASH == 3) && lead && sl == 0) {
 #pragma unroll
                 for (int b = 0; b < DG; ++b) {
                     const int l = l0 + (b * RT_WAVES + wave) * GPW + grp;
@@ -1187,6 +1313,7 @@ __device__ __forceinline__ void lsh_head_body(
             int32_t e0[DG], e1[DG], e2[DG];
             int r1s[DG];
             uint32_t more = 0u, wide = 0u;                                  // wave-uniform bit masks over b
+            uint32_t lu[LEAN ? DG : 1], lo[LEAN ? DG : 1];                  // LEAN: token index / first-hit result per slot id
 #pragma unroll
             for (int b = 0; b < DG; ++b) {
                 const int l = l0 + (b * RT_WAVES + wave) * GPW + grp;
@@ -1219,9 +1346,38 @@ __device__ __forceinline__ void lsh_head_body(
                         atomicAdd(&s_tmp[30], 1);
                     }
                 }
-                if (l < L && sl >= 2 && sl - 2 < pl) apply(v[b]);       // the slot's own ids
+                if constexpr (LEAN) {
+                    if (!(l < L && sl >= 2 && sl - 2 < pl)) v[b] = -1;
+                    lean_first(v[b], lu[b], lo[b]);                     // the slot's own ids: stage 1 as the slot arrives
+                } else {
+                    if (l < L && sl >= 2 && sl - 2 < pl) apply(v[b]);   // the slot's own ids
+                }
             }
+            if constexpr (LEAN) lean_rest(v, lu, lo, pcap);             // stage 2 for the DG slots together
             if (more) {                                                 // wave-uniform; one wait for all follow-ups
+                if constexpr (LEAN) {
+                    // e0 of every b as ONE batch (lanes without a follow-up id idle), then -- rare -- e1 and e2 as another
+#pragma unroll
+                    for (int b = 0; b < DG; ++b) {
+                        e0[b] = ((more >> b) & 1u) && sl < r1s[b] ? e0[b] : -1;
+                        lean_first(e0[b], lu[b], lo[b]);
+                    }
+                    lean_rest(e0, lu, lo, pcap);
+                    if (wide) {                                         // uniform
+#pragma unroll
+                        for (int b = 0; b < DG; ++b) {
+                            e1[b] = ((wide >> b) & 1u) && sl + SW < r1s[b] ? e1[b] : -1;
+                            lean_first(e1[b], lu[b], lo[b]);
+                        }
+                        lean_rest(e1, lu, lo, pcap);
+#pragma unroll
+                        for (int b = 0; b < DG; ++b) {
+                            e2[b] = ((wide >> b) & 1u) && sl + 2 * SW < r1s[b] ? e2[b] : -1;
+                            lean_first(e2[b], lu[b], lo[b]);
+                        }
+                        lean_rest(e2, lu, lo, pcap);
+                    }
+                } else {
 #pragma unroll
                 for (int b = 0; b < DG; ++b) {
                     if (more & (1u << b)) {
@@ -1231,6 +1387,7 @@ __device__ __forceinline__ void lsh_head_body(
                             apply(sl + 2 * SW < r1s[b] ? e2[b] : -1);
                         }
                     }
+                }
                 }
             }
         }
@@ -1242,21 +1399,7 @@ __device__ __forceinline__ void lsh_head_body(
         else if (L > RT_WAVES * 2 * 6) direct_pass(std::integral_constant<int, 10>{}, std::integral_constant<int, 5>{});
         else direct_pass(std::integral_constant<int, 6>{}, std::integral_constant<int, 5>{});
         MP_STAMP(stamp, 45);                                            // this wave's pieces counted
-        MP_CHAIN_BARRIER();
-        MP_STAMP(stamp, 17);
-        if (s_tmp[30] > 0) {                                            // uniform; pieces longer than 30 + 96 ids
-            for (int l = tid; l < L; l += RT_THREADS) {
-                const int len = s_len[l];                               // start and length were checked above
-                if (len > 0) {
-                    const int nch = (len + 63) >> 6;
-                    const int base = atomicAdd(s_ntail, nch);
-                    for (int c = 0; c < nch && base + c < RT_TAIL_CAP; ++c)
-                        s_tail[base + c] = ((uint32_t)l << 16) | (uint32_t)c;
-                }
-            }
-            __syncthreads();
-        }
-        MP_STAMP(stamp, 18);
+        if constexpr (!LEAN) direct_pool_build();                       // (LEAN: behind the wave's own gather, below)
     } else {
     // probe: the two sub-bounds of this workgroup's token range, adjacent 4-byte words of the bucket's record
     // (issued first: longest latency)
@@ -1266,7 +1409,7 @@ __device__ __forceinline__ void lsh_head_body(
             int code;
             if (HASH != 0) {
                 code = code_of(l);
-                if ((HASH == 1 || HASH == 3) && lead) ha.codes_out[h * L + l] = code;
+                if (!LEAN && (HASH == 1 || HASH == 3) && lead) ha.codes_out[h * L + l] = code;
             } else {
                 code = query[h * L + l];
             }
@@ -1359,11 +1502,32 @@ __device__ __forceinline__ void lsh_head_body(
                 tail_first_done = true;
             }
             // applied in issue order: the first piece's ids are counted while the last piece's are still on their way
-#pragma unroll
-            for (int b = 0; b < RT_GROUP; ++b) apply(lane < ln[b] ? id0[b] : -1);
             bool longer = false;
 #pragma unroll
             for (int b = 0; b < RT_GROUP; ++b) longer = longer || ln[b] > 64;
+            if constexpr (LEAN) {
+                uint32_t lu[RT_GROUP], lo[RT_GROUP];
+#pragma unroll
+                for (int b = 0; b < RT_GROUP; ++b) {
+                    if (!(lane < ln[b])) id0[b] = -1;
+                    lean_first(id0[b], lu[b], lo[b]);
+                }
+                lean_rest(id0, lu, lo, pcap);
+                if (longer) {                                                // wave-uniform (the loads are out already)
+#pragma unroll
+                    for (int b = 0; b < RT_GROUP; ++b) {
+                        if (!(lane + 64 < ln[b])) id1[b] = -1;
+                        lean_first(id1[b], lu[b], lo[b]);
+                    }
+                    lean_rest(id1, lu, lo, pcap);
+                }
+                if (tails_now) {
+#pragma unroll
+                    for (int u = 0; u < RT_TAIL_UNROLL; ++u) lean_apply1((tin >> u) & 1u ? idt[u] : -1, pcap);
+                }
+            } else {
+#pragma unroll
+            for (int b = 0; b < RT_GROUP; ++b) apply(lane < ln[b] ? id0[b] : -1);
             if (longer) {                                                    // wave-uniform (the loads are out already)
 #pragma unroll
                 for (int b = 0; b < RT_GROUP; ++b) apply(lane + 64 < ln[b] ? id1[b] : -1);
@@ -1371,6 +1535,7 @@ __device__ __forceinline__ void lsh_head_body(
             if (tails_now) {
 #pragma unroll
                 for (int u = 0; u < RT_TAIL_UNROLL; ++u) apply((tin >> u) & 1u ? idt[u] : -1);
+            }
             }
         }
     } else
@@ -1396,7 +1561,10 @@ __device__ __forceinline__ void lsh_head_body(
         }
         // applied in issue order: the first piece's ids are counted while the last piece's are still on their way
 #pragma unroll
-        for (int b = 0; b < RT_GROUP; ++b) apply(lane < ln[b] ? id0[b] : -1);
+        for (int b = 0; b < RT_GROUP; ++b) {
+            if constexpr (LEAN) lean_apply1(lane < ln[b] ? id0[b] : -1, pcap);   // (tables beyond 4 GB per KV group: not a tuned path)
+            else apply(lane < ln[b] ? id0[b] : -1);
+        }
         bool longer = false;
 #pragma unroll
         for (int b = 0; b < RT_GROUP; ++b) longer = longer || ln[b] > 64;
@@ -1409,21 +1577,85 @@ __device__ __forceinline__ void lsh_head_body(
                 id1[b] = MP_TLOAD(row + (lane + 64 < ln[b] ? lane + 64 : 0));
             }
 #pragma unroll
-            for (int b = 0; b < RT_GROUP; ++b) apply(lane + 64 < ln[b] ? id1[b] : -1);
+            for (int b = 0; b < RT_GROUP; ++b) {
+                if constexpr (LEAN) lean_apply1(lane + 64 < ln[b] ? id1[b] : -1, pcap);
+                else apply(lane + 64 < ln[b] ? id1[b] : -1);
+            }
         }
     }
     }
     }
+    // ---- LEAN: this wave's own finds are complete (its slots / pieces are counted: a token is appended by the lane that
+    // sees its second hit, and no later hit changes that) -- gather and fold them NOW, while other waves still count; then
+    // the window's share, then the wave's state goes to LDS behind a ticket.  No workgroup barrier from here on: the wave
+    // that draws the LAST ticket does what is left alone -- normally nothing but the merge; with skewed keys the chunk
+    // pool (pieces beyond slot + follow-up, the sub-bounds path's ids beyond 128) and the spill list.
+    constexpr int ADL = AD > 0 ? AD : 64;
+    AhState st_own = ah_state_init(lane, ADL / 8);
+    int cur_pub = 0, pre_total = 0;
+    bool rare = true;                           // LEAN, uniform: the last wave has pooled chunks / a spill list to see to
+    float m = 0.f, Z = 0.f, o0 = 0.f, o1 = 0.f;
+    if constexpr (LEAN) {
+        MP_STAMP(stamp, 33);
+        const int n_own = cur < pcap ? cur : pcap;                       // (the rest went to the spill list)
+        const u32x4 qv_l = *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADL / 8)) * 4);
+        auto own = [&](int j) { return *reinterpret_cast<const u32x4*>(mylist + j); };
+        const uint16_t* kv_l = aa.kv + g * M * 2 * ADL;
+        const float* kn_l = aa.kn + g * M;
+        constexpr int SHORT_L = (ADL == 128) ? 16 : AH_SLICE;
+        if (SHORT_L < AH_SLICE && n_own <= SHORT_L)                      // uniform per wave
+            attn_head_fold_lean<ADL, SHORT_L>(st_own, kv_l, kn_l, qv_l, s_rn[1], n_own, M, ha.K, L, 0, 1, own, idmask,
+                                              idbits, pay, stamp);
+        else
+            attn_head_fold_lean<ADL, AH_SLICE>(st_own, kv_l, kn_l, qv_l, s_rn[1], n_own, M, ha.K, L, 0, 1, own, idmask,
+                                               idbits, pay, stamp);
+        if (WIN && aa.win_kv != nullptr) {      // the static window: dense slices rank, rank + R, ... over the waves
+            int wl = aa.win_len[h];
+            wl = wl < 0 ? 0 : (wl > aa.win_M ? (int)aa.win_M : wl);
+            auto none = [](int) { return u32x4{0u, 0u, 0u, 0u}; };
+            if (wl > 0)
+                attn_head_fold<ADL, RT_WAVES, true, AH_SLICE>(st_own, aa.win_kv + g * aa.win_M * 2 * ADL, nullptr, qv_l, 1.f,
+                                                              wl, aa.win_M, 0, 0, rank, 1 << clog, none, nullptr, stamp);
+        }
+#if MP_STAMPS
+        // per-wave: own fold done (slots 48 + wave; bits 0..9 of the 100 MHz stamp replaced by the wave's list length)
+        if (stamp != nullptr && lane == 0)
+            ::mp::s_stampbuf[48 + wave] = (wall_clock64() << 10) | (unsigned long long)(cur < 1023 ? cur : 1023);
+#endif
+        attn_head_publish<ADL>(st_own, s_merge);
+        if (lane == 0 && cur > 0) atomicAdd(s_nsel, cur);
+        if (cur > pcap) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's spill stores are acknowledged
+        int tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(s_tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk != RT_WAVES - 1) {
+            MP_STAMP_FLUSH(stamp);
+            return;
+        }
+        MP_STAMP_L(stamp, 40);                                           // every wave's state is in LDS
+        // ONE round of LDS reads for all the last wave normally needs: the sixteen states, the count, and the three words
+        // that say whether anything is left to do (as dependent reads further down they were four round trips)
+        const int v30 = s_tmp[30], vnt = *s_ntail, vsp = *s_nspill;
+        pre_total = *s_nsel;
+        attn_head_merge_read<ADL, RT_WAVES>(s_merge, m, Z, o0, o1);
+        rare = (direct_path && v30 > 0) || vnt > 0 || vsp > 0;
+        cur_pub = cur;
+        if (rare && direct_path) direct_pool_build();
+    }
+    // (LEAN: what follows is run by one wave)
+    const int pw = LEAN ? 0 : wave;
+    constexpr int PN = LEAN ? 1 : RT_WAVES, PT = LEAN ? WAVE : RT_THREADS;
+    const int ptid = LEAN ? lane : tid;
     // ids beyond the first 128 of a piece (skewed data): pooled 64-id chunks, waves take them
     // round-robin with RT_TAIL_UNROLL loads in flight
-    const int ntail = __builtin_amdgcn_readfirstlane(*s_ntail);
+    const int ntail = (LEAN && !rare) ? 0 : __builtin_amdgcn_readfirstlane(*s_ntail);
     if (ntail <= RT_TAIL_CAP) {
         // (sub-bounds path, one-trip stream: the first round of the pool went out with the pieces' own loads)
-        for (int c0 = wave + (tail_first_done ? RT_WAVES * RT_TAIL_UNROLL : 0); c0 < ntail; c0 += RT_WAVES * RT_TAIL_UNROLL) {
+        for (int c0 = pw + (tail_first_done ? PN * RT_TAIL_UNROLL : 0); c0 < ntail; c0 += PN * RT_TAIL_UNROLL) {
             int32_t idt[RT_TAIL_UNROLL];
 #pragma unroll
             for (int u = 0; u < RT_TAIL_UNROLL; ++u) {
-                const int c = c0 + u * RT_WAVES;
+                const int c = c0 + u * PN;
                 idt[u] = -1;
                 if (c < ntail) {
                     const uint32_t d = s_tail[c];
@@ -1431,8 +1663,15 @@ __device__ __forceinline__ void lsh_head_body(
                     if (j < s_len[l]) idt[u] = tab[(int64_t)l * M + s_start[l] + j];
                 }
             }
+            if constexpr (LEAN) {
+                uint32_t lu[RT_TAIL_UNROLL], lo[RT_TAIL_UNROLL];
+#pragma unroll
+                for (int u = 0; u < RT_TAIL_UNROLL; ++u) lean_first(idt[u], lu[u], lo[u]);
+                lean_rest(idt, lu, lo, 0);                    // (the pool runs behind the waves' own gathers: spill list)
+            } else {
 #pragma unroll
             for (int u = 0; u < RT_TAIL_UNROLL; ++u) apply(idt[u]);
+            }
         }
     } else {   // pool overflow (> 128 K extra ids per head): plain strided sweep of every long piece
         const int first = (AD > 0 && slots != nullptr) ? 0 : 128;      // direct mode: s_start is already past the slot's ids
@@ -1440,11 +1679,23 @@ __device__ __forceinline__ void lsh_head_body(
             const int len = s_len[l];
             if (len <= first) continue;
             const int32_t* row = tab + (int64_t)l * M + s_start[l];
-            for (int j = first + tid; j < len; j += RT_THREADS) apply(row[j]);
+            for (int j0 = first; j0 < len; j0 += PT) {                       // (uniform trip count: the LEAN form ballots)
+                const int j = j0 + ptid;
+                const int32_t t = j < len ? row[j] : -1;
+                if constexpr (LEAN) lean_apply1(t, 0);
+                else apply(t);
+            }
         }
     }
+    if constexpr (LEAN) {
+        if (cur > cur_pub) {                                            // uniform: the pool's finds (spill list)
+            if (lane == 0) atomicAdd(s_nsel, cur - cur_pub);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
     // (direct pass without pooled chunks: nothing was counted since the barrier behind the pass)
-    if (!(AD > 0 && HASH != 0 && slots != nullptr && ntail == 0)) MP_CHAIN_BARRIER();
+    if (!(direct_path && ntail == 0)) MP_CHAIN_BARRIER();
+    }
     MP_STAMP(stamp, 19);
 
     // sweep B: contiguous words per thread, block-wide exclusive scan, ascending emission
@@ -1455,16 +1706,25 @@ __device__ __forceinline__ void lsh_head_body(
     const int nsw = words;
     const int wpt = (nsw + RT_THREADS - 1) / RT_THREADS;
     const int w0 = tid * wpt;
-    for (int k = 0; k < wpt; ++k)
-        if (w0 + k < nsw) cnt += __popc(bmB[w0 + k]);
-    int total;
-    int off = block_excl_scan<MP_LDS_BARRIERS != 0>(cnt, s_tmp, total);
+    // LEAN: there is no list to emit -- the waves have folded their own finds; the workgroup's count is in *s_nsel
+    int total = 0, off = 0;
+    constexpr bool ordered = !LEAN;
+    int nspill = 0;                                                  // uniform
+    if constexpr (LEAN) {
+        total = rare ? *s_nsel : pre_total;
+        nspill = rare ? *s_nspill : 0;
+    }
+    if (ordered) {
+        for (int k = 0; k < wpt; ++k)
+            if (w0 + k < nsw) cnt += __popc(bmB[w0 + k]);
+        off = block_excl_scan<MP_LDS_BARRIERS != 0>(cnt, s_tmp, total);
+    }
     MP_STAMP(stamp, 20);
     // AD: the member's ids stay in LDS; a list longer than the stage (cap ids) is read back from HBM
-    const bool spill = AD > 0 && total > aa.cap;
+    const bool spill = !LEAN && AD > 0 && total > aa.cap;
     uint32_t cs1 = 0u, cs2 = 0u;            // stand-alone retrieve: checksum of this thread's entries (host-buffer mode)
     int32_t* out2 = (AD == 0 && aa.rows2 != nullptr) ? aa.rows2 + h * M : nullptr;
-    for (int k = 0; k < wpt; ++k) {
+    for (int k = 0; k < wpt && ordered; ++k) {
         if (w0 + k >= nsw) break;
         uint32_t bits = bmB[w0 + k];
         const int base = (int)T0 + ((w0 + k) << 5);
@@ -1485,7 +1745,7 @@ __device__ __forceinline__ void lsh_head_body(
             ++off;
         }
     }
-    if (tid == 0 && (AD == 0 || clog == 0)) {
+    if ((LEAN ? lane : tid) == 0 && (AD == 0 || clog == 0)) {
         nnz[h] = total;
         if (AD == 0 && aa.rows2 != nullptr && aa.part_cnt != nullptr) aa.part_cnt[h] = total;
     }
@@ -1516,7 +1776,7 @@ __device__ __forceinline__ void lsh_head_body(
         wlen = aa.win_len[h];
         wlen = wlen < 0 ? 0 : (wlen > aa.win_M ? (int)aa.win_M : wlen);
     }
-    if (clog == 0 && total == 0 && wlen == 0) {
+    if (!LEAN && clog == 0 && total == 0 && wlen == 0) {
         attn_head_empty<ADD>(out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
         MP_STAMP_FLUSH(stamp);
         return;
@@ -1524,13 +1784,15 @@ __device__ __forceinline__ void lsh_head_body(
     // s_ids complete.  Only a SPILLED list is read back from HBM by other waves (ids_hbm): only then must the stores have
     // drained (vmcnt) and be visible in L2; otherwise the barrier orders LDS alone -- the by-product rows' stores are
     // acknowledged ~0.5 us after they were issued, and this barrier sits on the path to the first row request
-    if (spill || !MP_LDS_BARRIERS) __syncthreads();
-    else lds_barrier();
+    // (LEAN, list in the stage: the counting barrier already ordered the appended ids in front of everything below)
+    if constexpr (!LEAN) {
+        if (spill || !MP_LDS_BARRIERS) __syncthreads();
+        else lds_barrier();
+    }
     MP_STAMP(stamp, 33);
     // two instantiations of the sparse fold: the LDS path carries no global load ahead of its gathers
-    float m, Z, o0, o1;
     const u32x4 qv = *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADD / 8)) * 4);
-    float* score_h = aa.score ? aa.score + h * M + t0 : nullptr;
+    float* score_h = (!LEAN && aa.score) ? aa.score + h * M + t0 : nullptr;
     const uint16_t* kv_g = aa.kv + g * M * 2 * ADD;
     const float* kn_g = aa.kn + g * M;
     auto ids_lds = [&](int j) { return *reinterpret_cast<const u32x4*>(s_ids + j); };
@@ -1546,8 +1808,15 @@ __device__ __forceinline__ void lsh_head_body(
     // steps + 129 ids) -- 37.2 us per layer against 35.6 with HBM saturated.
     constexpr int SHORT = (ADD == 128) ? 16 : AH_SLICE;
     const bool short_list = SHORT < AH_SLICE && total <= SHORT * RT_WAVES && !spill;
-    AhState st = ah_state_init(lane, ADD / 8);
+    AhState st = LEAN ? st_own : ah_state_init(lane, ADD / 8);
     const uint16_t* kn_lds = pay ? s_kn : nullptr;
+    if constexpr (LEAN) {
+        // the waves folded their own finds above; what is left is the spill list (raw table words in this member's columns
+        // of the result row; every wave waited for its stores before it drew its ticket), folded by this one wave
+        if (nspill > 0)                                                  // uniform
+            attn_head_fold_lean<ADD, AH_SLICE>(st, kv_g, kn_g, qv, s_rn[1], nspill, M, ha.K, L, 0, 1, ids_hbm,
+                                               idmask, idbits, pay, stamp);
+    } else
     if (short_list)
         attn_head_fold<ADD, RT_WAVES, false, SHORT>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1, ids_lds,
                                                     score_h, stamp, 0, kn_lds, (int)T0);
@@ -1557,16 +1826,26 @@ __device__ __forceinline__ void lsh_head_body(
     else
         attn_head_fold<ADD, RT_WAVES, false, AH_SLICE>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1,
                                                        ids_hbm, score_h, stamp, 0, kn_lds, (int)T0);
-    if (WIN && wlen > 0) {                  // the static window: dense slices rank, rank + R, ... (k runs from
+    if (!LEAN && WIN && wlen > 0) {         // the static window: dense slices rank, rank + R, ... (k runs from
                                             // `wave` again, so the waves that got no sparse slice are served first)
         auto none = [](int) { return u32x4{0u, 0u, 0u, 0u}; };
         attn_head_fold<ADD, RT_WAVES, true, AH_SLICE>(st, aa.win_kv + g * aa.win_M * 2 * ADD, nullptr, qv, 1.f, wlen,
                                                       aa.win_M, 0, 0, rank, 1 << clog, none, nullptr, stamp);
     }
+    if constexpr (LEAN) {                   // (this wave drew the last ticket above; its own slot again if it folded more)
+        if (rare) {
+            if (nspill > 0) attn_head_publish<ADD>(st, s_merge);
+            attn_head_merge_read<ADD, RT_WAVES>(s_merge, m, Z, o0, o1);
+        }
+    } else {
 #if MP_MERGE_TICKET
     // no workgroup barrier: the wave that draws the last LDS ticket merges and goes on to the hand-off -- ONE wave from
     // here on, whichever it is (round 5; EXPERIMENTS.md R5-2)
-    if (!attn_head_merge_ticket<ADD, RT_WAVES>(st, s_merge, s_tk, m, Z, o0, o1)) return;
+    if (!attn_head_merge_ticket<ADD, RT_WAVES>(st, s_merge, s_tk, m, Z, o0, o1)) {
+        MP_STAMP_FLUSH(stamp);
+        return;
+    }
+    MP_STAMP_L(stamp, 40);
 #else
     attn_head_merge<ADD, RT_WAVES, true>(st, s_merge, m, Z, o0, o1);
     MP_STAMP(stamp, 40);   // the waves' states have met in LDS (the barrier waits for the wave whose rows came last)
@@ -1574,10 +1853,11 @@ __device__ __forceinline__ void lsh_head_body(
     // own stores, ticket and loads, and the other fifteen are done
     if (wave != 0) return;
 #endif
+    }
     if (clog == 0) {
         attn_head_finalize<ADD>(m, Z, o0, o1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
-        MP_STAMP(stamp, 39);
-        MP_STAMP_FLUSH(stamp);
+        MP_STAMP_L(stamp, 39);
+        MP_STAMP_FLUSH_L(stamp);
         return;
     }
     // ---- cluster > 1: publish this member's state (a member without tokens publishes m = -inf, Z = 0), drain,
@@ -1618,13 +1898,13 @@ __device__ __forceinline__ void lsh_head_body(
             __builtin_amdgcn_raw_buffer_store_b32((uint32_t)total | (my_xcc << 24), rc, rank * 4, 0, kSc0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing lane of this wave drained
-        MP_STAMP(stamp, 41);
+        MP_STAMP_L(stamp, 41);
         if (lane == 0)
             ticket = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
-        MP_STAMP(stamp, 38);
+        MP_STAMP_L(stamp, 38);
         if (ticket != nmem - 1) {
-            MP_STAMP_FLUSH(stamp);
+            MP_STAMP_FLUSH_L(stamp);
             return;
         }
         if (lane == 0) {
@@ -1648,9 +1928,9 @@ __device__ __forceinline__ void lsh_head_body(
         if (lane == 0)
             ticket = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
-        MP_STAMP(stamp, 38);
+        MP_STAMP_L(stamp, 38);
         if (ticket != nmem - 1) {
-            MP_STAMP_FLUSH(stamp);
+            MP_STAMP_FLUSH_L(stamp);
             return;
         }
         if (lane == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1734,8 +2014,8 @@ __device__ __forceinline__ void lsh_head_body(
     else merge_records(std::integral_constant<int, 32>{});
     attn_head_finalize<ADD>(mm, ZZ, q0, q1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);   // ZZ = 0: no member had a token
     if (lane == 0) nnz[h] = csum;
-    MP_STAMP(stamp, 39);
-    MP_STAMP_FLUSH(stamp);
+    MP_STAMP_L(stamp, 39);
+    MP_STAMP_FLUSH_L(stamp);
 }
 
 // LSH::batch_retrieve (optionally with the query hash as its prologue)
@@ -1757,14 +2037,14 @@ __global__ __launch_bounds__(RT_THREADS, 4) void lsh_retrieve_kernel(
 }
 
 // the whole sparse layer of models/attnserver.py:264-300: hash -> retrieve -> attention
-template <int CH, int AD, bool WIN, int HASH = 1>
+template <int CH, int AD, bool WIN, int HASH = 1, bool LEAN = false>
 __global__ __launch_bounds__(RT_THREADS, 4) void lsh_decode_kernel(
     const int32_t* __restrict__ bounds, const int32_t* __restrict__ table,
     int32_t* __restrict__ results, int32_t* __restrict__ nnz,
     int G, int L, int NB, int64_t M, int R, int range_len, int words, int Lpad, int idbits, HashArgs ha, AttnArgs aa,
     unsigned long long* __restrict__ stamp) {
-    lsh_head_body<HASH, CH, AD, WIN>(bounds, table, nullptr, results, nnz, G, L, NB, M, R, range_len, words, Lpad,
-                                     idbits, ha, aa, stamp);
+    lsh_head_body<HASH, CH, AD, WIN, LEAN>(bounds, table, nullptr, results, nnz, G, L, NB, M, R, range_len, words, Lpad,
+                                           idbits, ha, aa, stamp);
 }
 
 // The decode kernel leaves member r's selected ids / logits at column r * range_len of the head's row; this
@@ -2052,8 +2332,13 @@ bool xcd_round_robin_verified() { return xcd_round_robin_map(nullptr); }
 
 constexpr int DECODE_ID_CAP = 4096;   // ids of the fused kernel's LDS stage per workgroup (128 slices)
 
-static size_t decode_lds_bytes(int64_t tokens, int L, int D) {
-    return body_lds_bytes(tokens, L) + ((size_t)DECODE_ID_CAP + attn_head_lds_floats(RT_WAVES, D) + 16 + 64) * 4;
+static size_t decode_lds_bytes(int64_t tokens, int L, int D, bool lean = false) {
+    size_t b = body_lds_bytes(tokens, L) + ((size_t)DECODE_ID_CAP + attn_head_lds_floats(RT_WAVES, D) + 16 + 64) * 4;
+    if (lean) {      // per-token counters (8 bits while L <= 255, else 16) in place of the two bitmaps
+        const size_t words = (size_t)((tokens + 31) / 32);
+        b += ((words << (L <= 255 ? 3 : 4)) - 2 * words) * 4;
+    }
+    return b;
 }
 
 static hipError_t retrieve_attr_set() {
@@ -2069,7 +2354,15 @@ static hipError_t retrieve_attr_set() {
                          reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, false, 3>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, false, 3>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, true, 3>),
-                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, true, 3>)};
+                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, true, 3>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, false, 1, true>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, false, 1, true>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, true, 1, true>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, true, 1, true>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, false, 3, true>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, false, 3, true>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, true, 3, true>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, true, 3, true>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RT_LDS_DYN_MAX);
         if (e != hipSuccess) return e;
@@ -2153,7 +2446,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                              const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
                              bool codes_given, unsigned long long* xw, unsigned int* xseq, int xwords, int xmode,
                              int idbits, const int* idbits_dev, const int* pay_bad, const unsigned int* att_ver,
-                             const unsigned int* kn_ver, hipStream_t st) {
+                             const unsigned int* kn_ver, bool lean, bool* lean_ran, hipStream_t st) {
     const int range_len = lsh_range_len(M, R);
     const int words = range_len / 32;
     const int Lpad = (L + 63) & ~63;
@@ -2175,13 +2468,21 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     const dim3 grid((unsigned)BHp << clog);
     size_t lds = decode_lds_bytes(range_len, L, D);
     // key norms from the table entries' payload: 2 bytes of LDS per token of a member's range, where they fit
-    if (pay_bad != nullptr && att_ver != nullptr && kn_ver != nullptr && idbits != 0 &&
-        lds + (size_t)range_len * 2 + 16 <= RT_LDS_DYN_MAX) {
+    const bool want_pay = pay_bad != nullptr && att_ver != nullptr && kn_ver != nullptr && idbits != 0 &&
+                          lds + (size_t)range_len * 2 + 16 <= RT_LDS_DYN_MAX;
+    // the LEAN form keeps a counter per token where the other keeps two bits: only where that fits next to everything
+    // else (the payload's norms first: they are worth more than the lean form)
+    if (lean) {      // (a selected token's norm travels in its list entry there: no norm array)
+        if (decode_lds_bytes(range_len, L, D, true) <= RT_LDS_DYN_MAX && !codes_given) lds = decode_lds_bytes(range_len, L, D, true);
+        else lean = false;
+    }
+    if (want_pay) {
         aa.pay_bad = pay_bad;
         aa.att_ver = att_ver;
         aa.kn_ver = kn_ver;
-        lds += (size_t)range_len * 2 + 16;
+        if (!lean) lds += (size_t)range_len * 2 + 16;
     }
+    if (lean_ran) *lean_ran = lean;
     if (codes_given) {   // A/B: the codes and ||q|| come from simhash_query_kernel (plain decode only)
         if (win_kv != nullptr) return hipErrorInvalidValue;
         if (D == 128)
@@ -2194,8 +2495,14 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     }
 #define MP_DECODE_CASE(DD, CHH, WW)                                                                            \
     if (D == DD && (win_kv != nullptr) == WW) {                                                                \
-        if (split_hash)                                                                                        \
+        if (split_hash && lean)                                                                                \
+            hipLaunchKernelGGL((lsh_decode_kernel<CHH, DD, WW, 3, true>), grid, dim3(RT_THREADS), lds, st, bounds,   \
+                               table, results, nnz, G, L, NB, M, R, range_len, words, Lpad, idbits, ha, aa, g_stamp);  \
+        else if (split_hash)                                                                                   \
             hipLaunchKernelGGL((lsh_decode_kernel<CHH, DD, WW, 3>), grid, dim3(RT_THREADS), lds, st, bounds,   \
+                               table, results, nnz, G, L, NB, M, R, range_len, words, Lpad, idbits, ha, aa, g_stamp);  \
+        else if (lean)                                                                                         \
+            hipLaunchKernelGGL((lsh_decode_kernel<CHH, DD, WW, 1, true>), grid, dim3(RT_THREADS), lds, st, bounds,   \
                                table, results, nnz, G, L, NB, M, R, range_len, words, Lpad, idbits, ha, aa, g_stamp);  \
         else                                                                                                   \
             hipLaunchKernelGGL((lsh_decode_kernel<CHH, DD, WW>), grid, dim3(RT_THREADS), lds, st, bounds,      \

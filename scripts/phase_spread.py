@@ -52,6 +52,7 @@ if data != "randn":     # heavy hitters (bench.py --queries heavy)
         qs[:, li, :, :, 0] = 0.5 * qs[:, li, :, :, 0] + 3.0 * kcen[bi, gi, j].float()
 qs = qs.to(torch.bfloat16)
 server.collect_nnz = False
+server.by_products = os.environ.get("MP_LEAN", "0") != "1"      # MP_LEAN=1: the MP_DECODE_NO_BYPRODUCTS launch
 for r in range(3):
     for li in range(NLAYER): server.decode(qs[r % reps, li], li)
 torch.cuda.synchronize()
@@ -65,6 +66,7 @@ names = ["start", "q row in", "normalised", "own unit", "hashed", "slots issued"
          "wave counted", "pieces in", "stream done", "own words scanned", "ids staged", "gathers issued",
          "qk", "transform", "pv", "states met", "stores acked", "ticket", "end (merger)"]
 acc = []
+perwave = []
 if use_graph:
     q_static = qs[0].clone()
     side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
@@ -80,8 +82,14 @@ if use_graph:
         stamp.zero_()
         q_static.copy_(qs[(r + 1) % reps])
         graph.replay(); torch.cuda.synchronize()
-        a = stamp.cpu().numpy().reshape(grid, STRIDE)[:, slots].astype(np.float64) * 0.01
+        raw = stamp.cpu().numpy().reshape(grid, STRIDE)
+        a = raw[:, slots].astype(np.float64) * 0.01
         a[a == 0] = np.nan
+        if os.environ.get("MP_LEAN", "0") == "1":      # per-wave: (own fold done << 10 | list length) in slots 48 .. 63
+            pw = raw[:, 48:64]
+            t = (pw >> 10).astype(np.float64) * 0.01
+            t[pw == 0] = np.nan
+            perwave.append((t - np.nanmin(a[:, 0]), (pw & 1023).astype(np.int64)))
         # every launch of the replay overwrote the slots it passed: keep the workgroups whose stamps are those of ONE
         # launch (monotone), relative to the last launch's first start
         acc.append(a - np.nanmin(a[:, 0]))
@@ -105,3 +113,23 @@ for i, nm in enumerate(names):
     st = [np.nanmedian(f(x, axis=1)) for f in (np.nanmin, np.nanmedian, lambda v, axis: np.nanpercentile(v, 90, axis=axis), np.nanmax)]
     r0 = np.nanmedian(x[:, :BHp]); ro = np.nanmedian(x[:, BHp:]) if R > 1 else float("nan")
     print(f"{nm:>16} {st[0]:7.2f} {st[1]:7.2f} {st[2]:7.2f} {st[3]:7.2f}   {r0:7.2f} / {ro:7.2f}")
+
+if perwave:
+    t = np.array([p[0] for p in perwave]); n = np.array([p[1] for p in perwave])      # [runs, grid, 16]
+    print("per-wave own fold done (us): median %.2f  p90 %.2f  p99 %.2f  max(median over runs of per-launch max) %.2f" % (
+        np.nanmedian(t), np.nanpercentile(t, 90), np.nanpercentile(t, 99), np.nanmedian(np.nanmax(t, axis=(1, 2)))))
+    for lo, hi in ((0, 8), (9, 16), (17, 24), (25, 32), (33, 1023)):
+        sel = (n >= lo) & (n <= hi)
+        if sel.any():
+            print("  list length %3d..%3d: %5.1f %% of waves, fold done median %.2f  p90 %.2f  max %.2f" % (
+                lo, hi, 100.0 * sel.mean(), np.nanmedian(t[sel]), np.nanpercentile(t[sel], 90), np.nanmax(t[sel])))
+    wg_last = np.nanmax(t, axis=2)                      # [runs, grid]: the workgroup's slowest wave
+    wg_n = n.sum(axis=2)
+    print("workgroup's slowest wave: median %.2f  p90 %.2f  max %.2f;  tokens per workgroup: median %d  max %d" % (
+        np.nanmedian(wg_last), np.nanpercentile(wg_last, 90), np.nanmedian(np.nanmax(wg_last, axis=1)), np.median(wg_n), wg_n.max()))
+    big = wg_n >= np.percentile(wg_n, 90)
+    print("  workgroups in the top decile by tokens: slowest wave median %.2f;  the rest: %.2f" % (
+        np.nanmedian(wg_last[big]), np.nanmedian(wg_last[~big])))
+    late = wg_last >= np.nanpercentile(wg_last, 95)
+    print("  the 5 %% slowest workgroups: tokens median %d, their slowest wave's list length median %d" % (
+        np.median(wg_n[late]), np.median(np.take_along_axis(n, np.nanargmax(np.where(np.isnan(t), -1, t), axis=2)[..., None], axis=2)[..., 0][late])))
