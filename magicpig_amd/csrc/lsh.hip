@@ -109,6 +109,12 @@ constexpr int RT_GROUP = 12;               // buckets in flight per wave per rou
                                            // -0.07 us per layer at cfg 1 / cfg 4, -0.45 at cfg 0, -0.03 at cfg 3; A/B: -DMP_MERGE_TICKET=0,
                                            // which the stamp build uses -- its "states met" stamp belongs to wave 0)
 #endif
+#ifndef MP_LEAN_GREEDY
+#define MP_LEAN_GREEDY 0                   // LEAN, A/B (-DMP_LEAN_GREEDY=1, measured slower: EXPERIMENTS.md R6-1): an idle wave takes what the
+#endif                                     // list holds (>= MP_LEAN_MIN entries, compare-and-swap on the head) instead of waiting for a full slice
+#ifndef MP_LEAN_MIN
+#define MP_LEAN_MIN 8
+#endif
 #ifndef MP_SETPRIO_WAVE0
 #define MP_SETPRIO_WAVE0 0                 // s_setprio 3 on wave 0 while it normalises the query row (A/B)
 #endif
@@ -767,15 +773,17 @@ struct AttnArgs {
 // to ha.codes_out / ha.qnorm_out by simhash_query_kernel (the MFMA kernel) in a launch of its own: the A/B
 // variant of the decode entry behind the decode_mfma_hash option.
 // LEAN (decode only; mp_decode_*_ex with MP_DECODE_NO_BYPRODUCTS): the launch leaves no by-products -- no codes, no ||q||,
-// no result rows, no logits -- and there is no workgroup-wide list of selected ids at all: every WAVE appends the tokens
-// whose SECOND collision it counted (exactly one lane per selected token sees its counter go 1 -> 2, whatever the
-// interleaving) to a list of its own in LDS and gathers their K / V rows the moment its own counting is done -- no barrier,
-// no popcount sweep, no block scan, no ordered emission, no staging between "counted" and the first row request.  A wave's
-// share is Poisson (~12 tokens at cfg 1): one 16-token step, a 32-token step above 16; the slots past its count request
-// nothing (buffer loads beyond num_records).  What bounds the gather is the number of row requests a CU turns over
-// (EXPERIMENTS.md R3-10), not which wave issues them -- so they should start as early as they can.  Entries beyond a wave's
-// 256-entry list (nearly every token selected: K = 1 tests) and the chunk pool's finds go through a spill list in HBM,
-// folded by the whole workgroup at the end.
+// no result rows, no logits -- and nothing between "counted" and the first row request: no workgroup barrier, no popcount
+// sweep, no block scan, no ordered emission, no staging.  A token joins the workgroup's list in LDS the moment its SECOND
+// collision is counted (exactly one lane sees its counter go 1 -> 2, whatever the interleaving: a reservation by one LDS
+// atomic per wave and batch); a wave that is done counting CLAIMS the next 16 (32) entries of that list with another atomic
+// and gathers them at once -- while other waves still count -- and comes back for more until production is over.  Balanced
+// by construction (every step is a full slice, whoever takes it) and as early as it can be: what bounds the gather is the
+// row requests a CU turns over (EXPERIMENTS.md R3-10; measured per wave here: a step's time grows with its valid rows), so
+// they should start early and be spread evenly.  (Round 6 first built wave-OWNED lists -- no reservation, a Poisson share per
+// wave: the workgroup then waits for its longest list, R6-1.)  Entries beyond the 4 096-entry stage (nearly every token
+// selected: K = 1 tests) and the chunk pool's finds go through a spill list in HBM, folded by the wave that draws the last
+// ticket.
 template <int HASH, int CH, int AD, bool WIN, bool LEAN = false>    // CH = min(16, D / 8): plane chunks kept in registers (HASH only);
                                                  // WIN: fold the static window in (its own instantiation, so the
                                                  // plain decode kernel carries none of its code)
@@ -863,12 +871,16 @@ __device__ __forceinline__ void lsh_head_body(
         if (AD > 0) s_tk[0] = 0;                                  // (MP_MERGE_TICKET: the waves' LDS ticket)
         s_tmp[30] = 0;                                            // pieces that overflow their direct slot
         s_tmp[29] = 1;                                            // split hash: every word of the head arrived
-        s_tmp[27] = 0;                                            // LEAN: selected tokens of the workgroup
-        s_tmp[26] = 0;                                            // LEAN: entries of the spill list
+        s_tmp[27] = 0;                                            // LEAN: entries reserved in the workgroup's list (= tokens selected)
+        s_tmp[25] = 0;                                            // LEAN: entries claimed
+        s_tmp[24] = 0;                                            // LEAN: waves done counting
     }
     // collision bitmaps and piece lengths start at zero: done here, under the query row's round trip
     if constexpr (LEAN) {                                     // (cw is a multiple of 8: 16-byte stores)
         for (int i = tid * 4; i < cw; i += RT_THREADS * 4) *reinterpret_cast<u32x4*>(s_u32 + i) = u32x4{0u, 0u, 0u, 0u};
+        // the list: every entry "not written yet" (-1 is no table word: the packing refuses a NaN norm, an id is < M)
+        for (int i = tid * 4; i < (AD > 0 ? aa.cap : 0); i += RT_THREADS * 4)
+            *reinterpret_cast<u32x4*>(s_ids + i) = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     } else {
         for (int i = tid; i < 2 * words; i += RT_THREADS) s_u32[i] = 0u;
     }
@@ -1138,14 +1150,15 @@ __device__ __forceinline__ void lsh_head_body(
     // for every outstanding one at the join, which would serialise the batch again.  The compiler does not count them, so
     // lean_rest starts with an explicit s_waitcnt; its own waits stay correct (LDS operations return in order: waiting
     // for its k youngest covers everything older, counted or not).
-    int* s_nsel = s_tmp + 27;                                                // selected tokens of the workgroup (sum of the waves')
-    int* s_nspill = s_tmp + 26;                                              // entries of the spill list in HBM
+    int* s_res = s_tmp + 27;                                                 // entries reserved in the list (incl. those beyond the stage)
+    int* s_head = s_tmp + 25;                                                // entries claimed by gathering waves
+    int* s_done = s_tmp + 24;                                                // waves that have finished counting
     const uint32_t lds0 = (uint32_t)(uintptr_t)s_u32;                        // LDS byte offset of the counting area
     const uint32_t cmask = (1u << (1u << csh)) - 1u;                         // 0xff / 0xffff
-    const int pcap = (AD > 0 ? aa.cap : 0) / RT_WAVES;                       // entries of a wave's own list (256)
-    int32_t* mylist = s_ids + wave * pcap;
+    const int lcap = AD > 0 ? aa.cap : 0;                                    // entries of the stage (4 096)
     int32_t* spill_rows = results + h * M + t0;                              // the member's columns of the head's result row: >= its tokens
-    int cur = 0;                                                             // entries this wave has appended (wave-uniform)
+    int nsp = 0;                                                             // the last wave alone: entries it has put on the spill list
+    bool spilled = false;                                                    // uniform: this wave has stores to the spill list in flight
     auto lean_first = [&](int32_t t, uint32_t& u, uint32_t& old) {
         const uint32_t uu = ((uint32_t)t & idmask) - T0;
         const bool ok = t != -1 && uu < tlen;
@@ -1165,33 +1178,45 @@ __device__ __forceinline__ void lsh_head_body(
                      : "s"(m), "v"(addr), "v"(one)
                      : "memory");
     };
-    auto lean_rest = [&](auto& t, auto& u, auto& old, int cap_now) {        // cap_now = 0: everything to the spill list
+    // alone = false: reserve in the workgroup's list; alone = true (the wave that drew the last ticket, nobody left to claim):
+    // straight to the spill list, positions from a register
+    auto lean_rest = [&](auto& t, auto& u, auto& old, bool alone) {
         constexpr int N = (int)std::extent<typename std::remove_reference<decltype(old)>::type>::value;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // every counter of the batch has answered
+        int run = 0;                                                         // wave-uniform
+        int off[N];
 #pragma unroll
         for (int b = 0; b < N; ++b) {
             // the counter stood at 1: this lane's id is its token's second hit (a lane without an id kept old = 0)
             const bool second = ((old[b] >> ((u[b] & ((32u >> csh) - 1u)) << csh)) & cmask) == 1u;
             const unsigned long long bal = __ballot(second);
-            if (bal != 0ull) {                                               // uniform
-                const int pos = cur + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                if (second) {
-                    if (pos < cap_now) {
-                        mylist[pos] = t[b];
-                    } else {                                                 // (rare: K = 1-like data, the chunk pool)
-                        const int sp = atomicAdd(s_nspill, 1);
-                        spill_rows[sp] = t[b];
-                    }
+            off[b] = second ? run + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u)) : -1;
+            run += __popcll(bal);
+        }
+        if (run > 0) {                                                       // uniform
+            int base = lcap + nsp;
+            if (!alone) {
+                if (lane == 0) base = atomicAdd(s_res, run);
+                base = __builtin_amdgcn_readfirstlane(base);
+            } else {
+                nsp += run;
+            }
+            spilled = spilled || base + run > lcap;
+#pragma unroll
+            for (int b = 0; b < N; ++b) {
+                if (off[b] >= 0) {
+                    const int pos = base + off[b];
+                    if (pos < lcap) s_ids[pos] = t[b];
+                    else spill_rows[pos - lcap] = t[b];                      // (rare: K = 1-like data, the chunk pool)
                 }
-                cur += __popcll(bal);
             }
         }
     };
-    auto lean_apply1 = [&](int32_t t, int cap_now) {                         // a batch of one (the rare sweeps)
+    auto lean_apply1 = [&](int32_t t, bool alone) {                          // a batch of one (the rare sweeps)
         int32_t tt[1] = {t};
         uint32_t uu[1], oo[1];
         lean_first(t, uu[0], oo[0]);
-        lean_rest(tt, uu, oo, cap_now);
+        lean_rest(tt, uu, oo, alone);
     };
     auto code_of = [&](int l) {   // HASH 1: bit i of code l <- plane l*K + i
         if (HASH == 2) return (int)ha.codes_out[h * L + l];
@@ -1353,7 +1378,7 @@ __device__ __forceinline__ void lsh_head_body(
                     if (l < L && sl >= 2 && sl - 2 < pl) apply(v[b]);   // the slot's own ids
                 }
             }
-            if constexpr (LEAN) lean_rest(v, lu, lo, pcap);             // stage 2 for the DG slots together
+            if constexpr (LEAN) lean_rest(v, lu, lo, false);             // stage 2 for the DG slots together
             if (more) {                                                 // wave-uniform; one wait for all follow-ups
                 if constexpr (LEAN) {
                     // e0 of every b as ONE batch (lanes without a follow-up id idle), then -- rare -- e1 and e2 as another
@@ -1362,20 +1387,20 @@ __device__ __forceinline__ void lsh_head_body(
                         e0[b] = ((more >> b) & 1u) && sl < r1s[b] ? e0[b] : -1;
                         lean_first(e0[b], lu[b], lo[b]);
                     }
-                    lean_rest(e0, lu, lo, pcap);
+                    lean_rest(e0, lu, lo, false);
                     if (wide) {                                         // uniform
 #pragma unroll
                         for (int b = 0; b < DG; ++b) {
                             e1[b] = ((wide >> b) & 1u) && sl + SW < r1s[b] ? e1[b] : -1;
                             lean_first(e1[b], lu[b], lo[b]);
                         }
-                        lean_rest(e1, lu, lo, pcap);
+                        lean_rest(e1, lu, lo, false);
 #pragma unroll
                         for (int b = 0; b < DG; ++b) {
                             e2[b] = ((wide >> b) & 1u) && sl + 2 * SW < r1s[b] ? e2[b] : -1;
                             lean_first(e2[b], lu[b], lo[b]);
                         }
-                        lean_rest(e2, lu, lo, pcap);
+                        lean_rest(e2, lu, lo, false);
                     }
                 } else {
 #pragma unroll
@@ -1512,18 +1537,18 @@ __device__ __forceinline__ void lsh_head_body(
                     if (!(lane < ln[b])) id0[b] = -1;
                     lean_first(id0[b], lu[b], lo[b]);
                 }
-                lean_rest(id0, lu, lo, pcap);
+                lean_rest(id0, lu, lo, false);
                 if (longer) {                                                // wave-uniform (the loads are out already)
 #pragma unroll
                     for (int b = 0; b < RT_GROUP; ++b) {
                         if (!(lane + 64 < ln[b])) id1[b] = -1;
                         lean_first(id1[b], lu[b], lo[b]);
                     }
-                    lean_rest(id1, lu, lo, pcap);
+                    lean_rest(id1, lu, lo, false);
                 }
                 if (tails_now) {
 #pragma unroll
-                    for (int u = 0; u < RT_TAIL_UNROLL; ++u) lean_apply1((tin >> u) & 1u ? idt[u] : -1, pcap);
+                    for (int u = 0; u < RT_TAIL_UNROLL; ++u) lean_apply1((tin >> u) & 1u ? idt[u] : -1, false);
                 }
             } else {
 #pragma unroll
@@ -1562,7 +1587,7 @@ __device__ __forceinline__ void lsh_head_body(
         // applied in issue order: the first piece's ids are counted while the last piece's are still on their way
 #pragma unroll
         for (int b = 0; b < RT_GROUP; ++b) {
-            if constexpr (LEAN) lean_apply1(lane < ln[b] ? id0[b] : -1, pcap);   // (tables beyond 4 GB per KV group: not a tuned path)
+            if constexpr (LEAN) lean_apply1(lane < ln[b] ? id0[b] : -1, false);   // (tables beyond 4 GB per KV group: not a tuned path)
             else apply(lane < ln[b] ? id0[b] : -1);
         }
         bool longer = false;
@@ -1578,37 +1603,110 @@ __device__ __forceinline__ void lsh_head_body(
             }
 #pragma unroll
             for (int b = 0; b < RT_GROUP; ++b) {
-                if constexpr (LEAN) lean_apply1(lane + 64 < ln[b] ? id1[b] : -1, pcap);
+                if constexpr (LEAN) lean_apply1(lane + 64 < ln[b] ? id1[b] : -1, false);
                 else apply(lane + 64 < ln[b] ? id1[b] : -1);
             }
         }
     }
     }
     }
-    // ---- LEAN: this wave's own finds are complete (its slots / pieces are counted: a token is appended by the lane that
-    // sees its second hit, and no later hit changes that) -- gather and fold them NOW, while other waves still count; then
-    // the window's share, then the wave's state goes to LDS behind a ticket.  No workgroup barrier from here on: the wave
-    // that draws the LAST ticket does what is left alone -- normally nothing but the merge; with skewed keys the chunk
-    // pool (pieces beyond slot + follow-up, the sub-bounds path's ids beyond 128) and the spill list.
+    // ---- LEAN: this wave is done counting -- it has nothing more to add to the list.  It now CLAIMS slices of the list
+    // (16 entries where a head is split over a cluster, 32 otherwise) and gathers them, while other waves still count, until
+    // every wave is done and the list is used up; then the window's share, then its state goes to LDS behind a ticket.  No
+    // workgroup barrier from here on: the wave that draws the LAST ticket does what is left alone -- normally nothing but
+    // the merge; with skewed keys the chunk pool (pieces beyond slot + follow-up, the sub-bounds path's ids beyond 128) and
+    // the spill list.
     constexpr int ADL = AD > 0 ? AD : 64;
     AhState st_own = ah_state_init(lane, ADL / 8);
-    int cur_pub = 0, pre_total = 0;
+    int pre_total = 0;
+    u32x4 qv_own = {0u, 0u, 0u, 0u};            // LEAN: this lane's eight query elements (read once, used again by the last wave)
     bool rare = true;                           // LEAN, uniform: the last wave has pooled chunks / a spill list to see to
     float m = 0.f, Z = 0.f, o0 = 0.f, o1 = 0.f;
     if constexpr (LEAN) {
         MP_STAMP(stamp, 33);
-        const int n_own = cur < pcap ? cur : pcap;                       // (the rest went to the spill list)
+        if (lane == 0) (void)__hip_atomic_fetch_add(s_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const u32x4 qv_l = *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADL / 8)) * 4);
-        auto own = [&](int j) { return *reinterpret_cast<const u32x4*>(mylist + j); };
+        qv_own = qv_l;
         const uint16_t* kv_l = aa.kv + g * M * 2 * ADL;
         const float* kn_l = aa.kn + g * M;
         constexpr int SHORT_L = (ADL == 128) ? 16 : AH_SLICE;
-        if (SHORT_L < AH_SLICE && n_own <= SHORT_L)                      // uniform per wave
-            attn_head_fold_lean<ADL, SHORT_L>(st_own, kv_l, kn_l, qv_l, s_rn[1], n_own, M, ha.K, L, 0, 1, own, idmask,
-                                              idbits, pay, stamp);
-        else
-            attn_head_fold_lean<ADL, AH_SLICE>(st_own, kv_l, kn_l, qv_l, s_rn[1], n_own, M, ha.K, L, 0, 1, own, idmask,
-                                               idbits, pay, stamp);
+        const int CL = (SHORT_L < AH_SLICE && clog > 0) ? SHORT_L : AH_SLICE;      // uniform: entries per claim
+        int folded = 0;
+        for (;;) {
+            int start = 0, nh = 0;
+#if MP_LEAN_GREEDY
+            // take what is there: a full slice, or -- rather than wait for one -- at least MP_LEAN_MIN entries, or whatever
+            // is left once nobody counts any more (then `res` is final: a wave's last reservation precedes its "done").
+            // The claim is a compare-and-swap on the list's head: several idle waves look at the same entries.
+            bool over = false;
+            for (;;) {
+                const int done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                int res = __hip_atomic_load(s_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int head = __builtin_amdgcn_readfirstlane(__hip_atomic_load(s_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                res = __builtin_amdgcn_readfirstlane(res);
+                const bool fin = __builtin_amdgcn_readfirstlane(done) >= RT_WAVES;
+                const int avail = (res < lcap ? res : lcap) - head;
+                if (avail >= MP_LEAN_MIN || (fin && avail > 0)) {
+                    const int n = avail < CL ? avail : CL;
+                    int seen = head;
+                    if (lane == 0) {
+                        int expect = head;
+                        (void)__hip_atomic_compare_exchange_strong(s_head, &expect, head + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                        seen = expect;
+                    }
+                    if (__builtin_amdgcn_readfirstlane(seen) == head) {
+                        start = head;
+                        nh = n;
+                        break;
+                    }
+                    continue;                                            // another wave took them: look again
+                }
+                if (fin) {                                               // nothing left, nothing to come
+                    over = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (over) break;
+#else
+            if (lane == 0) start = __hip_atomic_fetch_add(s_head, CL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            start = __builtin_amdgcn_readfirstlane(start);
+            if (start >= lcap) break;                                    // (beyond the stage: the spill list, below)
+            // until the slice is reserved in full, or nobody counts any more (then `res` is final: a wave's last
+            // reservation precedes its "done")
+            int res;
+            for (;;) {
+                const int done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                res = __hip_atomic_load(s_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (res >= start + CL || done >= RT_WAVES) break;
+                // a poll is an instruction the counting waves of this SIMD do not issue: far from its turn a wave sleeps longer
+                if (start + CL - res > 2 * CL) __builtin_amdgcn_s_sleep(8);
+                else __builtin_amdgcn_s_sleep(1);
+            }
+            res = __builtin_amdgcn_readfirstlane(res);
+            nh = (res < lcap ? res : lcap) - start;
+            if (nh <= 0) break;
+            nh = nh < CL ? nh : CL;
+#endif
+            // reserved is not written: the reserving wave stores its entries right behind its atomic
+            for (;;) {
+                const int32_t w = lane < nh ? __hip_atomic_load(s_ids + start + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+                if (__ballot(w == -1) == 0ull) break;
+            }
+            // (a greedy claim starts anywhere: four 4-byte reads, not one that needs 16-byte alignment)
+            auto slice = [&](int j) {
+                const int32_t* e = s_ids + start + j;
+                return u32x4{(uint32_t)e[0], (uint32_t)e[1], (uint32_t)e[2], (uint32_t)e[3]};
+            };
+            if (SHORT_L < AH_SLICE && clog > 0)
+                attn_head_fold_lean<ADL, SHORT_L>(st_own, kv_l, kn_l, qv_l, s_rn[1], nh, M, ha.K, L, 0, 1, slice, idmask,
+                                                  idbits, pay, stamp);
+            else
+                attn_head_fold_lean<ADL, AH_SLICE>(st_own, kv_l, kn_l, qv_l, s_rn[1], nh, M, ha.K, L, 0, 1, slice, idmask,
+                                                   idbits, pay, stamp);
+            folded += nh;
+        }
         if (WIN && aa.win_kv != nullptr) {      // the static window: dense slices rank, rank + R, ... over the waves
             int wl = aa.win_len[h];
             wl = wl < 0 ? 0 : (wl > aa.win_M ? (int)aa.win_M : wl);
@@ -1618,13 +1716,13 @@ __device__ __forceinline__ void lsh_head_body(
                                                               wl, aa.win_M, 0, 0, rank, 1 << clog, none, nullptr, stamp);
         }
 #if MP_STAMPS
-        // per-wave: own fold done (slots 48 + wave; bits 0..9 of the 100 MHz stamp replaced by the wave's list length)
+        // per-wave: gathers done (slots 48 + wave; bits 0..9 of the 100 MHz stamp replaced by the entries the wave folded)
         if (stamp != nullptr && lane == 0)
-            ::mp::s_stampbuf[48 + wave] = (wall_clock64() << 10) | (unsigned long long)(cur < 1023 ? cur : 1023);
+            ::mp::s_stampbuf[48 + wave] = (wall_clock64() << 10) | (unsigned long long)(folded < 1023 ? folded : 1023);
 #endif
+        (void)folded;
         attn_head_publish<ADL>(st_own, s_merge);
-        if (lane == 0 && cur > 0) atomicAdd(s_nsel, cur);
-        if (cur > pcap) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's spill stores are acknowledged
+        if (spilled) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's spill stores are acknowledged
         int tk = 0;
         if (lane == 0) tk = __hip_atomic_fetch_add(s_tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         tk = __builtin_amdgcn_readfirstlane(tk);
@@ -1633,13 +1731,14 @@ __device__ __forceinline__ void lsh_head_body(
             return;
         }
         MP_STAMP_L(stamp, 40);                                           // every wave's state is in LDS
-        // ONE round of LDS reads for all the last wave normally needs: the sixteen states, the count, and the three words
-        // that say whether anything is left to do (as dependent reads further down they were four round trips)
-        const int v30 = s_tmp[30], vnt = *s_ntail, vsp = *s_nspill;
-        pre_total = *s_nsel;
+        // ONE round of LDS reads for all the last wave normally needs: the sixteen states, the count, and the words that
+        // say whether anything is left to do
+        const int v30 = s_tmp[30], vnt = *s_ntail;
+        pre_total = *s_res;
         attn_head_merge_read<ADL, RT_WAVES>(s_merge, m, Z, o0, o1);
-        rare = (direct_path && v30 > 0) || vnt > 0 || vsp > 0;
-        cur_pub = cur;
+        rare = (direct_path && v30 > 0) || vnt > 0 || pre_total > lcap;
+        spilled = false;
+        nsp = pre_total > lcap ? pre_total - lcap : 0;                   // the spill list so far: what did not fit the stage
         if (rare && direct_path) direct_pool_build();
     }
     // (LEAN: what follows is run by one wave)
@@ -1667,7 +1766,7 @@ __device__ __forceinline__ void lsh_head_body(
                 uint32_t lu[RT_TAIL_UNROLL], lo[RT_TAIL_UNROLL];
 #pragma unroll
                 for (int u = 0; u < RT_TAIL_UNROLL; ++u) lean_first(idt[u], lu[u], lo[u]);
-                lean_rest(idt, lu, lo, 0);                    // (the pool runs behind the waves' own gathers: spill list)
+                lean_rest(idt, lu, lo, true);                 // (the pool is the last wave's: spill list)
             } else {
 #pragma unroll
             for (int u = 0; u < RT_TAIL_UNROLL; ++u) apply(idt[u]);
@@ -1682,16 +1781,13 @@ __device__ __forceinline__ void lsh_head_body(
             for (int j0 = first; j0 < len; j0 += PT) {                       // (uniform trip count: the LEAN form ballots)
                 const int j = j0 + ptid;
                 const int32_t t = j < len ? row[j] : -1;
-                if constexpr (LEAN) lean_apply1(t, 0);
+                if constexpr (LEAN) lean_apply1(t, true);
                 else apply(t);
             }
         }
     }
     if constexpr (LEAN) {
-        if (cur > cur_pub) {                                            // uniform: the pool's finds (spill list)
-            if (lane == 0) atomicAdd(s_nsel, cur - cur_pub);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (spilled) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the pool's finds: this wave's own stores)
     } else {
     // (direct pass without pooled chunks: nothing was counted since the barrier behind the pass)
     if (!(direct_path && ntail == 0)) MP_CHAIN_BARRIER();
@@ -1706,13 +1802,13 @@ __device__ __forceinline__ void lsh_head_body(
     const int nsw = words;
     const int wpt = (nsw + RT_THREADS - 1) / RT_THREADS;
     const int w0 = tid * wpt;
-    // LEAN: there is no list to emit -- the waves have folded their own finds; the workgroup's count is in *s_nsel
+    // LEAN: there is no list to emit -- the waves have gathered it slice by slice; the count is what was reserved
     int total = 0, off = 0;
     constexpr bool ordered = !LEAN;
     int nspill = 0;                                                  // uniform
     if constexpr (LEAN) {
-        total = rare ? *s_nsel : pre_total;
-        nspill = rare ? *s_nspill : 0;
+        total = pre_total + nsp - (pre_total > lcap ? pre_total - lcap : 0);    // + the pool's finds
+        nspill = nsp;
     }
     if (ordered) {
         for (int k = 0; k < wpt; ++k)
@@ -1791,7 +1887,7 @@ __device__ __forceinline__ void lsh_head_body(
     }
     MP_STAMP(stamp, 33);
     // two instantiations of the sparse fold: the LDS path carries no global load ahead of its gathers
-    const u32x4 qv = *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADD / 8)) * 4);
+    const u32x4 qv = LEAN ? qv_own : *reinterpret_cast<const u32x4*>(s_qraw + (lane % (ADD / 8)) * 4);
     float* score_h = (!LEAN && aa.score) ? aa.score + h * M + t0 : nullptr;
     const uint16_t* kv_g = aa.kv + g * M * 2 * ADD;
     const float* kn_g = aa.kn + g * M;
@@ -2472,8 +2568,11 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                           lds + (size_t)range_len * 2 + 16 <= RT_LDS_DYN_MAX;
     // the LEAN form keeps a counter per token where the other keeps two bits: only where that fits next to everything
     // else (the payload's norms first: they are worth more than the lean form)
+    // Where a head has ONE workgroup (clog == 0: B*H >= CUs / 2, cfg 2 / 3) the lean form is not used: there the gather is
+    // bound by HBM, and row requests that start while other workgroups still count delay THEIR table loads -- measured
+    // +0.7 ... +1.3 us per launch at cfg 2 / 3 (EXPERIMENTS.md R6-1); the flag then only has no effect.
     if (lean) {      // (a selected token's norm travels in its list entry there: no norm array)
-        if (decode_lds_bytes(range_len, L, D, true) <= RT_LDS_DYN_MAX && !codes_given) lds = decode_lds_bytes(range_len, L, D, true);
+        if (clog > 0 && decode_lds_bytes(range_len, L, D, true) <= RT_LDS_DYN_MAX && !codes_given) lds = decode_lds_bytes(range_len, L, D, true);
         else lean = false;
     }
     if (want_pay) {

@@ -46,10 +46,11 @@ def test_lean_decode_vs_reference_and_oracle(mp, name):
     out, lse = server.decode(q, 1)
     torch.cuda.synchronize()
     assert np.array_equal(server.nnz.cpu().numpy(), g["nnz"])                     # integer work: bit-exact
-    with pytest.raises(L_.MagicPigError):
-        server.attn_server.get_score()
-    with pytest.raises(L_.MagicPigError):
-        server.lsh_retriever.get_mask()
+    if server.lsh_retriever.R > 1:      # (one workgroup per head: the flag has no effect, the by-products are there)
+        with pytest.raises(L_.MagicPigError):
+            server.attn_server.get_score()
+        with pytest.raises(L_.MagicPigError):
+            server.lsh_retriever.get_mask()
     ref_lists = cases.split_ragged(g["results_ref_order"], g["nnz"])
     ind = np.zeros((B * H, M), np.int32)
     for h, lst in enumerate(ref_lists):
