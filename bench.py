@@ -147,9 +147,14 @@ def parse():
                     help="batch: every rank serves its own B requests (weak scaling); head: the kv heads of the "
                          "whole model are partitioned over the ranks like the reference's TP variant (strong scaling).  "
                          "Default: head for cfg4 on more than one GPU (the configuration IS the TP = 8 layout), batch otherwise")
-    ap.add_argument("--legs", default="cfg2,cfg4",
+    ap.add_argument("--legs", default="cfg2,cfg3,cfg4",
                     help="extra configurations measured after the headline in the default single-GPU cfg1 run and reported "
-                         "under `legs` (cfg4 = its per-GPU share, as --config cfg4 on one GPU); '' or --no-legs: none")
+                         "under `legs` (cfg3 / cfg4 = their per-GPU shares, as --config cfg3 / cfg4 on one GPU; `e2e` = the "
+                         "end-to-end decode step with its split, see --no-e2e-leg); '' or --no-legs: none")
+    ap.add_argument("--no-e2e-leg", action="store_true",
+                    help="skip legs.e2e: the whole decode step (examples/bench.py:43-59) with random Llama-3.1-8B weights at "
+                         "cfg 1 (B = 1) and cfg 2 (B = 8), each with its split by kind of work")
+    ap.add_argument("--e2e-steps", type=int, default=24, help="timed steps of an e2e leg (+ 4 warm-up)")
     ap.add_argument("--no-legs", action="store_true")
     ap.add_argument("--leg-cpu-steps", type=int, default=1024,
                     help="decode steps of one sparse layer the CPU path is timed on in a leg (one thread placement)")
@@ -728,7 +733,8 @@ def config_leg(mp, sharding, args, name, dev):
     dt = time.perf_counter() - t0
     roof = w.roofline()
     w.server.attn_server.check()
-    leg = {"workload": f"{name}{' (per-GPU share of TP=8)' if name == 'cfg4' else ''}: {cfg['model']} B={w.B} P={w.P} "
+    share = {"cfg4": " (per-GPU share of TP=8)", "cfg3": " (per-GPU share: B = 8 of 64)"}.get(name, "")
+    leg = {"workload": f"{name}{share}: {cfg['model']} B={w.B} P={w.P} "
                        f"K={w.K} L={w.Lt}, {w.NL} sparse layers/step, H={w.H} Hkv={w.Hkv} D={w.D}",
            "tokens_per_s": w.B * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
            "us_per_layer": dt / args.steps * 1e6 / w.NL, "steps": args.steps, "warmup": args.warmup,
@@ -741,6 +747,38 @@ def config_leg(mp, sharding, args, name, dev):
         leg["cpu_baseline"] = w.cpu_check(args.leg_cpu_steps, ("cores",))
         leg["speedup_vs_cpu"] = leg["tokens_per_s"] / leg["cpu_baseline"]["value"]
     w.release()
+    return leg
+
+
+def e2e_leg(args, name, dev):
+    """legs.e2e: the WHOLE decode step of examples/bench.py:43-59 -- embedding, 32 layers of projections +
+    RoPE + attention (30 LSH-sparse layers through the hot path with the static window folded in, 2 dense layers) + MLP,
+    lm_head -- on random Llama-3.1-8B weights at one BASELINE configuration, captured in a hipGraph; tokens/s of the step
+    and its split by kind of work (each kind re-captured as a graph of its own over all layers, HIP events around
+    back-to-back replays: decode_harness.split_decode_step).  The model GEMMs are torch-ROCm plumbing outside the
+    north-star path: context for what "decode tokens/sec" means end to end, not the headline."""
+    from magicpig_amd import decode_harness as dh
+
+    cfg = CONFIGS[name]
+    steps, warmup = args.e2e_steps, 4
+    t_s = time.time()
+    dec = dh.SyntheticLlamaDecoder(dh.LLAMA_3_1_8B, K=cfg["K"], L=cfg["L"], batch_size=cfg["B"], max_length=cfg["M"],
+                                   generation_buffer=max(64, steps + warmup + 16), dense_layers=cfg["dense"], device=str(dev), seed=0)
+    dec.attention_server.by_products = bool(args.by_products)
+    ms, tps = dh.run_decode_benchmark(dec, cfg["P"], warmup=warmup, steps=steps, use_graph=not args.no_graph)
+    split = dh.split_decode_step(dec)
+    parts = sum(split.values())
+    leg = {"workload": f"{name} end to end: Llama-3.1-8B (random weights) B={cfg['B']} P={cfg['P']} K={cfg['K']} L={cfg['L']}, "
+                       f"{len(dec.sparse_layers)} LSH-sparse + {len(dec.dense_layers)} dense layers, projections / MLP / lm_head in torch-ROCm",
+           "tokens_per_s": tps, "ms_per_step": ms, "steps": steps, "warmup": warmup,
+           "launch": "eager" if args.no_graph else "hipGraph",
+           "split_ms": {k: round(v, 4) for k, v in split.items()}, "split_sum_ms": round(parts, 4),
+           "split_note": "each kind of work re-captured as its own hipGraph over all layers on static inputs, HIP events around "
+                         "8 replays; sparse_attention = append + q-hash + retrieve + sampled attention + static window (one "
+                         "launch + the append per sparse layer)",
+           "hot_path_share_of_step": round(split["sparse_attention"] / ms, 4), "leg_wall_s": round(time.time() - t_s, 1)}
+    del dec
+    torch.cuda.empty_cache()
     return leg
 
 
@@ -997,11 +1035,17 @@ def main():
         out["host_mode_pinned_results"] = attempt("host_mode_pinned_results",
                                                   lambda: host_mode_leg(server, cfg, qs, H, pin_results=True),
                                                   lambda msg: {"us_per_layer": None, "what": msg})
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # (rank 0 of an N-rank run times it too -- on ITS share of the units: the line of a multi-GPU run is self-contained;
+    # the other ranks wait at the barrier below)
+    if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = attempt("cpu_baseline", lambda: w.cpu_check(args.cpu_steps, (None, "cores")),
                                       lambda msg: {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": msg})
         if out["cpu_baseline"].get("value"):
-            out["speedup_vs_cpu"] = tokens_per_s / out["cpu_baseline"]["value"]
+            if world > 1:      # the CPU figure is one rank's share on one host: compare it with that rank's share of the GPU rate
+                out["cpu_baseline"]["sample"] = "rank 0's units only; " + out["cpu_baseline"]["sample"]
+                out["speedup_vs_cpu"] = (tokens_per_s / world if shard is None else tokens_per_s) / out["cpu_baseline"]["value"]
+            else:
+                out["speedup_vs_cpu"] = tokens_per_s / out["cpu_baseline"]["value"]
             if out.get("host_mode", {}).get("us_per_layer"):      # the unchanged caller against the CPU path, same layer
                 t_cpu = out["cpu_baseline"]["t_retrieve_us"] + out["cpu_baseline"]["t_attention_us"]
                 out["host_mode"]["speedup_vs_cpu_layer"] = t_cpu / out["host_mode"]["us_per_layer"]
@@ -1042,15 +1086,21 @@ def main():
             if name not in CONFIGS or name == args.config:
                 continue
             t_leg = time.time()
-            key = name + "_share" if name == "cfg4" else name
+            key = name + "_share" if name in ("cfg3", "cfg4") else name
             out["legs"][key] = attempt("leg " + name, lambda: config_leg(mp, sharding, args, name, dev),
                                        lambda msg: {"tokens_per_s": None, "failed": msg})
             out["legs"][key]["leg_wall_s"] = round(time.time() - t_leg, 1)
+    if solo and shard is None and args.config == "cfg1" and args.data == "randn" and legs and not args.no_e2e_leg:
+        out["legs"]["e2e"] = {}
+        for name in ("cfg1", "cfg2"):
+            out["legs"]["e2e"][name] = attempt("leg e2e " + name, lambda: e2e_leg(args, name, dev),
+                                               lambda msg: {"tokens_per_s": None, "failed": msg})
     if failures:
         out["failed_legs"] = failures
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()              # (the other ranks wait here while rank 0 times the CPU path)
         dist.destroy_process_group()
     if failures and not args.allow_missing_legs:
         sys.exit("bench.py: " + "; ".join(failures))

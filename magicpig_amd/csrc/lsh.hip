@@ -1630,7 +1630,10 @@ __device__ __forceinline__ void lsh_head_body(
         const uint16_t* kv_l = aa.kv + g * M * 2 * ADL;
         const float* kn_l = aa.kn + g * M;
         constexpr int SHORT_L = (ADL == 128) ? 16 : AH_SLICE;
-        const int CL = (SHORT_L < AH_SLICE && clog > 0) ? SHORT_L : AH_SLICE;      // uniform: entries per claim
+#ifndef MP_LEAN_CL
+#define MP_LEAN_CL SHORT_L                 // A/B: entries per claim where a head is a cluster (12: a claim = what a wave adds on average)
+#endif
+        const int CL = (SHORT_L < AH_SLICE && clog > 0) ? MP_LEAN_CL : AH_SLICE;    // uniform: entries per claim
         int folded = 0;
         for (;;) {
             int start = 0, nh = 0;

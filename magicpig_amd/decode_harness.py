@@ -313,3 +313,73 @@ def run_decode_benchmark(decoder: SyntheticLlamaDecoder, prompt_len: int, warmup
     if decoder.dense_layers:
         decoder.dense_server.check()
     return dt / steps * 1e3, B * steps / dt
+
+
+def split_decode_step(decoder: SyntheticLlamaDecoder, reps: int = 8) -> dict:
+    """Where a decode step's time goes (bench.py's `e2e` leg): the step's launches re-captured as five hipGraphs, one per
+    kind of work over ALL layers -- (1) the sparse layers' attention (append + q-hash + retrieve + sampled attention +
+    static window: the north-star path plus rows f-2), (2) the dense layers' attention, (3) the q / k / v / o and MLP
+    projections, (4) RMSNorm + RoPE + residual adds, (5) embedding + final norm + lm_head -- each timed by HIP events
+    around back-to-back replays.  The parts run on static inputs of the step's shapes; their sum is compared with the whole
+    captured step by the caller.  Call after run_decode_benchmark (the stores are filled, lazy initialisation is done)."""
+    d = decoder
+    B, H, Hkv, D = d.batch_size, d.shape.num_attention_heads, d.shape.num_key_value_heads, d._head_dim
+    hs, dev, dt = d.full_shape.hidden_size, d.device, d.dtype
+    g = torch.Generator(device=dev).manual_seed(321)
+    rnd = lambda *dims: torch.randn(dims, device=dev, generator=g).to(dt)          # noqa: E731
+    x, q, k, v = rnd(B, 1, hs), rnd(B, H, 1, D), rnd(B, Hkv, 1, D), rnd(B, Hkv, 1, D)
+    attn = rnd(B, 1, H * D)
+    pos = torch.full((B, 1), d.max_length - 2, device=dev, dtype=torch.long)
+    ids = torch.zeros((B, 1), device=dev, dtype=torch.long)
+    eps = d.shape.rms_norm_eps
+
+    def sparse_attn():
+        for layer in d.sparse_layers:
+            d.attention_server.decode_full_fused(q, k, v, d.sparse_index[layer])
+
+    def dense_attn():
+        for layer in d.dense_layers:
+            d._dense_attention(q, k, v, layer)
+
+    def projections():
+        for W in d.layers:
+            F.linear(x, W["wq"]); F.linear(x, W["wk"]); F.linear(x, W["wv"]); F.linear(attn, W["wo"])
+            F.linear(F.silu(F.linear(x, W["gate"])) * F.linear(x, W["up"]), W["down"])
+
+    def norms_rope():
+        for W in d.layers:
+            y = rms_norm(x, W["ln1"], eps)
+            apply_rotary_pos_emb(k, d.cos_cache, d.sin_cache, pos)
+            apply_rotary_pos_emb(q, d.cos_cache, d.sin_cache, pos)
+            h = x + y
+            h + rms_norm(h, W["ln2"], eps)
+
+    def head():
+        hdn = F.embedding(ids, d.embed_tokens)
+        F.linear(rms_norm(hdn, d.norm_weight, eps), d.lm_head).float()
+
+    out = {}
+    with torch.inference_mode():
+        for name, fn in (("sparse_attention", sparse_attn), ("dense_attention", dense_attn), ("projections_mlp", projections),
+                         ("norms_rope_residual", norms_rope), ("embed_lm_head", head)):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fn()
+            graph.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            out[name] = e0.elapsed_time(e1) / reps
+            del graph
+    d.attention_server.window_server.check()
+    return out
