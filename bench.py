@@ -181,6 +181,10 @@ def parse():
                     help="0 (default): the timed decode is mp_decode_sparse_layer_ex with MP_DECODE_NO_BYPRODUCTS -- output, LSE "
                          "and counts only, what a serving loop reads; 1: mp_decode_sparse_layer as in rounds 1-5 (query codes, "
                          "result rows and logits written for get_mask / get_score).  The line says which form it timed")
+    ap.add_argument("--accel-budget", type=float, default=None,
+                    help="GB of HBM the LSH handle may spend on accelerator structures over all layers (direct piece slots, the "
+                         "host-buffer mode's row copy): mp_lsh_alloc_ex.  Default: the library's rule (a third of what is free)")
+    ap.add_argument("--ranges", type=int, default=0, help="token ranges per table row = workgroups per head (mp_lsh_alloc_ex; 0 = auto)")
     ap.add_argument("--two-launch", action="store_true",
                     help="A/B: the decode entry as (hash + retrieve) then attention instead of one launch")
     ap.add_argument("--end-to-end", action="store_true",
@@ -552,7 +556,9 @@ class Workload:
         B, H, Hkv, D, P, NL, n, G = self.B, self.H, self.Hkv, self.D, self.P, self.NL, self.n, self.G
         srv = mp.LSHSparseAttnServer(NL, H, Hkv, D, K=self.K, L=self.Lt, batch_size=B, max_length=self.M,
                                      dense_layers=(), device=str(dev), hash_func=self.hash_func,
-                                     table_build=self.args.table_build)
+                                     table_build=self.args.table_build,
+                                     accel_budget_bytes=None if self.args.accel_budget is None else int(self.args.accel_budget * 1e9),
+                                     ranges=self.args.ranges)
         t_s = time.time()
         for li in range(NL):
             for b in range(B):

@@ -95,6 +95,20 @@ int mp_lsh_destroy(mp_lsh_t* h);                      /* LSH::~LSH()           l
 /* LSH::alloc, lsh.cc:44-91 (same argument order). */
 int mp_lsh_alloc(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_heads,
                  int num_key_value_heads, int batch_size, int max_length);
+/* LSH::alloc with the two decisions mp_lsh_alloc takes by itself stated by the caller (the reference's alloc takes exactly
+ * what its arguments say, lsh.cc:44-91; mp_lsh_alloc = mp_lsh_alloc_ex(..., -1, 0)):
+ *   accel_budget_bytes  HBM this handle may spend, over ALL its layers, on structures that only make the decode faster: the
+ *                       direct piece slots (1.26 GB per layer at cfg 1 for -1.4 us per launch) and the HBM copy of
+ *                       the rows a MP_MEM_HOST batch_retrieve hands out (4 B x B*H x max_length).  0 = none of them; < 0 =
+ *                       mp_lsh_alloc's rule: each is taken where it pays and needs less than a third of the HBM that is FREE
+ *                       when it is allocated -- which makes layout and speed depend on what else the process has allocated
+ *                       by then; a serving process that loads its weights later should state a figure.  The tables and
+ *                       bounds are not accelerators and are always allocated.
+ *   ranges              token ranges per table row = workgroups per query head of the one-launch decode: 0 = by B*H, the
+ *                       CU count and the tokens per range (mp_lsh_alloc), else 1, 2, 4, 8, 16 or 32.
+ * The process-wide debug options "decode_cluster" / "decode_direct" / "decode_slot_log2" still override both (A/B runs). */
+int mp_lsh_alloc_ex(mp_lsh_t* h, int K, int L, int num_layers, int num_attention_heads,
+                    int num_key_value_heads, int batch_size, int max_length, int64_t accel_budget_bytes, int ranges);
 /* LSH::fill, lsh.cc:143-201.  sorted_codes int16 [Hkv, L, n], sorted_ids int32 [Hkv, L, n].
  * Unlike the reference the slot need not be cleared first (rows are re-zeroed on device). */
 int mp_lsh_fill(mp_lsh_t* h, int layer_id, int request_id, const int16_t* sorted_codes,
@@ -136,6 +150,11 @@ int mp_lsh_get_ranges(mp_lsh_t* h, int* ranges, int* range_len);
  * [3] bytes of one slot (128, 64, 32 or 0).  The reference's tables are [1] alone (lsh.cc:44-91: table + table_start /
  * table_end); bounds with R + 1 entries and the slots are this implementation's accelerators. */
 int mp_lsh_get_footprint(mp_lsh_t* h, int64_t* bytes4);
+/* The same plus what the host-buffer mode and the budget of mp_lsh_alloc_ex add, bytes8: [0..3] as above (PER LAYER);
+ * [4] HBM copy of the rows a MP_MEM_HOST batch_retrieve hands out (whole handle; 0 until the first such call, or when the
+ * budget refused it); [5] pinned host memory the handle holds for that mode; [6] the accelerator budget (< 0: "a third of
+ * what is free"); [7] accelerator bytes in use: all layers' slots + [4]. */
+int mp_lsh_get_footprint_ex(mp_lsh_t* h, int64_t* bytes8);
 /* Width of the id field of the layer's table words: 17 while every token id the layer's tables hold is below 2^17
  * (any max_length), 0 (plain ids) from the first mp_lsh_fill / mp_lsh_build that brings a wider one until mp_lsh_clear.
  * Where it is 17, a table word is  token id | (payload << 17): the one-launch decode entries let the entries carry
@@ -257,7 +276,7 @@ int mp_debug_xcd_round_robin(void);
  *                        (2 = also at R = 1, one workgroup per head: measured -0.5 us of 28.9 per layer at cfg 3 for
  *                        +1.26 GB per layer, not taken by default)
  *   "decode_slot_log2"   0 = slot width by the mean piece length (default), 3 / 4 / 5 = 32- / 64- / 128-byte slots forced;
- *                        process-wide, read at alloc, table build and launch: set it before the handles are allocated
+ *                        process-wide, read at ALLOC only (a handle keeps the width it was allocated with)
  *   "attn_head_kernel"   -1 = auto, 0 = split-KV kernel with the in-launch ticket merge, 1 = one workgroup per head
  *   "attn_gx"            0 = auto, n = split-KV workgroups per head
  *   "attn_dense_grouped" 1 = mp_attn_full reads K/V once per kv group (default), 0 = once per query head
@@ -270,6 +289,7 @@ int mp_debug_xcd_round_robin(void);
  *                        which the LDS serves the lanes of one atomic instruction (lane order on gfx950), every written bucket run
  *                        verified, the request rebuilt with the exact ranking if one does not ascend
  *   "build_rank_fallbacks"   COUNTER of such rebuilds (expected 0)
+ *   "build_rank_inject"  n > 0: the next n table builds behave as if that verification had failed (test hook for the rebuild)
  *   "host_fast_hits" / "host_fast_edited" / "host_fast_unpaired"   COUNTERS (get to read, set 0 to reset): MP_MEM_HOST
  *                        mp_attn_sparse calls that recognised the rows mp_lsh_batch_retrieve had just handed out (no index
  *                        upload) / found the pairing but a row edited (launch dropped, rows uploaded) / found no pairing

@@ -58,6 +58,8 @@ def lib() -> C.CDLL:
         "mp_lsh_create": ([pp], i32),
         "mp_lsh_destroy": ([p], i32),
         "mp_lsh_alloc": ([p, i32, i32, i32, i32, i32, i32, i32], i32),
+        "mp_lsh_alloc_ex": ([p, i32, i32, i32, i32, i32, i32, i32, i64, i32], i32),
+        "mp_lsh_get_footprint_ex": ([p, C.POINTER(i64)], i32),
         "mp_lsh_fill": ([p, i32, i32, p, p, i64, i32, p], i32),
         "mp_lsh_build": ([p, i32, i32, p, i64, i32, p], i32),
         "mp_lsh_build_with_norms": ([p, p, i32, i32, p, i64, i32, p], i32),

@@ -33,7 +33,7 @@ class LSHSparseAttnServer:
                  max_length: int = 8192,
                  dense_layers=(0, 16, 32, 48, 64), device: str = "cuda:0",
                  dtype=torch.bfloat16, hash_func: torch.Tensor | None = None, seed: int = 7,
-                 table_build: str = "counting"):
+                 table_build: str = "counting", accel_budget_bytes: int | None = None, ranges: int = 0):
         """Mirrors models/attnserver.py:9-57 (the LlamaConfig is replaced by its four numbers).
         hash_func: bf16 [head_dim, K*L]; the reference draws it unseeded (:55), here it is
         seeded or supplied (e.g. broadcast from rank 0, attnserver_dist.py:279)."""
@@ -61,7 +61,7 @@ class LSHSparseAttnServer:
                                    batch_size, max_length)
             self.lsh_retriever = LSH()
             self.lsh_retriever.alloc(K, L, num_layers, num_attention_heads, num_key_value_heads,
-                                     batch_size, max_length)
+                                     batch_size, max_length, accel_budget_bytes=accel_budget_bytes, ranges=ranges)
         BH = batch_size * num_attention_heads
         self.avg_k = [torch.zeros(batch_size, num_key_value_heads, 1, head_dim, device=self.device,
                                   dtype=dtype) for _ in range(num_layers)]

@@ -2256,19 +2256,21 @@ hipError_t launch_lsh_subbounds(const int32_t* table, int32_t* bounds, int rows,
 // of ~2.5x the mean (SimHash buckets are wider than Poisson: p99 of a probed piece at cfg 1 is 2.3x its mean)
 static int g_slot_log2 = 0;   // mp_debug_set_option("decode_slot_log2"): 3 / 4 / 5 forces 32- / 64- / 128-byte slots (A/B), 0 = by the mean piece
 void set_slot_log2(int v) { g_slot_log2 = (v >= 3 && v <= 5) ? v : 0; }
+int get_slot_log2() { return g_slot_log2; }
 int lsh_slot_log2(int64_t M, int NB, int R) {
     if (g_slot_log2) return g_slot_log2;
     const double mean = (double)M / ((double)NB * (double)R);
     return mean > 5.0 ? 5 : (mean > 2.5 ? 4 : 3);
 }
 
+// swl: log2 of the words per slot THE HANDLE was allocated with (the option behind lsh_slot_log2 is process-wide and may
+// have changed since: the buffer's size, the builder and the reader must agree -- ADVICE r05)
 hipError_t launch_lsh_slots(const int32_t* table, const int32_t* bounds, int32_t* slots, int rows, int NB, int R,
-                            int64_t M, hipStream_t st) {
+                            int64_t M, int swl, hipStream_t st) {
     if (slots == nullptr) return hipSuccess;          // (R = 1 with slots: the decode_direct = 2 experiment)
     int gx = (NB * R + 31) / 32;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(lsh_slots_kernel, dim3(gx, rows), dim3(256), 0, st, table, bounds, slots, NB, R, M,
-                       lsh_slot_log2(M, NB, R));
+    hipLaunchKernelGGL(lsh_slots_kernel, dim3(gx, rows), dim3(256), 0, st, table, bounds, slots, NB, R, M, swl);
     return hipGetLastError();
 }
 
@@ -2346,6 +2348,11 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     });
     if (attr_err != hipSuccess) return attr_err;
     if (n > INT32_MAX || NB > BUILD_LDS_COUNTERS) return hipErrorInvalidValue;
+    if (n <= 0) {         // an empty request: every bucket empty (all entries of a record 0), no table word; the kernels
+                          // prefetch codes[min(k, n - 1)] and must not be launched on nothing
+        if (subbounds_done) *subbounds_done = true;
+        return hipMemsetAsync(bounds, 0, (size_t)rows * NB * (R + 1) * sizeof(int32_t), st);
+    }
     int nbits = 0;
     while ((1 << nbits) < NB) ++nbits;
     int nw, tpl;
@@ -2540,7 +2547,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                              const uint16_t* Wk, const float* wnorm, int D, int K, int KLpad,
                              int32_t* codes_out, float* qnorm_out, int32_t* results, int32_t* nnz,
                              const uint16_t* kv, const float* kn, float* part_o, float2* part_ml, int* part_cnt,
-                             int* head_cnt, uint16_t* out, float* mve, float2* head_mz, const int32_t* slots,
+                             int* head_cnt, uint16_t* out, float* mve, float2* head_mz, const int32_t* slots, int slot_log2,
                              float* score, int* err, int maxs, int R, bool same_xcd, const uint16_t* win_kv,
                              const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
                              bool codes_given, unsigned long long* xw, unsigned int* xseq, int xwords, int xmode,
@@ -2561,7 +2568,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     // cluster share an XCD (sx) and every unit of 64 planes finds a wave (K*L <= 1024 R)
     const bool split_hash = xmode != 0 && sx && xw != nullptr && xseq != nullptr && !codes_given &&
                             ((K * L + 63) / 64) <= (RT_WAVES << clog) && 2 * ((K * L + 63) / 64) <= xwords;
-    AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, slots, lsh_slot_log2(M, NB, R), score, err, BH, BHp, maxs,
+    AttnArgs aa = {kv, kn, part_o, part_ml, part_cnt, head_cnt, out, mve, head_mz, slots, slot_log2, score, err, BH, BHp, maxs,
                    DECODE_ID_CAP, clog, sx ? 1 : 0, split_hash ? xw : nullptr, split_hash ? xseq : nullptr, xwords, xmode, nullptr, idbits_dev, nullptr, nullptr,
                    win_kv, win_len, win_M};
     const dim3 grid((unsigned)BHp << clog);

@@ -26,10 +26,18 @@ class LSH:
             pass
 
     def alloc(self, K: int, L_: int, num_layers: int, num_attention_heads: int,
-              num_key_value_heads: int, batch_size: int, max_length: int) -> None:
-        """LSH::alloc, lsh.cc:44-91."""
-        L.check(L.lib().mp_lsh_alloc(self._h, K, L_, num_layers, num_attention_heads,
-                                     num_key_value_heads, batch_size, max_length))
+              num_key_value_heads: int, batch_size: int, max_length: int, accel_budget_bytes: int | None = None,
+              ranges: int = 0) -> None:
+        """LSH::alloc, lsh.cc:44-91.  accel_budget_bytes / ranges (not in the reference; mp_lsh_alloc_ex): how much HBM the
+        handle may spend on structures that only make the decode faster (direct piece slots, the host-buffer mode's row
+        copy; None = the library's rule: a third of what is free at the time), and the token ranges per table row
+        (0 = auto)."""
+        if accel_budget_bytes is None and ranges == 0:
+            L.check(L.lib().mp_lsh_alloc(self._h, K, L_, num_layers, num_attention_heads,
+                                         num_key_value_heads, batch_size, max_length))
+        else:
+            L.check(L.lib().mp_lsh_alloc_ex(self._h, K, L_, num_layers, num_attention_heads, num_key_value_heads, batch_size,
+                                            max_length, -1 if accel_budget_bytes is None else int(accel_budget_bytes), ranges))
         self.K, self.L, self.num_layers = K, L_, num_layers
         self.H, self.Hkv, self.B, self.M = (num_attention_heads, num_key_value_heads, batch_size,
                                             max_length)
@@ -103,9 +111,11 @@ class LSH:
     def footprint(self) -> dict:
         """HBM bytes per layer of the index structures (mp_lsh_get_footprint): the reference's table (lsh.cc:44-91)
         plus this implementation's sub-bounds and direct piece slots."""
-        b = (C.c_int64 * 4)()
-        L.check(L.lib().mp_lsh_get_footprint(self._h, b))
-        return {"bounds": int(b[0]), "table": int(b[1]), "slots": int(b[2]), "slot_bytes": int(b[3])}
+        b = (C.c_int64 * 8)()
+        L.check(L.lib().mp_lsh_get_footprint_ex(self._h, b))
+        return {"bounds": int(b[0]), "table": int(b[1]), "slots": int(b[2]), "slot_bytes": int(b[3]),
+                "host_mode_row_copy": int(b[4]), "host_mode_pinned": int(b[5]), "accel_budget": int(b[6]),
+                "accel_in_use": int(b[7])}
 
     def get_tables(self, layer_id: int, raw: bool = False):
         b, t = C.c_void_p(), C.c_void_p()
