@@ -293,6 +293,15 @@ int mp_debug_xcd_round_robin(void);
  *   "host_fast_hits" / "host_fast_edited" / "host_fast_unpaired"   COUNTERS (get to read, set 0 to reset): MP_MEM_HOST
  *                        mp_attn_sparse calls that recognised the rows mp_lsh_batch_retrieve had just handed out (no index
  *                        upload) / found the pairing but a row edited (launch dropped, rows uploaded) / found no pairing
+ *   "host_speculate"     1 (default) = a MP_MEM_HOST mp_lsh_batch_retrieve enqueues the paired store's attention launch behind
+ *                        its own kernel once the store's last MP_MEM_HOST mp_attn_sparse call came with a pinned query tensor
+ *                        (the reference's caller reuses one, models/attnserver.py:61-66, and fills it before batch_retrieve,
+ *                        :273): the attention call then checks that it is the call that launch assumed -- same store, layer,
+ *                        K, L, dtype, the same query tensor holding the same bytes, ||q|| within 2e-6 of the launch's own,
+ *                        rows untouched -- and copies the outputs out: two library calls, one wait.  Anything else is
+ *                        served as without the option.  0 = never
+ *   "host_spec_hits" / "host_spec_misses"   COUNTERS: attention calls served by such a launch / launches whose assumptions the
+ *                        call did not meet
  *   "simhash_exact_norm" 1 = the fused query hash normalises the row by the exact f64 sequence always (A/B, tests);
  *                        0 (default) = a fast f32 form with the exact sequence as its fallback: identical codes
  *   "decode_cluster"     0 = auto, else workgroups per query head of the one-launch decode (1 .. 32); read by mp_lsh_alloc

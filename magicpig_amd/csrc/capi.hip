@@ -78,6 +78,7 @@ hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, 
 bool lsh_hash_only_supported(int L);
 hipError_t launch_attn_ticket_check(int*, int, int*, hipStream_t);
 hipError_t launch_relay(const void*, void*, size_t, hipStream_t);
+hipError_t launch_row_norm(const void*, bool, int, int, float*, float*, hipStream_t);
 hipError_t launch_host_flag(unsigned int*, unsigned int, hipStream_t);
 hipError_t launch_host_rows(const int32_t*, const int32_t*, int32_t*, int64_t, int, const void*, void*, size_t, int,
                             hipStream_t);
@@ -115,6 +116,10 @@ struct DebugOptions {
     std::atomic<int> host_fast_hits{0};      // the rows batch_retrieve had just handed out were recognised: no index upload
     std::atomic<int> host_fast_edited{0};    // pairing found, but a row differed from what was handed out: launch dropped, upload path
     std::atomic<int> host_fast_unpaired{0};  // no pairing (other buffers, other counts, another handle in between): upload path
+    std::atomic<int> host_speculate{1};      // MP_MEM_HOST batch_retrieve enqueues the paired store's attention launch behind its own
+                                             // kernel when the last attention call came with a pinned query tensor (see mp_lsh::Spec)
+    std::atomic<int> host_spec_hits{0};      // counter: attention calls served by the launch the retrieve had issued
+    std::atomic<int> host_spec_misses{0};    // counter: such a launch existed but the call's arguments were not what it had assumed
 };
 static DebugOptions g_opt;
 
@@ -138,6 +143,9 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "host_fast_hits")) return &g_opt.host_fast_hits;
     if (!strcmp(name, "host_fast_edited")) return &g_opt.host_fast_edited;
     if (!strcmp(name, "host_fast_unpaired")) return &g_opt.host_fast_unpaired;
+    if (!strcmp(name, "host_speculate")) return &g_opt.host_speculate;
+    if (!strcmp(name, "host_spec_hits")) return &g_opt.host_spec_hits;
+    if (!strcmp(name, "host_spec_misses")) return &g_opt.host_spec_misses;
     return nullptr;
 }
 
@@ -356,6 +364,23 @@ struct mp_lsh {
     // host-mode retrieve writes these, and it forgets the pairing first.
     int32_t* hr_rows = nullptr;    // [BH][M]
     int32_t* hr_nnz = nullptr;     // [BH]
+    // Speculation (round 6).  The reference's caller hands attention_wrapper the SAME pinned query / output / max_value_expsum
+    // tensors every step, and fills the query tensor BEFORE it calls batch_retrieve (models/attnserver.py:59-66, 273, 299-300).
+    // So when the paired store's last MP_MEM_HOST attention call came with a pinned query tensor, the next host-mode
+    // batch_retrieve enqueues that store's attention launch right behind its own kernel -- reading q from the remembered
+    // tensor, ||q|| from a row-norm kernel, the rows from hr_rows -- and the two calls cost ONE wait.  The attention call
+    // then only checks that it is the call the launch assumed (same store, layer, K, L, dtype, query pointer AND bytes,
+    // the caller's ||q|| within 2e-6 of the kernel's, rows untouched) and copies the outputs out of its pinned block;
+    // anything else: the launch's outputs are dropped and the call is served as before.
+    struct Spec {
+        mp_attn_t* attn = nullptr;         // the store whose last host-mode attention call paired with this handle's rows
+        const void* q_host = nullptr;      // its query tensor (pinned, mapped)
+        int q_dtype = 0, K = 0, L = 0;
+        bool launched = false;             // the last batch_retrieve issued the attention launch
+        int layer = -1;
+        unsigned long long attn_seq = 0;   // attn->host_seq when it did: another call on the store since then owns its pinned block
+        std::vector<unsigned char> q_snap; // the query bytes as they were when the launch was issued
+    } spec;
     bool hr_refused = false;       // the copy does not fit the accelerator budget: host-mode retrieves take the staged path
     int ret_users = 0;             // attention calls that are working on hr_rows / host_ret right now (under g_host_ret_mu)
     int64_t accel_budget = -1;     // HBM the accelerator structures (direct slots, hr_rows) may take over all layers; < 0: a third of
@@ -396,6 +421,11 @@ struct mp_attn {
     Stage small, big;              // host-buffer mode: (q | qn | nnz | offsets | out | mve) and the packed index rows
     HostMap hostmap;               // host-buffer mode: caller buffers the kernels use in place
     HostFlag hostflag;             // host-buffer mode: completion word (host_flag_wait)
+    unsigned long long host_seq = 0;   // MP_MEM_HOST attention calls (and speculative launches) on this store: each owns the pinned block
+    float* spec_qn = nullptr;      // [BH] ||q|| of a speculative launch (device)
+    float* score_alt = nullptr;    // [BH][M], [BH]: where a speculative launch leaves its logits and (max, Z) -- the caller-visible
+    float2* head_mz_alt = nullptr; // state (get_score of the LAST attention call) changes hands only when the launch is accepted
+    std::vector<mp_lsh_t*> spec_owners;   // LSH handles whose spec.attn points here (cleared on destroy, under g_host_ret_mu)
     int32_t* ind_rows = nullptr;   // host-buffer mode: [BH][M] device copy of `ind`
     int32_t* last_nnz = nullptr;   // [BH] staging copy of host-side nnz
     std::vector<int32_t> lastz_host;   // host-buffer fast path: the counts of the last call as the caller held them; get_score
@@ -584,6 +614,16 @@ int mp_lsh_create(mp_lsh_t** out) {
 
 static void lsh_free(mp_lsh_t* h) {
     host_ret_forget(h);
+    {   // the store this handle speculates for no longer lists it
+        std::lock_guard<std::mutex> lock(g_host_ret_mu);
+        if (h->spec.attn != nullptr) {
+            auto& ow = h->spec.attn->spec_owners;
+            for (size_t i = 0; i < ow.size(); ++i)
+                if (ow[i] == h) { ow.erase(ow.begin() + i); break; }
+            h->spec.attn = nullptr;
+        }
+        h->spec.launched = false;
+    }
     for (auto p : h->bounds) if (p) (void)hipFree(p);
     for (auto p : h->table) if (p) (void)hipFree(p);
     for (auto p : h->slots) if (p) (void)hipFree(p);
@@ -844,6 +884,95 @@ int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes
     return lsh_build_entry(h, nullptr, layer_id, request_id, codes, n, mem, (hipStream_t)stream, "mp_lsh_build");
 }
 
+// the store's pinned block in host-buffer mode: (q | qn | nnz | offsets) up, (out | mve) down, and the ||q|| a
+// speculative launch computed
+struct AttnHostLayout {
+    size_t qbytes, o_q, o_qn, o_nnz, o_offs, o_out, o_mve, o_sqn, o_end;
+};
+static AttnHostLayout attn_host_layout(int BH, int D, int query_dtype) {
+    AttnHostLayout a;
+    a.qbytes = (size_t)BH * D * (query_dtype == MP_DTYPE_BF16 ? 2 : 4);
+    a.o_q = 0;
+    a.o_qn = a.o_q + ((a.qbytes + 15) & ~(size_t)15);
+    a.o_nnz = a.o_qn + (size_t)BH * 4;
+    a.o_offs = a.o_nnz + (size_t)BH * 4;
+    a.o_out = (a.o_offs + (size_t)(BH + 1) * 4 + 15) & ~(size_t)15;
+    a.o_mve = a.o_out + (size_t)BH * D * 2;
+    a.o_sqn = a.o_mve + (size_t)2 * BH * 4;
+    a.o_end = a.o_sqn + (size_t)BH * 4;
+    return a;
+}
+static int attn_run(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint16_t* output, float* mve, const void* query,
+                    int query_dtype, const float* qn, const int32_t* ind, const int32_t* nnz, hipStream_t st);
+
+// mp_lsh::Spec: the paired store's attention launch, enqueued behind the host-mode retrieve that has just been launched
+static bool lsh_speculate(mp_lsh_t* h, int layer_id, hipStream_t st) {
+    h->spec.launched = false;
+    if (g_opt.host_speculate.load() == 0 || h->hr_rows == nullptr) return false;
+    mp_attn_t* a = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_host_ret_mu);       // (the store's destroy clears the pointer under this mutex)
+        a = h->spec.attn;
+    }
+    const int BH = h->B * h->H;
+    if (a == nullptr || !a->allocated || a->device != h->device || a->B * a->H != BH || a->M != h->M ||
+        layer_id >= a->layers || h->spec.q_host == nullptr)
+        return false;
+    const AttnHostLayout lo = attn_host_layout(BH, a->D, h->spec.q_dtype);
+    if (a->small.reserve(lo.o_end) != MP_OK || a->small.hd == nullptr) return false;
+    void* qdev = a->hostmap.resolve(h->spec.q_host, lo.qbytes);   // still pinned and mapped?  (the tensor may be gone)
+    if (qdev == nullptr) return false;
+    if (a->spec_qn == nullptr && hipMalloc((void**)&a->spec_qn, (size_t)BH * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        a->spec_qn = nullptr;
+        return false;
+    }
+    const unsigned char* qh = reinterpret_cast<const unsigned char*>(h->spec.q_host);
+    h->spec.q_snap.assign(qh, qh + lo.qbytes);                    // what the launch will have read
+    char* hd = reinterpret_cast<char*>(a->small.hd);
+    char* dp = reinterpret_cast<char*>(a->small.dp);
+    const void* qsrc = qdev;
+    if (BH > 64) {         // many heads: every workgroup reading its row over PCIe queues there (attn_entry): one relay first
+        if (launch_relay(qdev, dp + lo.o_q, lo.qbytes, st) != hipSuccess) { (void)hipGetLastError(); return false; }
+        qsrc = dp + lo.o_q;
+    }
+    if (launch_row_norm(qsrc, h->spec.q_dtype == MP_DTYPE_BF16, BH, a->D, a->spec_qn, reinterpret_cast<float*>(hd + lo.o_sqn), st) !=
+        hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (a->score_alt == nullptr) {
+        if (hipMalloc((void**)&a->score_alt, (size_t)BH * a->M * 4) != hipSuccess ||
+            hipMalloc((void**)&a->head_mz_alt, (size_t)BH * sizeof(float2)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (a->score_alt) (void)hipFree(a->score_alt);
+            a->score_alt = nullptr;
+            a->head_mz_alt = nullptr;
+            return false;
+        }
+    }
+    // the launch works on the store's SECOND set of score buffers and leaves the bookkeeping of the last caller-visible call
+    // alone: until the attention call accepts it, it has not happened as far as get_score is concerned
+    const int32_t* keep_lastz = a->lastz;
+    const int keep_state = a->score_state, keep_R = a->seg_R;
+    const int* keep_seg = a->seg_cnt;
+    std::swap(a->score, a->score_alt);
+    std::swap(a->head_mz, a->head_mz_alt);
+    const int arc = attn_run(a, layer_id, false, h->spec.K, h->spec.L, reinterpret_cast<uint16_t*>(hd + lo.o_out),
+                             reinterpret_cast<float*>(hd + lo.o_mve), qsrc, h->spec.q_dtype, a->spec_qn, h->hr_rows, h->hr_nnz, st);
+    std::swap(a->score, a->score_alt);
+    std::swap(a->head_mz, a->head_mz_alt);
+    a->lastz = keep_lastz;
+    a->score_state = keep_state;
+    a->seg_cnt = keep_seg;
+    a->seg_R = keep_R;
+    if (arc != MP_OK) return false;
+    h->spec.attn_seq = ++a->host_seq;
+    h->spec.layer = layer_id;
+    h->spec.launched = true;
+    return true;
+}
+
 int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32_t* results,
                           int32_t* nnz, int mem, mp_stream_t stream) {
     MP_ON_DEVICE(h);
@@ -865,6 +994,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     // pinned block and writes the ids straight into the caller's `results` rows (mapped once, HostMap) and the counts
     // into the pinned block: ONE launch, ONE synchronisation, no copy engine.
     host_ret_forget(h);                                   // hr_rows / hr_nnz are about to be rewritten
+    h->spec.launched = false;
     const size_t o_codes = (size_t)(2 * BH + 1) * 4, o_sums = (o_codes + qb + 7) & ~(size_t)7;
     int rc = h->small.reserve(o_sums + (size_t)BH * 8);
     if (rc) return rc;
@@ -914,6 +1044,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
                                              reinterpret_cast<int32_t*>(res_dev), reinterpret_cast<int32_t*>(hd), BH,
                                              h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, h->hr_rows, h->hr_nnz,
                                              reinterpret_cast<uint32_t*>(hd + o_sums), st));
+            (void)lsh_speculate(h, layer_id, st);         // the paired store's attention launch rides behind it (mp_lsh::Spec)
             if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) return rc;
             memcpy(nnz, hp, (size_t)BH * 4);
             if (mirror) {                         // only the first nnz[h] entries of a row mean anything
@@ -1108,6 +1239,18 @@ static int attn_new_version(mp_attn_t* h, int layer_id, int request_id, hipStrea
 }
 
 static void attn_free(mp_attn_t* h) {
+    {   // LSH handles that would enqueue this store's attention launch forget it
+        std::lock_guard<std::mutex> lock(g_host_ret_mu);
+        for (mp_lsh_t* l : h->spec_owners) {
+            l->spec.attn = nullptr;
+            l->spec.launched = false;
+        }
+        h->spec_owners.clear();
+    }
+    if (h->spec_qn) (void)hipFree(h->spec_qn);
+    if (h->score_alt) (void)hipFree(h->score_alt);
+    if (h->head_mz_alt) (void)hipFree(h->head_mz_alt);
+    h->spec_qn = nullptr; h->score_alt = nullptr; h->head_mz_alt = nullptr;
     for (auto p : h->kv) if (p) (void)hipFree(p);
     for (auto p : h->kn) if (p) (void)hipFree(p);
     h->kv.clear();
@@ -1366,12 +1509,12 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
     // host buffers: ONE block of small arguments up (q | qn | nnz | offsets), the index rows packed to their first
     // nnz[h] entries in ONE copy, unpacked on device into the handle's [BH][M] rows; (out | mve) come back in ONE
     // copy.  All staging is pinned and owned by the handle.
-    const size_t qbytes = (size_t)BH * h->D * (query_dtype == MP_DTYPE_BF16 ? 2 : 4);
-    const size_t o_q = 0, o_qn = o_q + ((qbytes + 15) & ~(size_t)15), o_nnz = o_qn + (size_t)BH * 4,
-                 o_offs = o_nnz + (size_t)BH * 4, o_out = (o_offs + (size_t)(BH + 1) * 4 + 15) & ~(size_t)15,
-                 o_mve = o_out + (size_t)BH * h->D * 2, o_end = o_mve + (size_t)2 * BH * 4;
+    const AttnHostLayout lo = attn_host_layout(BH, h->D, query_dtype);
+    const size_t qbytes = lo.qbytes, o_q = lo.o_q, o_qn = lo.o_qn, o_nnz = lo.o_nnz, o_offs = lo.o_offs, o_out = lo.o_out,
+                 o_mve = lo.o_mve, o_sqn = lo.o_sqn, o_end = lo.o_end;
     int rc = h->small.reserve(o_end);
     if (rc) return rc;
+    const unsigned long long seq_at_entry = h->host_seq++;      // this call owns the pinned block from here on
     char* hp = reinterpret_cast<char*>(h->small.hp);
     char* dp = reinterpret_cast<char*>(h->small.dp);
     memcpy(hp + o_q, query, qbytes);
@@ -1418,6 +1561,71 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
                 g_host_ret_cv.notify_all();
             }
         } release{l};
+        // the rows are those the retrieve handed out?  exact where the handle kept them, checksums where the kernel wrote
+        // the caller's pinned rows
+        auto rows_untouched = [&]() {
+            bool same = true;
+            const int32_t* kept = l->host_ret.kept;
+            for (int i = 0; i < BH && same; ++i) {
+                int64_t z = nnz[i];
+                z = z < 0 ? 0 : (z > h->M ? h->M : z);
+                if (kept != nullptr) {
+                    same = z == 0 || memcmp(ind + (size_t)i * h->M, kept + (size_t)i * h->M, (size_t)z * 4) == 0;
+                } else {
+                    uint32_t s1, s2;
+                    host_row_sum(ind + (size_t)i * h->M, z, &s1, &s2);
+                    same = s1 == l->host_ret.sums[2 * i] && s2 == l->host_ret.sums[2 * i + 1];
+                }
+            }
+            return same;
+        };
+        // what this call looks like, for the paired handle's next retrieve (mp_lsh::Spec): only with a pinned query tensor
+        auto remember_call = [&]() {
+            if (g_opt.host_speculate.load() == 0 || h->hostmap.resolve(query, qbytes) == nullptr) return;
+            std::lock_guard<std::mutex> lock(g_host_ret_mu);
+            if (l->spec.attn != h) {
+                if (l->spec.attn != nullptr) {
+                    auto& ow = l->spec.attn->spec_owners;
+                    for (size_t i = 0; i < ow.size(); ++i)
+                        if (ow[i] == l) { ow.erase(ow.begin() + i); break; }
+                }
+                l->spec.attn = h;
+                h->spec_owners.push_back(l);
+            }
+            l->spec.q_host = query;
+            l->spec.q_dtype = query_dtype;
+            l->spec.K = K;
+            l->spec.L = L;
+        };
+        if (l != nullptr && l->spec.launched) {
+            // The retrieve that handed these rows out has already run this store's attention launch behind its own kernel.
+            // Is this the call it assumed?  Same store, nothing else on the store's pinned block since, same layer / K / L /
+            // dtype, the same query tensor holding the same bytes, the caller's ||q|| within rounding of the kernel's.
+            l->spec.launched = false;                              // (a launch serves one call)
+            bool hit = l->spec.attn == h && l->spec.attn_seq == seq_at_entry && l->spec.layer == layer_id && l->spec.K == K &&
+                       l->spec.L == L && l->spec.q_dtype == query_dtype && l->spec.q_host == query &&
+                       l->spec.q_snap.size() == qbytes && memcmp(query, l->spec.q_snap.data(), qbytes) == 0;
+            if (hit) {
+                const float* sq = reinterpret_cast<const float*>(hp + o_sqn);
+                for (int i = 0; i < BH && hit; ++i) hit = fabsf(qn[i] - sq[i]) <= 2e-6f * fabsf(sq[i]);
+            }
+            if (hit && rows_untouched()) {
+                g_opt.host_spec_hits.fetch_add(1, std::memory_order_relaxed);
+                g_opt.host_fast_hits.fetch_add(1, std::memory_order_relaxed);
+                std::swap(h->score, h->score_alt);                 // the launch's logits and (max, Z) are the last call's now
+                std::swap(h->head_mz, h->head_mz_alt);
+                h->score_state = 1;
+                h->seg_cnt = nullptr;
+                h->seg_R = 1;
+                h->lastz_host.assign(nnz, nnz + BH);
+                h->lastz = nullptr;
+                memcpy(output, hp + o_out, (size_t)BH * h->D * 2);
+                memcpy(mve, hp + o_mve, (size_t)2 * BH * 4);
+                remember_call();
+                return MP_OK;
+            }
+            g_opt.host_spec_misses.fetch_add(1, std::memory_order_relaxed);
+        }
         if (l != nullptr) {
             // Launched BEFORE the rows are verified: the attention kernel works on the rows + counts the retrieve kernel left
             // in HBM (l->hr_rows / hr_nnz: written by that retrieve and by nothing else) while the host compares the
@@ -1437,19 +1645,7 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
                           reinterpret_cast<float*>(hd + o_mve), qsrc + o_q, query_dtype,
                           reinterpret_cast<const float*>(qsrc + o_qn), l->hr_rows, l->hr_nnz, st);
             if (rc) return rc;
-            bool same = true;
-            const int32_t* kept = l->host_ret.kept;
-            for (int i = 0; i < BH && same; ++i) {
-                int64_t z = nnz[i];
-                z = z < 0 ? 0 : (z > h->M ? h->M : z);
-                if (kept != nullptr) {
-                    same = z == 0 || memcmp(ind + (size_t)i * h->M, kept + (size_t)i * h->M, (size_t)z * 4) == 0;
-                } else {
-                    uint32_t s1, s2;
-                    host_row_sum(ind + (size_t)i * h->M, z, &s1, &s2);
-                    same = s1 == l->host_ret.sums[2 * i] && s2 == l->host_ret.sums[2 * i + 1];
-                }
-            }
+            const bool same = rows_untouched();
             if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) return rc;
             if (same) {
                 g_opt.host_fast_hits.fetch_add(1, std::memory_order_relaxed);
@@ -1457,6 +1653,7 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
                 h->lastz = nullptr;
                 memcpy(output, hp + o_out, (size_t)BH * h->D * 2);
                 memcpy(mve, hp + o_mve, (size_t)2 * BH * 4);
+                remember_call();
                 return MP_OK;
             }
             g_opt.host_fast_edited.fetch_add(1, std::memory_order_relaxed);
