@@ -829,14 +829,23 @@ hipError_t launch_host_flag(unsigned int* flag_dev, unsigned int value, hipStrea
 // ||q|| of every query row (f32 of a bf16 / f32 row: what the reference's caller computes on the host,
 // models/attnserver.py:300) for the attention launch the host-mode retrieve issues on its own (capi.hip: speculation): one
 // wave per row, written to HBM for the kernel and to pinned memory for the comparison with the norms the caller hands over
+// (q_copy: the rows are also copied to HBM -- the attention launch then reads nothing of the caller's any more)
 __global__ __launch_bounds__(256) void row_norm_kernel(const void* __restrict__ q, int bf16, int rows, int D,
-                                                       float* __restrict__ out_dev, float* __restrict__ out_host) {
+                                                       float* __restrict__ out_dev, float* __restrict__ out_host,
+                                                       void* __restrict__ q_copy) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     float s = 0.f;
     for (int d = lane; d < D; d += 64) {
-        const float x = bf16 ? bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(q)[(size_t)row * D + d])
-                             : reinterpret_cast<const float*>(q)[(size_t)row * D + d];
+        float x;
+        if (bf16) {
+            const uint16_t b = reinterpret_cast<const uint16_t*>(q)[(size_t)row * D + d];
+            reinterpret_cast<uint16_t*>(q_copy)[(size_t)row * D + d] = b;
+            x = bf16_bits_to_f32(b);
+        } else {
+            x = reinterpret_cast<const float*>(q)[(size_t)row * D + d];
+            reinterpret_cast<float*>(q_copy)[(size_t)row * D + d] = x;
+        }
         s = fmaf(x, x, s);
     }
     s = wave_sum(s);
@@ -846,8 +855,9 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const void* __restrict__ 
         out_host[row] = n;
     }
 }
-hipError_t launch_row_norm(const void* q, bool bf16, int rows, int D, float* out_dev, float* out_host, hipStream_t st) {
-    hipLaunchKernelGGL(row_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, q, bf16 ? 1 : 0, rows, D, out_dev, out_host);
+hipError_t launch_row_norm(const void* q, bool bf16, int rows, int D, float* out_dev, float* out_host, void* q_copy,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(row_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, q, bf16 ? 1 : 0, rows, D, out_dev, out_host, q_copy);
     return hipGetLastError();
 }
 

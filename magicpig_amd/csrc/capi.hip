@@ -78,7 +78,7 @@ hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, 
 bool lsh_hash_only_supported(int L);
 hipError_t launch_attn_ticket_check(int*, int, int*, hipStream_t);
 hipError_t launch_relay(const void*, void*, size_t, hipStream_t);
-hipError_t launch_row_norm(const void*, bool, int, int, float*, float*, hipStream_t);
+hipError_t launch_row_norm(const void*, bool, int, int, float*, float*, void*, hipStream_t);
 hipError_t launch_host_flag(unsigned int*, unsigned int, hipStream_t);
 hipError_t launch_host_rows(const int32_t*, const int32_t*, int32_t*, int64_t, int, const void*, void*, size_t, int,
                             hipStream_t);
@@ -120,6 +120,7 @@ struct DebugOptions {
                                              // kernel when the last attention call came with a pinned query tensor (see mp_lsh::Spec)
     std::atomic<int> host_spec_hits{0};      // counter: attention calls served by the launch the retrieve had issued
     std::atomic<int> host_spec_misses{0};    // counter: such a launch existed but the call's arguments were not what it had assumed
+    std::atomic<int> host_flag_timeouts{0};  // counter: a completion word did not arrive within ~5 ms (the stream was synchronised instead)
 };
 static DebugOptions g_opt;
 
@@ -146,6 +147,7 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "host_speculate")) return &g_opt.host_speculate;
     if (!strcmp(name, "host_spec_hits")) return &g_opt.host_spec_hits;
     if (!strcmp(name, "host_spec_misses")) return &g_opt.host_spec_misses;
+    if (!strcmp(name, "host_flag_timeouts")) return &g_opt.host_flag_timeouts;
     return nullptr;
 }
 
@@ -233,8 +235,11 @@ struct HostFlag {
     unsigned int* hp = nullptr;   // pinned word
     unsigned int* hd = nullptr;   // as the device sees it
     unsigned int seq = 0;
-    int wait(hipStream_t st, bool spin) {
-        if (spin && hp == nullptr) {
+    // arm: a one-thread kernel on `st` writes the next sequence number to the pinned word (0 = could not be armed);
+    // reached: spin until the word has got there (false after ~5 ms: the caller synchronises the stream instead).  A call may
+    // arm a word in the MIDDLE of what it enqueues and wait for that point only (capi.hip: the speculative attention launch).
+    unsigned int arm(hipStream_t st) {
+        if (hp == nullptr) {
             void* p = nullptr;
             if (hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess) {
                 hp = reinterpret_cast<unsigned int*>(p);
@@ -244,20 +249,27 @@ struct HostFlag {
             }
             if (hd == nullptr) (void)hipGetLastError();
         }
-        if (spin && hd != nullptr) {
-            const unsigned int want = ++seq;
-            if (launch_host_flag(hd, want, st) == hipSuccess) {
-                volatile unsigned int* f = hp;
-                for (long it = 0; it < 5000000L; ++it) {          // ~5 ms
-                    if (*f == want) return MP_OK;
-#if defined(__x86_64__)
-                    __builtin_ia32_pause();
-#endif
-                }
-            } else {
-                (void)hipGetLastError();
-            }
+        if (hd == nullptr) return 0u;
+        if (++seq == 0u) ++seq;
+        if (launch_host_flag(hd, seq, st) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0u;
         }
+        return seq;
+    }
+    bool reached(unsigned int want) const {
+        if (want == 0u || hp == nullptr) return false;
+        volatile unsigned int* f = hp;
+        for (long it = 0; it < 5000000L; ++it) {          // ~5 ms
+            if ((int)(*f - want) >= 0) return true;       // (a later number has passed it)
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        return false;
+    }
+    int wait(hipStream_t st, bool spin) {
+        if (spin && reached(arm(st))) return MP_OK;
         MP_HIP_CHECK(hipStreamSynchronize(st));
         return MP_OK;
     }
@@ -380,6 +392,9 @@ struct mp_lsh {
         int layer = -1;
         unsigned long long attn_seq = 0;   // attn->host_seq when it did: another call on the store since then owns its pinned block
         std::vector<unsigned char> q_snap; // the query bytes as they were when the launch was issued
+        bool prepared = false;             // the query's copy + norms are enqueued (in front of the retrieve kernel)
+        unsigned int done_flag = 0;        // the store's completion word behind the launch (0: synchronise `stream` instead)
+        hipStream_t stream = nullptr;
     } spec;
     bool hr_refused = false;       // the copy does not fit the accelerator budget: host-mode retrieves take the staged path
     int ret_users = 0;             // attention calls that are working on hr_rows / host_ret right now (under g_host_ret_mu)
@@ -905,9 +920,13 @@ static AttnHostLayout attn_host_layout(int BH, int D, int query_dtype) {
 static int attn_run(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint16_t* output, float* mve, const void* query,
                     int query_dtype, const float* qn, const int32_t* ind, const int32_t* nnz, hipStream_t st);
 
-// mp_lsh::Spec: the paired store's attention launch, enqueued behind the host-mode retrieve that has just been launched
-static bool lsh_speculate(mp_lsh_t* h, int layer_id, hipStream_t st) {
-    h->spec.launched = false;
+// mp_lsh::Spec, in two steps around the retrieve kernel's launch.  prepare (IN FRONT of it): is there a store to launch
+// for, is its caller's query tensor still pinned and mapped?  then snapshot the query bytes and enqueue the kernel that copies
+// the query rows to HBM and computes their norms -- from the retrieve call's return on, nothing enqueued reads the caller's
+// memory.  launch (BEHIND the retrieve kernel and the completion word the call waits for): the attention kernel on the copy,
+// then the store's own completion word.
+static bool lsh_spec_prepare(mp_lsh_t* h, int layer_id, hipStream_t st) {
+    h->spec.launched = h->spec.prepared = false;
     if (g_opt.host_speculate.load() == 0 || h->hr_rows == nullptr) return false;
     mp_attn_t* a = nullptr;
     {
@@ -927,20 +946,6 @@ static bool lsh_speculate(mp_lsh_t* h, int layer_id, hipStream_t st) {
         a->spec_qn = nullptr;
         return false;
     }
-    const unsigned char* qh = reinterpret_cast<const unsigned char*>(h->spec.q_host);
-    h->spec.q_snap.assign(qh, qh + lo.qbytes);                    // what the launch will have read
-    char* hd = reinterpret_cast<char*>(a->small.hd);
-    char* dp = reinterpret_cast<char*>(a->small.dp);
-    const void* qsrc = qdev;
-    if (BH > 64) {         // many heads: every workgroup reading its row over PCIe queues there (attn_entry): one relay first
-        if (launch_relay(qdev, dp + lo.o_q, lo.qbytes, st) != hipSuccess) { (void)hipGetLastError(); return false; }
-        qsrc = dp + lo.o_q;
-    }
-    if (launch_row_norm(qsrc, h->spec.q_dtype == MP_DTYPE_BF16, BH, a->D, a->spec_qn, reinterpret_cast<float*>(hd + lo.o_sqn), st) !=
-        hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
     if (a->score_alt == nullptr) {
         if (hipMalloc((void**)&a->score_alt, (size_t)BH * a->M * 4) != hipSuccess ||
             hipMalloc((void**)&a->head_mz_alt, (size_t)BH * sizeof(float2)) != hipSuccess) {
@@ -951,6 +956,27 @@ static bool lsh_speculate(mp_lsh_t* h, int layer_id, hipStream_t st) {
             return false;
         }
     }
+    const unsigned char* qh = reinterpret_cast<const unsigned char*>(h->spec.q_host);
+    h->spec.q_snap.assign(qh, qh + lo.qbytes);                    // what the launch will have read
+    char* hd = reinterpret_cast<char*>(a->small.hd);
+    char* dp = reinterpret_cast<char*>(a->small.dp);
+    if (launch_row_norm(qdev, h->spec.q_dtype == MP_DTYPE_BF16, BH, a->D, a->spec_qn, reinterpret_cast<float*>(hd + lo.o_sqn),
+                        dp + lo.o_q, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    h->spec.prepared = true;
+    return true;
+}
+
+static bool lsh_spec_launch(mp_lsh_t* h, int layer_id, hipStream_t st) {
+    if (!h->spec.prepared) return false;
+    h->spec.prepared = false;
+    mp_attn_t* a = h->spec.attn;
+    const int BH = h->B * h->H;
+    const AttnHostLayout lo = attn_host_layout(BH, a->D, h->spec.q_dtype);
+    char* hd = reinterpret_cast<char*>(a->small.hd);
+    char* dp = reinterpret_cast<char*>(a->small.dp);
     // the launch works on the store's SECOND set of score buffers and leaves the bookkeeping of the last caller-visible call
     // alone: until the attention call accepts it, it has not happened as far as get_score is concerned
     const int32_t* keep_lastz = a->lastz;
@@ -959,7 +985,8 @@ static bool lsh_speculate(mp_lsh_t* h, int layer_id, hipStream_t st) {
     std::swap(a->score, a->score_alt);
     std::swap(a->head_mz, a->head_mz_alt);
     const int arc = attn_run(a, layer_id, false, h->spec.K, h->spec.L, reinterpret_cast<uint16_t*>(hd + lo.o_out),
-                             reinterpret_cast<float*>(hd + lo.o_mve), qsrc, h->spec.q_dtype, a->spec_qn, h->hr_rows, h->hr_nnz, st);
+                             reinterpret_cast<float*>(hd + lo.o_mve), dp + lo.o_q, h->spec.q_dtype, a->spec_qn, h->hr_rows,
+                             h->hr_nnz, st);
     std::swap(a->score, a->score_alt);
     std::swap(a->head_mz, a->head_mz_alt);
     a->lastz = keep_lastz;
@@ -967,6 +994,8 @@ static bool lsh_speculate(mp_lsh_t* h, int layer_id, hipStream_t st) {
     a->seg_cnt = keep_seg;
     a->seg_R = keep_R;
     if (arc != MP_OK) return false;
+    h->spec.done_flag = a->hostflag.arm(st);
+    h->spec.stream = st;
     h->spec.attn_seq = ++a->host_seq;
     h->spec.layer = layer_id;
     h->spec.launched = true;
@@ -1000,7 +1029,12 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
     if (rc) return rc;
     if (g_opt.host_zero_copy.load() != 0 && h->small.hd != nullptr) {
         const size_t rbytes = (size_t)BH * h->M * 4;
-        void* res_dev = h->hostmap.resolve(results, rbytes);
+        // Where the attention launch rides behind this call (mp_lsh::Spec), the caller's rows are verified by the HOST at the
+        // attention call with nothing left to hide that under: an exact compare against the handle's mirror (both in cache
+        // by then: the rows were just copied from one to the other) costs a fifth of the two checksums over 190 KB the GPU
+        // has just written -- so PINNED caller rows go through the mirror too (measured at cfg 1: attention_wrapper 36 -> 15 us)
+        const bool spec_likely = g_opt.host_speculate.load() != 0 && h->spec.attn != nullptr && h->spec.q_host != nullptr;
+        void* res_dev = spec_likely ? nullptr : h->hostmap.resolve(results, rbytes);
         bool mirror = false;
         if (res_dev == nullptr) {                 // pageable `results`: the rows go to the handle's pinned mirror
             rc = h->big.reserve(rbytes, true);
@@ -1032,6 +1066,7 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
             char* hp = reinterpret_cast<char*>(h->small.hp);
             char* hd = reinterpret_cast<char*>(h->small.hd);
             memcpy(hp + o_codes, query, qb);
+            const bool spec = lsh_spec_prepare(h, layer_id, st);            // (mp_lsh::Spec: query copy + norms, in front)
             h->lastq = reinterpret_cast<const int32_t*>(hd + o_codes);      // (get_mask reads them again)
             h->last_layer = layer_id;
             h->last_lean = false;
@@ -1044,8 +1079,18 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
                                              reinterpret_cast<int32_t*>(res_dev), reinterpret_cast<int32_t*>(hd), BH,
                                              h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, h->hr_rows, h->hr_nnz,
                                              reinterpret_cast<uint32_t*>(hd + o_sums), st));
-            (void)lsh_speculate(h, layer_id, st);         // the paired store's attention launch rides behind it (mp_lsh::Spec)
-            if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) return rc;
+            if (spec) {
+                // the call waits for ITS kernel's completion word; the paired store's attention launch rides behind that word
+                // and is waited for by the attention call (or by whatever synchronises the stream next)
+                const unsigned int mine = h->hostflag.arm(st);
+                (void)lsh_spec_launch(h, layer_id, st);
+                if (!h->hostflag.reached(mine)) {
+                    if (mine != 0u) g_opt.host_flag_timeouts.fetch_add(1, std::memory_order_relaxed);
+                    MP_HIP_CHECK(hipStreamSynchronize(st));
+                }
+            } else if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) {
+                return rc;
+            }
             memcpy(nnz, hp, (size_t)BH * 4);
             if (mirror) {                         // only the first nnz[h] entries of a row mean anything
                 const int32_t* rows = reinterpret_cast<const int32_t*>(h->big.hp);
@@ -1606,10 +1651,14 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
                        l->spec.L == L && l->spec.q_dtype == query_dtype && l->spec.q_host == query &&
                        l->spec.q_snap.size() == qbytes && memcmp(query, l->spec.q_snap.data(), qbytes) == 0;
             if (hit) {
-                const float* sq = reinterpret_cast<const float*>(hp + o_sqn);
+                const float* sq = reinterpret_cast<const float*>(hp + o_sqn);        // (written in front of the retrieve kernel)
                 for (int i = 0; i < BH && hit; ++i) hit = fabsf(qn[i] - sq[i]) <= 2e-6f * fabsf(sq[i]);
             }
             if (hit && rows_untouched()) {
+                if (!h->hostflag.reached(l->spec.done_flag)) {
+                    if (l->spec.done_flag != 0u) g_opt.host_flag_timeouts.fetch_add(1, std::memory_order_relaxed);
+                    MP_HIP_CHECK(hipStreamSynchronize(l->spec.stream));
+                }
                 g_opt.host_spec_hits.fetch_add(1, std::memory_order_relaxed);
                 g_opt.host_fast_hits.fetch_add(1, std::memory_order_relaxed);
                 std::swap(h->score, h->score_alt);                 // the launch's logits and (max, Z) are the last call's now
@@ -1625,6 +1674,9 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
                 return MP_OK;
             }
             g_opt.host_spec_misses.fetch_add(1, std::memory_order_relaxed);
+            // the launch's outputs are dropped: what this call enqueues overwrites them in stream order -- on another
+            // stream only behind a synchronisation
+            if (l->spec.stream != st) MP_HIP_CHECK(hipStreamSynchronize(l->spec.stream));
         }
         if (l != nullptr) {
             // Launched BEFORE the rows are verified: the attention kernel works on the rows + counts the retrieve kernel left

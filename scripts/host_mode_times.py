@@ -97,4 +97,5 @@ host_layer(qs[0]); a = out_cuda.clone(); device_three_call(qs[0])
 # (the host path takes ||q|| from torch's CPU norm, attnserver.py:300: f32 sums in another order than the kernel's)
 print("max |host - device| output:", float((a.float() - d_out.float()).abs().max()), " nnz equal:", torch.equal(nnz.cuda(), d_nnz))
 import magicpig_amd._lib as _L
-print("attention calls served:", {n: _L.get_option("host_fast_" + n) for n in ("hits", "edited", "unpaired")})
+print("attention calls served:", {n: _L.get_option("host_fast_" + n) for n in ("hits", "edited", "unpaired")},
+      "by the launch behind the retrieve:", {n: _L.get_option("host_" + n) for n in ("spec_hits", "spec_misses", "flag_timeouts")})
