@@ -185,6 +185,8 @@ def parse():
                     help="GB of HBM the LSH handle may spend on accelerator structures over all layers (direct piece slots, the "
                          "host-buffer mode's row copy): mp_lsh_alloc_ex.  Default: the library's rule (a third of what is free)")
     ap.add_argument("--ranges", type=int, default=0, help="token ranges per table row = workgroups per head (mp_lsh_alloc_ex; 0 = auto)")
+    ap.add_argument("--quad-hash", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="A/B: the quad MFMA query hash at one workgroup per head (cfg 2 / 3): 0 never, 1 on, 2 on but nobody publishes")
     ap.add_argument("--two-launch", action="store_true",
                     help="A/B: the decode entry as (hash + retrieve) then attention instead of one launch")
     ap.add_argument("--end-to-end", action="store_true",
@@ -841,6 +843,8 @@ def main():
         L.set_option("decode_cluster", args.cluster)
     if args.split_hash >= 0:
         L.set_option("decode_split_hash", args.split_hash)
+    if args.quad_hash >= 0:
+        L.set_option("decode_quad_hash", args.quad_hash)
     if args.slot_log2:
         L.set_option("decode_slot_log2", args.slot_log2)
     if args.no_direct_slots:

@@ -268,6 +268,12 @@ int mp_debug_xcd_round_robin(void);
  *                        are split over the workgroups of a head's cluster and the sign bits exchanged through the
  *                        XCD's L2, with a bounded wait and hashing alone as the fallback; 2 = split but nobody
  *                        publishes (test: every workgroup takes the fallback)
+ *   "decode_quad_hash"   one workgroup per head (B*H >= CUs / 2), B*H a multiple of 32, head_dim 128, XCD placement observed:
+ *                        1 = the four heads of an XCD residue inside a block of 32 hash together -- each evaluates a quarter of
+ *                        the hyperplanes against the four query rows with v_mfma_f32_32x32x16_bf16 and hands the sign bits to
+ *                        their heads through the XCD's L2 (words tagged with the launch's number, bounded wait, hashing alone as
+ *                        the fallback); 2 = the same but nobody publishes (test: every head falls back); 0 = never; -1 = the
+ *                        library's choice
  *   "decode_kn_payload"  1 = the decode entries pack the key norms into the table entries and use them (default, while
  *                        the layer's ids fit 17 bits), 0 = one HBM access per selected token
  *   "decode_direct"      -1 = auto, 0 = never, 1 = always (where R > 1): keep direct slots (length, position + the first

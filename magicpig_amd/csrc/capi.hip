@@ -31,7 +31,7 @@ hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, co
                              float*, float2*, int*, int*, uint16_t*, float*, float2*, const int32_t*, int, float*, int*,
                              int, int, bool, const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t,
                              bool, unsigned long long*, unsigned int*, int, int, int, const int*, const int*, const unsigned int*,
-                             const unsigned int*, bool, bool*, hipStream_t);
+                             const unsigned int*, bool, bool*, const uint16_t*, int, hipStream_t);
 hipError_t set_stamp_stride(int);
 void set_exact_norm(int);
 void set_slot_log2(int);
@@ -100,6 +100,7 @@ struct DebugOptions {
     std::atomic<int> decode_agent_scope{0};  // 1: cluster hand-off through memory even when the XCD placement was observed
     std::atomic<int> decode_mfma_hash{0};    // 1: query SimHash by the MFMA kernel in a launch of its own, then the decode
     std::atomic<int> decode_split_hash{-1};  // -1 = auto, 0 = never, 1 = always (clusters on one XCD), 2 = split but nobody publishes (test)
+    std::atomic<int> decode_quad_hash{-1};   // one workgroup per head: -1 = auto, 0 = never, 1 = the heads of an XCD residue hash in quads on the matrix pipe
     std::atomic<int> decode_direct{-1};      // -1 = auto, 0 = never, 1 = always (when R > 1) keep direct piece slots
     std::atomic<int> attn_head_kernel{-1};   // -1 = auto, 0 = split-KV kernel, 1 = one workgroup per head
     std::atomic<int> attn_gx{0};             // 0 = auto, else split-KV workgroups per head
@@ -131,6 +132,7 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "decode_agent_scope")) return &g_opt.decode_agent_scope;
     if (!strcmp(name, "decode_direct")) return &g_opt.decode_direct;
     if (!strcmp(name, "decode_split_hash")) return &g_opt.decode_split_hash;
+    if (!strcmp(name, "decode_quad_hash")) return &g_opt.decode_quad_hash;
     if (!strcmp(name, "decode_mfma_hash")) return &g_opt.decode_mfma_hash;
     if (!strcmp(name, "attn_head_kernel")) return &g_opt.attn_head_kernel;
     if (!strcmp(name, "attn_gx")) return &g_opt.attn_gx;
@@ -741,11 +743,13 @@ int mp_lsh_alloc_ex(mp_lsh_t* h, int K, int L, int num_layers, int num_attention
         }
     }
     h->xwords = 2 * ((K * L + 63) / 64);
-    if (rc == MP_OK && h->R > 1) rc = alloc_zero((void**)&h->xw, BH * (size_t)h->xwords * 8);
-    if (rc == MP_OK && h->R > 1) {
+    const bool quads = h->R == 1 && BH % 32 == 0;              // one workgroup per head, heads in blocks of 32: the quad hash's exchange
+    if (rc == MP_OK && (h->R > 1 || quads)) rc = alloc_zero((void**)&h->xw, BH * (size_t)h->xwords * 8);
+    if (rc == MP_OK && (h->R > 1 || quads)) {
         rc = alloc_zero((void**)&h->xseq, BH * 4);
         // words start at sequence 0, launches at 1: nothing stale can pass for a word of the first launch
-        if (rc == MP_OK && hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->xseq), 1, BH) != hipSuccess) rc = MP_ERR_HIP;
+        // (quads: the word of a quad's first head is its arrival counter, launch number = counter / 4: starts at 4)
+        if (rc == MP_OK && hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->xseq), quads ? 4 : 1, BH) != hipSuccess) rc = MP_ERR_HIP;
     }
     if (rc == MP_OK) rc = alloc_zero((void**)&h->pay_bad, (size_t)num_layers * batch_size * num_key_value_heads * 4);
     if (rc == MP_OK) rc = alloc_zero((void**)&h->att_ver_dev, (size_t)num_layers * batch_size * num_key_value_heads * 4);
@@ -2073,7 +2077,7 @@ static int decode_layer(mp_simhash_t* s, mp_lsh_t* lsh, mp_attn_t* attn, mp_attn
                                        win ? win->kv[layer_id] : nullptr, win_len, win ? win->M : 0, BH, lsh->G,
                                        lsh->L, lsh->NB, lsh->M, mfma_hash, lsh->xw, lsh->xseq, lsh->xwords, xmode, lsh->idbits_of[layer_id], lsh->idbits_dev + layer_id,
                                        kn_payload ? lsh->pay_bad + goff : nullptr, lsh->att_ver_dev + goff,
-                                       attn->kn_ver_dev + goff, lean, &lean, st));
+                                       attn->kn_ver_dev + goff, lean, &lean, s->Wt, g_opt.decode_quad_hash.load(), st));
         attn->lastz = lsh->nnz;
         attn->score_state = lean ? 3 : 1;               // 3: the last call left no logits (mp_attn_get_score says so)
         attn->seg_cnt = lsh->R > 1 ? attn->part_cnt : nullptr;

@@ -761,7 +761,7 @@ struct AttnArgs {
     // stand-alone retrieve, host-buffer mode (capi.hip: HostRetrieve): a second copy of the emitted rows in HBM and a
     // checksum per row (two u32 sums: row_mix of (entry, position), entry x position), by which the attention entry
     // recognises rows the kernel wrote straight into the caller's pinned memory
-    int32_t* rows2;          // [BH][M] or nullptr
+    int32_t* rows2;          // [BH][M] or nullptr  (HASH = 5: the hyperplanes' plane-major copy Wt [KLpad][D] bf16 instead)
     uint32_t* rowsum;        // [BH][2] or nullptr
     // (with rows2 the stand-alone retrieve also leaves a second copy of its counts in HBM -- nnz is pinned host memory then --
     // through part_cnt, which only the decode uses otherwise: a field of its own grew the decode kernel's argument block and
@@ -840,9 +840,15 @@ __device__ __forceinline__ void lsh_head_body(
     //    elements per lane (D = 64, 128 or 256).  Requested before anything else touches the kernel arguments: they
     //    arrive in half a dozen dependent scalar loads, and behind them the row was requested ~1 us into the kernel.
     uint32_t e01 = 0u, e23 = 0u;                                 // elements 0,1 | 2,3 of this lane (bf16 pairs)
-    if ((HASH == 1 || HASH == 3) && wave == 0) {                 // ONE load per lane, no loop: nothing to wait for here
+    // HASH = 5 (one workgroup per head, B*H a multiple of 32, head_dim 128): the heads h0 + 8 i, i < 4 -- four workgroups of
+    // one XCD -- hash TOGETHER: member qm evaluates the 32-plane tiles t = qm (mod 4) against all FOUR query rows on the
+    // matrix pipe and hands every row's sign bits to its head through the XCD's L2 (below).  Waves 0 .. 3 fetch a row each.
+    constexpr bool QUAD = HASH == 5;
+    const int64_t qh0 = (h & ~(int64_t)31) + (h & 7);
+    const int qm = (int)((h & 31) >> 3);
+    if ((HASH == 1 || HASH == 3 || HASH == 5) && wave < (QUAD ? 4 : 1)) {   // ONE load per lane, no loop: nothing to wait for here
         const int per0 = ha.D >> 6;
-        const uint16_t* src = ha.q + (padding_block ? 0 : h) * ha.D + lane * per0;
+        const uint16_t* src = ha.q + (padding_block ? 0 : (QUAD ? qh0 + 8 * wave : h)) * ha.D + lane * per0;
         if (per0 == 2) e01 = *reinterpret_cast<const uint32_t*>(src);
         else if (per0 == 1) e01 = *src;
         else {
@@ -912,7 +918,7 @@ __device__ __forceinline__ void lsh_head_body(
             if (lane == 0) s_rn[1] = ha.qnorm_out[h];
         }
     }
-    if (HASH == 1 || HASH == 3) {
+    if (HASH == 1 || HASH == 3 || HASH == 5) {
         const int D = ha.D, KL = ha.K * L;
         const int chunks = D >> 3;                              // 16-byte plane chunks per hyperplane
         const u32x4* Wk4 = reinterpret_cast<const u32x4*>(ha.Wk);
@@ -939,13 +945,21 @@ __device__ __forceinline__ void lsh_head_body(
 #pragma unroll
             for (int i = 0; i < CH; ++i) w[i] = Wk4[cc + (int64_t)i * ha.KLpad];
         };
-        load_planes(split ? (unit << 6) + lane : tid);
+        if (!QUAD) load_planes(split ? (unit << 6) + lane : tid);   // (the quad's members pull a quarter of the planes, as MFMA tiles)
+        // QUAD: this launch's number = the quad's arrival counter / 4, drawn HERE by an L2 atomic (launches of a stream do not
+        // overlap: the four members of launch k draw 4 k .. 4 k + 3 before any member of launch k + 1 exists); a word tagged
+        // with it proves by itself that it belongs to this launch.  Wave 15 has no tile: it draws.
+        if (QUAD && wave == RT_WAVES - 1 && lane == 0)
+            s_tmp[28] = (int)(__hip_atomic_fetch_add(aa.xseq + qh0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 2);
+        uint32_t* s_q4 = s_tail;                                 // QUAD: the four normalised rows [4][64 words] (the pool's LDS, unused
+        float* s_rn4 = reinterpret_cast<float*>(s_tail + 256);   // until the probe) and their guard bounds
         // the column norm of the first column this thread decides: fetched here, under the query row's round trip (as a
         // load behind the dot chain its L2 latency sat between the dots and the sign)
         const int col_first = split ? (unit << 6) + lane : tid;
         const float wn_first = ha.wnorm[col_first < ha.KLpad ? col_first : ha.KLpad - 1];
-        // -- normalise the query row
-        if (wave == 0) {
+        // -- normalise the query row (QUAD: waves 0 .. 3 one row of the quad each; wave qm's is this head's own)
+        const bool own_row = !QUAD || wave == qm;
+        if (wave < (QUAD ? 4 : 1)) {
 #if MP_SETPRIO_WAVE0
             __builtin_amdgcn_s_setprio(3);     // the one wave everybody waits for: ahead of its 15 siblings at the issue ports
 #endif
@@ -983,8 +997,9 @@ __device__ __forceinline__ void lsh_head_body(
                 nrm = (float)sqrt((double)(float)ss);          // (__fsqrt_rn measured no faster here, and not bit-identical)
             }
             nb = bf16_bits_to_f32(f32_to_bf16_rne(nrm));
-            if (!LEAN && lane == 0 && lead && ha.qnorm_out != nullptr) ha.qnorm_out[h] = nrm;
+            if (!LEAN && lane == 0 && lead && own_row && ha.qnorm_out != nullptr) ha.qnorm_out[h] = nrm;
             uint16_t* dst = reinterpret_cast<uint16_t*>(s_q) + lane * per;
+            uint16_t* dst4 = reinterpret_cast<uint16_t*>(s_q4 + wave * 64) + lane * per;
             uint16_t* raw = reinterpret_cast<uint16_t*>(s_qraw) + lane * per;
             float tq[4];
             bool amb = false;
@@ -1008,13 +1023,20 @@ __device__ __forceinline__ void lsh_head_body(
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < per) {
-                    dst[i] = f32_to_bf16_rne(tq[i]);
-                    if (AD > 0) raw[i] = e[i];
+                    const uint16_t nq = f32_to_bf16_rne(tq[i]);
+                    if (QUAD) dst4[i] = nq;
+                    if (own_row) {
+                        dst[i] = nq;
+                        if (AD > 0) raw[i] = e[i];
+                    }
                 }
             // ||nq|| <= ||q||/nb * (1 + 2^-8): every element is rounded to bf16 once (guard bound)
             if (lane == 0) {
-                s_rn[0] = (nrm / nb) * 1.005f;
-                s_rn[1] = nrm;
+                if (QUAD) s_rn4[wave] = (nrm / nb) * 1.005f;
+                if (own_row) {
+                    s_rn[0] = (nrm / nb) * 1.005f;
+                    s_rn[1] = nrm;
+                }
             }
             MP_STAMP(stamp, 29);                               // normalised row written to LDS
 #if MP_SETPRIO_WAVE0
@@ -1057,6 +1079,89 @@ __device__ __forceinline__ void lsh_head_body(
             }
         };
         bool have_bits = false;                                  // (every workgroup barrier below orders LDS only)
+        if constexpr (QUAD) {
+            // ---- tile t = qm + 4 wave (32 planes) x the quad's four rows: C' = W X^T by v_mfma_f32_32x32x16_bf16 -- A = the
+            // planes (plane-major copy Wt: lane (n, kh) holds plane n's k-chunk kh of every 16-wide step), B = the rows
+            // (row n < 4 from LDS, rows 4 .. 31 zero: 7/8 of the tile is idle, which costs nothing: the pipe has nothing else
+            // to do); lane (n, kh) ends up with C[plane (i / 4) 8 + kh 4 + i % 4][row n], i < 16.  Guard band as everywhere
+            // (2^-16 ||nq|| ||w||, here against the widest plane of the tile), exact f64 recomputation inside it.
+            // (the plane-major copy travels in AttnArgs::rows2, which only the stand-alone retrieve uses otherwise: a field of
+            // its own would grow the argument block of every instantiation -- measured +0.1 us at cfg 1 in round 5)
+            const uint16_t* Wt5 = reinterpret_cast<const uint16_t*>(aa.rows2);
+            const int T2 = 2 * U;                                    // 32-bit words (= tiles) the head's workgroup polls
+            const int tile = qm + 4 * wave;
+            const int n = lane & 31, kh = lane >> 5;
+            const uint32_t kq = (uint32_t)s_tmp[28];                 // (drawn in front of the barrier behind the normalisation)
+            if (tile < T2 && aa.xmode != 2) {
+                const uint16_t* wrow = Wt5 + (int64_t)(tile * 32 + n) * D + kh * 8;
+                u32x4 av[8], bv[8];
+#pragma unroll
+                for (int st8 = 0; st8 < 8; ++st8) av[st8] = *reinterpret_cast<const u32x4*>(wrow + st8 * 16);
+                const float wn_n = ha.wnorm[tile * 32 + n];
+#pragma unroll
+                for (int st8 = 0; st8 < 8; ++st8)
+                    bv[st8] = n < 4 ? *reinterpret_cast<const u32x4*>(s_q4 + n * 64 + st8 * 8 + kh * 4) : u32x4{0u, 0u, 0u, 0u};
+                f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st8 = 0; st8 < 8; ++st8)
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[st8]), __builtin_bit_cast(bf16x8, bv[st8]),
+                                                                c, 0, 0, 0);
+                const float band = (1.0f / 65536.0f) * s_rn4[n & 3] * wave_max(wn_n);
+                uint32_t bits = 0u, nearm = 0u;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int pb = (i / 4) * 8 + kh * 4 + (i % 4);
+                    bits |= (c[i] > 0.f ? 1u : 0u) << pb;
+                    nearm |= (fabsf(c[i]) <= band ? 1u : 0u) << pb;
+                }
+                // planes past K L are padding (zero columns: their exact product IS zero, bit 0 -- nothing to recompute; left
+                // in, the all-padding tile at the end of the row cost its wave 128 recomputations and its peers a time-out)
+                const int live = KL - tile * 32;
+                const uint32_t livem = live >= 32 ? 0xffffffffu : (live <= 0 ? 0u : (1u << live) - 1u);
+                bits &= livem;
+                nearm &= livem;
+                if (n >= 4) nearm = 0u;
+                for (unsigned long long fm = __ballot(nearm != 0u); fm; fm &= fm - 1) {   // wave-uniform: rare
+                    const int src = __ffsll((long long)fm) - 1;
+                    uint32_t left = (uint32_t)__builtin_amdgcn_readlane((int)nearm, src);
+                    const int row = src & 3;
+                    while (left) {
+                        const int pb = __ffs((int)left) - 1;
+                        left &= left - 1;
+                        const uint32_t qw = s_q4[row * 64 + lane];                            // elements 2 lane, 2 lane + 1
+                        const uint32_t ww = *reinterpret_cast<const uint32_t*>(Wt5 + (int64_t)(tile * 32 + pb) * D + 2 * lane);
+                        const double part = (double)bf16_lo(qw) * (double)bf16_lo(ww) + (double)bf16_hi(qw) * (double)bf16_hi(ww);
+                        const double ex = wave_sum(part);
+                        if (lane == src) bits = (bits & ~(1u << pb)) | ((ex > 0.0 ? 1u : 0u) << pb);
+                    }
+                }
+                bits |= (uint32_t)__shfl_xor((int)bits, 32);         // the two k-halves hold disjoint planes of the tile
+                MP_STAMP(stamp, 23);                                 // own tile evaluated
+                if (lane < 4) {                                      // row `lane`'s 32 sign bits of this tile -> that row's head
+                    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(       // (one descriptor over the block of 32 heads)
+                        aa.xw + (h & ~(int64_t)31) * aa.xwords, 0, 32 * aa.xwords * 8, 0x00020000);
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 pk = {bits, kq};
+                    __builtin_amdgcn_raw_buffer_store_b64(pk, rx, (((int)(h & 7) + 8 * lane) * aa.xwords + tile) * 8, 0, 1);   // sc0: to the XCD's L2
+                }
+            }
+            unsigned long long* xh = aa.xw + h * aa.xwords;
+            if (tid < T2) {
+                unsigned long long v = 0;
+                bool ok = false;
+                for (int it = 0; it < 96 && !ok; ++it) {             // bounded: a member may only wait for peers that are running
+                    v = __hip_atomic_load(xh + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (uint32_t)(v >> 32) == kq;
+                }
+                s_bits[tid] = (uint32_t)v;
+                if (!ok) s_tmp[29] = 0;
+            }
+            __syncthreads();
+            MP_STAMP(stamp, 24);
+            have_bits = s_tmp[29] != 0;                              // uniform
+            bits_exchanged = have_bits;
+            if (!have_bits) load_planes(tid);                        // a peer is not running: this head hashes alone
+        }
         if (split) {
             // ---- this wave's unit (if it has one), published as two 64-bit words (sequence << 32 | 32 sign bits):
             // a word proves by itself that it belongs to THIS launch, so there is no counter, no acknowledgement and
@@ -1319,7 +1424,7 @@ __device__ __forceinline__ void lsh_head_body(
 #pragma unroll
             for (int b = 0; b < DG; ++b) v[b] = MP_TLOAD(sg + at[b]);
             MP_STAMP(stamp, 42);                                     // slot loads issued
-            if (!LEAN && (HASH == 1 || HASH == 3) && lead && sl == 0) {
+            if (!LEAN && (HASH == 1 || HASH == 3 || HASH == 5) && lead && sl == 0) {
 #pragma unroll
                 for (int b = 0; b < DG; ++b) {
                     const int l = l0 + (b * RT_WAVES + wave) * GPW + grp;
@@ -1434,7 +1539,7 @@ __device__ __forceinline__ void lsh_head_body(
             int code;
             if (HASH != 0) {
                 code = code_of(l);
-                if (!LEAN && (HASH == 1 || HASH == 3) && lead) ha.codes_out[h * L + l] = code;
+                if (!LEAN && (HASH == 1 || HASH == 3 || HASH == 5) && lead) ha.codes_out[h * L + l] = code;
             } else {
                 code = query[h * L + l];
             }
@@ -2461,6 +2566,8 @@ static hipError_t retrieve_attr_set() {
                          reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, false, 3>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, true, 3>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, true, 3>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, false, 5>),
+                         reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, true, 5>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, false, 1, true>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<8, 64, false, 1, true>),
                          reinterpret_cast<const void*>(lsh_decode_kernel<16, 128, true, 1, true>),
@@ -2552,7 +2659,7 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
                              const int32_t* win_len, int64_t win_M, int BH, int G, int L, int NB, int64_t M,
                              bool codes_given, unsigned long long* xw, unsigned int* xseq, int xwords, int xmode,
                              int idbits, const int* idbits_dev, const int* pay_bad, const unsigned int* att_ver,
-                             const unsigned int* kn_ver, bool lean, bool* lean_ran, hipStream_t st) {
+                             const unsigned int* kn_ver, bool lean, bool* lean_ran, const uint16_t* Wt, int quad_mode, hipStream_t st) {
     const int range_len = lsh_range_len(M, R);
     const int words = range_len / 32;
     const int Lpad = (L + 63) & ~63;
@@ -2600,6 +2707,24 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
         else
             hipLaunchKernelGGL((lsh_decode_kernel<8, 64, false, 2>), grid, dim3(RT_THREADS), lds, st, bounds, table,
                                results, nnz, G, L, NB, M, R, range_len, words, Lpad, idbits, ha, aa, g_stamp);
+        return hipGetLastError();
+    }
+    // HASH = 5, the quad MFMA hash: one workgroup per head, the heads in blocks of 32 (four per XCD residue), head_dim 128,
+    // the placement block b -> XCD b % 8 observed, an exchange word per 32 planes, at most 64 tiles (16 waves x 4 members)
+    const bool sxq = same_xcd && xcd_round_robin_verified();
+    if (quad_mode >= 1 && clog == 0 && D == 128 && BH % 32 == 0 && sxq && Wt != nullptr && xw != nullptr && xseq != nullptr &&
+        !codes_given && 2 * ((K * L + 63) / 64) <= 64 && 2 * ((K * L + 63) / 64) <= xwords &&
+        2 * ((K * L + 63) / 64) * 32 <= KLpad && words % 2 == 0) {     // (the rows' LDS copies are read 16 bytes at a time)
+        aa.xw = xw;
+        aa.xseq = xseq;
+        aa.xmode = quad_mode == 2 ? 2 : 1;                          // 2: nobody publishes (test: every head falls back to hashing alone)
+        aa.rows2 = reinterpret_cast<int32_t*>(const_cast<uint16_t*>(Wt));
+        if (win_kv != nullptr)
+            hipLaunchKernelGGL((lsh_decode_kernel<16, 128, true, 5>), grid, dim3(RT_THREADS), lds, st, bounds, table, results, nnz,
+                               G, L, NB, M, R, range_len, words, Lpad, idbits, ha, aa, g_stamp);
+        else
+            hipLaunchKernelGGL((lsh_decode_kernel<16, 128, false, 5>), grid, dim3(RT_THREADS), lds, st, bounds, table, results, nnz,
+                               G, L, NB, M, R, range_len, words, Lpad, idbits, ha, aa, g_stamp);
         return hipGetLastError();
     }
 #define MP_DECODE_CASE(DD, CHH, WW)                                                                            \
