@@ -1738,7 +1738,9 @@ __device__ __forceinline__ void lsh_head_body(
 #ifndef MP_LEAN_CL
 #define MP_LEAN_CL SHORT_L                 // A/B: entries per claim where a head is a cluster (12: a claim = what a wave adds on average)
 #endif
-        const int CL = (SHORT_L < AH_SLICE && clog > 0) ? MP_LEAN_CL : AH_SLICE;    // uniform: entries per claim
+        // (the launcher uses this form only where a head is a cluster: the step is the short one -- 16 tokens at head_dim 128 --
+        // and no 32-token instantiation of the fold sits in this kernel: its registers were the kernel's spills)
+        const int CL = SHORT_L < AH_SLICE ? MP_LEAN_CL : AH_SLICE;                  // uniform: entries per claim
         int folded = 0;
         for (;;) {
             int start = 0, nh = 0;
@@ -1778,25 +1780,28 @@ __device__ __forceinline__ void lsh_head_body(
             }
             if (over) break;
 #else
+            // (the first look at the two counters travels with the claim: one LDS round trip, not two)
+            int done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int res = __hip_atomic_load(s_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (lane == 0) start = __hip_atomic_fetch_add(s_head, CL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             start = __builtin_amdgcn_readfirstlane(start);
             if (start >= lcap) break;                                    // (beyond the stage: the spill list, below)
             // until the slice is reserved in full, or nobody counts any more (then `res` is final: a wave's last
-            // reservation precedes its "done")
-            int res;
+            // reservation precedes its "done", and `done` is read first)
             for (;;) {
-                const int done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                res = __hip_atomic_load(s_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (res >= start + CL || done >= RT_WAVES) break;
                 // a poll is an instruction the counting waves of this SIMD do not issue: far from its turn a wave sleeps longer
                 if (start + CL - res > 2 * CL) __builtin_amdgcn_s_sleep(8);
                 else __builtin_amdgcn_s_sleep(1);
+                done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                res = __hip_atomic_load(s_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             res = __builtin_amdgcn_readfirstlane(res);
             nh = (res < lcap ? res : lcap) - start;
             if (nh <= 0) break;
             nh = nh < CL ? nh : CL;
 #endif
+#if MP_LEAN_GREEDY
             // reserved is not written: the reserving wave stores its entries right behind its atomic
             for (;;) {
                 const int32_t w = lane < nh ? __hip_atomic_load(s_ids + start + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
@@ -1807,12 +1812,40 @@ __device__ __forceinline__ void lsh_head_body(
                 const int32_t* e = s_ids + start + j;
                 return u32x4{(uint32_t)e[0], (uint32_t)e[1], (uint32_t)e[2], (uint32_t)e[3]};
             };
-            if (SHORT_L < AH_SLICE && clog > 0)
-                attn_head_fold_lean<ADL, SHORT_L>(st_own, kv_l, kn_l, qv_l, s_rn[1], nh, M, ha.K, L, 0, 1, slice, idmask,
-                                                  idbits, pay, stamp);
-            else
-                attn_head_fold_lean<ADL, AH_SLICE>(st_own, kv_l, kn_l, qv_l, s_rn[1], nh, M, ha.K, L, 0, 1, slice, idmask,
-                                                   idbits, pay, stamp);
+            attn_head_fold_lean<ADL, SHORT_L>(st_own, kv_l, kn_l, qv_l, s_rn[1], nh, M, ha.K, L, 0, 1, slice, idmask, idbits, pay,
+                                              stamp);
+#else
+            // reserved is not written: the reserving wave stores its entries right behind its atomic.  The gather's own
+            // read of the slice is the check -- row group r of the step reads entries r UPS .. r UPS + UPS - 1 (attn_head_fold_lean);
+            // an entry of the slice that still says "not written" (-1) means: read again.  The fold gets the registers.
+            constexpr int LPRc = ADL / 8, RPLc = 64 / LPRc;
+            u32x4 pre0 = {0u, 0u, 0u, 0u}, pre1 = {0u, 0u, 0u, 0u};      // (two named registers: an array here went to scratch)
+            auto read_slice = [&](auto ups_tag) {
+                constexpr int UPSc = decltype(ups_tag)::value;
+                const int e0 = (lane / LPRc) * UPSc;
+                for (;;) {
+                    bool missing = false;
+                    pre0 = *reinterpret_cast<const volatile u32x4*>(s_ids + start + e0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) missing = missing || (e0 + e < nh && pre0[e] == 0xffffffffu);
+                    if constexpr (UPSc > 4) {
+                        pre1 = *reinterpret_cast<const volatile u32x4*>(s_ids + start + e0 + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) missing = missing || (e0 + 4 + e < nh && pre1[e] == 0xffffffffu);
+                    }
+                    if (__ballot(missing) == 0ull) break;            // wave-uniform
+                }
+            };
+            constexpr int UPS_S = SHORT_L / RPLc;                        // entries a row group reads: 4 (or 8: two registers)
+            const int e0s = (lane / LPRc) * UPS_S;
+            auto slice = [&](int j) {                                    // (the fold asks for entries e0 and, UPS = 8, e0 + 4)
+                if constexpr (UPS_S > 4) return (j - e0s) >= 4 ? pre1 : pre0;
+                else return pre0;
+            };
+            read_slice(std::integral_constant<int, UPS_S>{});
+            attn_head_fold_lean<ADL, SHORT_L>(st_own, kv_l, kn_l, qv_l, s_rn[1], nh, M, ha.K, L, 0, 1, slice, idmask, idbits, pay,
+                                              stamp);
+#endif
             folded += nh;
         }
         if (WIN && aa.win_kv != nullptr) {      // the static window: dense slices rank, rank + R, ... over the waves
@@ -2018,8 +2051,8 @@ __device__ __forceinline__ void lsh_head_body(
         // the waves folded their own finds above; what is left is the spill list (raw table words in this member's columns
         // of the result row; every wave waited for its stores before it drew its ticket), folded by this one wave
         if (nspill > 0)                                                  // uniform
-            attn_head_fold_lean<ADD, AH_SLICE>(st, kv_g, kn_g, qv, s_rn[1], nspill, M, ha.K, L, 0, 1, ids_hbm,
-                                               idmask, idbits, pay, stamp);
+            attn_head_fold_lean<ADD, (ADD == 128 ? 16 : AH_SLICE)>(st, kv_g, kn_g, qv, s_rn[1], nspill, M, ha.K, L, 0, 1, ids_hbm,
+                                                                   idmask, idbits, pay, stamp);
     } else
     if (short_list)
         attn_head_fold<ADD, RT_WAVES, false, SHORT>(st, kv_g, kn_g, qv, s_rn[1], total, M, ha.K, L, 0, 1, ids_lds,

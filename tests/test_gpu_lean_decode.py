@@ -146,9 +146,9 @@ def test_lean_decode_unusual_shapes(mp, B, H, Hkv, D, K, L, n, M):
     server.attn_server.check()
 
 
-def test_lean_decode_long_lists_take_the_ordered_path(mp):
-    """K = 1 selects almost every token: a member's list is longer than the LDS stage, the LEAN kernel then emits the
-    ordered rows through HBM exactly as the by-products-on kernel does (bitmap B holds the same set)."""
+def test_lean_decode_long_lists_go_through_the_spill_list(mp):
+    """K = 1 selects almost every token: a member's list is longer than the 4 096-entry LDS stage; what does not fit goes
+    to the spill list in HBM, which the wave that draws the last ticket folds."""
     B, H, Hkv, n, M, D, K, L = 1, 2, 1, 40000, 40960, 128, 1, 40
     server, _ = _fused_server(mp, B, H, Hkv, n, M, D, K, L, 99)
     q = torch.randn((B, H, 1, D), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)).to(torch.bfloat16)
@@ -158,7 +158,8 @@ def test_lean_decode_long_lists_take_the_ordered_path(mp):
     server.by_products = False
     o2, l2 = server.decode(q, 0)
     assert torch.equal(server.nnz, z1)
-    assert torch.equal(o1, o2) and torch.equal(l1, l2)        # the ordered path: the same summation order, the same bits
+    assert _ulp_close(o1.float().cpu().numpy(), o2.float().cpu().numpy())
+    assert np.allclose(l1.cpu().numpy(), l2.cpu().numpy(), atol=1e-3)
 
 
 @pytest.mark.parametrize("B,H,Hkv", [(1, 32, 8), (1, 8, 2), (8, 32, 8)])
