@@ -2748,6 +2748,8 @@ hipError_t launch_lsh_decode(const int32_t* bounds, const int32_t* table, const 
     if (quad_mode >= 1 && clog == 0 && D == 128 && BH % 32 == 0 && sxq && Wt != nullptr && xw != nullptr && xseq != nullptr &&
         !codes_given && 2 * ((K * L + 63) / 64) <= 64 && 2 * ((K * L + 63) / 64) <= xwords &&
         2 * ((K * L + 63) / 64) * 32 <= KLpad && words % 2 == 0) {     // (the rows' LDS copies are read 16 bytes at a time)
+        if (lean_ran) *lean_ran = false;                            // (the quad hash exists in the by-products-on form only)
+        lds = decode_lds_bytes(range_len, L, D) + (want_pay ? (size_t)range_len * 2 + 16 : 0);
         aa.xw = xw;
         aa.xseq = xseq;
         aa.xmode = quad_mode == 2 ? 2 : 1;                          // 2: nobody publishes (test: every head falls back to hashing alone)
