@@ -985,6 +985,8 @@ def main():
             key = "lsh_decode_bytes_per_launch" if fused else "two_launch_bytes_per_layer"
             if args.data != "randn":
                 key += "_" + args.data              # PMC passes exist per key distribution (or not at all)
+            elif fused and args.by_products:
+                key += "_byproducts"                # ... and per form of the launch
             roof["traffic"] = (tj.get(key) or {}).get(args.config)
             if roof["traffic"] is not None:
                 roof["traffic_source"] = "not measured in this run: rocprofv3 PMC passes of " + str(tj.get("source", "profiles/"))

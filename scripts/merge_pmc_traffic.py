@@ -8,7 +8,7 @@ import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out")
-out = {"lsh_decode_bytes_per_launch": {}, "lsh_decode_bytes_per_launch_clustered": {}}
+out = {"lsh_decode_bytes_per_launch": {}, "lsh_decode_bytes_per_launch_clustered": {}, "lsh_decode_bytes_per_launch_byproducts": {}}
 
 
 def avg(path):
@@ -20,7 +20,8 @@ def avg(path):
 
 
 for cfg in ("cfg1", "cfg2", "cfg3", "cfg4"):
-    for suffix, key in (("", "lsh_decode_bytes_per_launch"), ("_clustered", "lsh_decode_bytes_per_launch_clustered")):
+    for suffix, key in (("", "lsh_decode_bytes_per_launch"), ("_clustered", "lsh_decode_bytes_per_launch_clustered"),
+                        ("_byproducts", "lsh_decode_bytes_per_launch_byproducts")):      # bench.py --by-products 1
         f = os.path.join(src, f"{tag}_pmc_FETCH_SIZE_{cfg}{suffix}.md")
         w = os.path.join(src, f"{tag}_pmc_WRITE_SIZE_{cfg}{suffix}.md")
         b = os.path.join(src, f"{tag}_bench_{cfg}{suffix}.json")
@@ -42,6 +43,6 @@ for cfg in ("cfg1", "cfg2", "cfg3", "cfg4"):
                 o.write(f"; algorithmic bytes (SURVEY 8d) {alg / 1e6:.2f} MB -> x{total / alg:.2f}")
             o.write("\n")
         print(cfg + suffix, f"{total / 1e6:.2f} MB", f"x{total / alg:.2f}" if alg else "")
-out = {"source": f"profiles/{tag}_pmc_hbm_traffic_cfg{{1,2,3,4}}[_clustered].md (FETCH_SIZE x 2 + WRITE_SIZE, separate "
+out = {"source": f"profiles/{tag}_pmc_hbm_traffic_cfg{{1,2,3,4}}[_clustered|_byproducts].md (FETCH_SIZE x 2 + WRITE_SIZE, separate "
                  "rocprofv3 --pmc passes, KB = 1024 B)", **out}
 json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"), "w"), indent=1)

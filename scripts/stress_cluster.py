@@ -3,7 +3,10 @@ shape: a hipGraph of 30 back-to-back launches of ONE layer is replayed `reps` ti
 every replay's output, LSE and nnz must equal the eager result of that query bit for bit, and the device flags
 (mp_attn_check) must stay quiet.  With `contend` a second stream keeps the CUs busy with large GEMMs meanwhile, so
 that members of a cluster are not resident together (the bounded waits time out and the fallbacks run).
-usage: python scripts/stress_cluster.py [cfg1] [reps] [contend]"""
+`lean` (round 6): the replayed launches are mp_decode_sparse_layer_ex(MP_DECODE_NO_BYPRODUCTS) -- the claim list's spins and
+the last wave's hand-off under replay and contention; counts bit for bit, outputs / LSE within the parity bar (the order in
+which tokens enter the softmax is not reproducible there).
+usage: python scripts/stress_cluster.py [cfg1] [reps] [contend] [lean]"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +16,8 @@ from bench import CONFIGS
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg1"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-contend = len(sys.argv) > 3 and sys.argv[3] == "contend"
+contend = "contend" in sys.argv[3:]
+lean = "lean" in sys.argv[3:]
 cfg = CONFIGS[name]
 B, H, Hkv, D, M, K, Lt, P = (cfg[k] for k in ("B", "H", "Hkv", "D", "M", "K", "L", "P"))
 dev = torch.device("cuda:0")
@@ -29,6 +33,7 @@ ref = []
 for i in range(NQ):
     o, l = server.decode(qs[i], 0)
     ref.append((o.clone(), l.clone(), server.nnz.clone()))
+server.by_products = not lean
 q_static = qs[0].clone()
 side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
@@ -50,9 +55,14 @@ for r in range(reps):
                 xb = xa @ xa
     graph.replay()
     torch.cuda.synchronize()
-    if not (torch.equal(o_g, ref[i][0]) and torch.equal(l_g, ref[i][1]) and torch.equal(server.nnz, ref[i][2])):
+    if lean:
+        ok = torch.equal(server.nnz, ref[i][2]) and \
+            torch.allclose(o_g.float(), ref[i][0].float(), rtol=2 ** -7, atol=2e-4) and torch.allclose(l_g, ref[i][1], atol=1e-3)
+    else:
+        ok = torch.equal(o_g, ref[i][0]) and torch.equal(l_g, ref[i][1]) and torch.equal(server.nnz, ref[i][2])
+    if not ok:
         bad += 1
 server.attn_server.check()
-print(f"{name}: R = {server.lsh_retriever.R}; {reps} replays x 30 launches{' against concurrent GEMMs' if contend else ''}, "
+print(f"{name}{' (lean launches)' if lean else ''}: R = {server.lsh_retriever.R}; {reps} replays x 30 launches{' against concurrent GEMMs' if contend else ''}, "
       f"{bad} replays differed from the eager result; device flags quiet")
 sys.exit(1 if bad else 0)

@@ -23,8 +23,9 @@ def test_traffic_json_is_what_the_pmc_passes_say():
     tag = _latest_tag()
     traffic = json.load(open(os.path.join(PROF, "hbm_traffic_latest.json")))
     seen = 0
-    for key, suffix in (("lsh_decode_bytes_per_launch", ""), ("lsh_decode_bytes_per_launch_clustered", "_clustered")):
-        for cfg, total in traffic[key].items():
+    for key, suffix in (("lsh_decode_bytes_per_launch", ""), ("lsh_decode_bytes_per_launch_clustered", "_clustered"),
+                        ("lsh_decode_bytes_per_launch_byproducts", "_byproducts")):
+        for cfg, total in traffic.get(key, {}).items():
             text = open(os.path.join(PROF, f"{tag}_pmc_hbm_traffic_{cfg}{suffix}.md")).read()
             kb = {}
             for m in re.finditer(r"\|\s*void mp::lsh_decode_kernel.*\|\s*(FETCH_SIZE|WRITE_SIZE)\s*\|\s*\d+\s*\|\s*([\d.]+)\s*\|", text):
@@ -56,7 +57,7 @@ def test_bench_lines_close(path):
     assert c["gpu_matches"]["nnz_equal"] is True and c["gpu_matches"]["max_abs_out_diff"] <= 1e-2
     if "cfg0" not in path:
         cfg = re.search(r"(cfg\d)", path).group(1)
-        key = "lsh_decode_bytes_per_launch" + ("_clustered" if "clustered" in path else "")
+        key = "lsh_decode_bytes_per_launch" + ("_clustered" if "clustered" in path else "_byproducts" if "byproducts" in path else "")
         assert r["traffic"] is not None and r["traffic"] >= r["bytes_per_launch"]      # never below the algorithmic bytes
         assert "not measured in this run" in r["traffic_source"]
         # the rocprofv3 average of the same command agrees with the HIP-event time of the line
