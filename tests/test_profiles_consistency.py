@@ -74,13 +74,24 @@ def test_default_line_carries_the_other_configurations():
     path = os.path.join(PROF, f"{_latest_tag()}_bench_driver_style.json")
     d = json.loads(open(path).read().strip().splitlines()[-1])
     assert "cfg1" in d["config"]["workload"] and d["n_gpus"] == 1 and "failed_legs" not in d
-    legs = d["legs"]
-    assert set(legs) == {"cfg2", "cfg4_share"}
+    legs = dict(d["legs"])
+    # round 6: cfg 3's share and the end-to-end step with its split ride in the same line
+    assert set(legs) == {"cfg2", "cfg3_share", "cfg4_share", "e2e"}
+    e2e = legs.pop("e2e")
+    for name in ("cfg1", "cfg2"):
+        leg = e2e[name]
+        batch = 1 if name == "cfg1" else 8
+        assert abs(leg["tokens_per_s"] - batch / (leg["ms_per_step"] * 1e-3)) <= 1e-6 * leg["tokens_per_s"]
+        split = leg["split_ms"]
+        assert set(split) == {"sparse_attention", "dense_attention", "projections_mlp", "norms_rope_residual", "embed_lm_head"}
+        # the parts are re-captured one kind at a time: they add up to the step or less (what the step's own graph overlaps
+        # or adds between them), never to more than a few per cent above it
+        assert 0.7 * leg["ms_per_step"] <= sum(split.values()) <= 1.05 * leg["ms_per_step"], (name, split)
     for name, leg in legs.items():
         r = leg["roofline"]
         assert abs(r["achieved"] - r["bytes_per_launch"] / r["avg_launch_us"] / 1e3) <= 1e-6 * r["achieved"], name
         assert abs(r["frac"] - r["achieved"] / 8000.0) <= 1e-9, name
-        assert leg["tokens_per_s"] > 0 and abs(leg["us_per_layer"] * 1e-3 * (30 if name == "cfg2" else 75) - leg["ms_per_step"]) < 1e-6
+        assert leg["tokens_per_s"] > 0 and abs(leg["us_per_layer"] * 1e-3 * (75 if name == "cfg4_share" else 30) - leg["ms_per_step"]) < 1e-6
         g = leg["cpu_baseline"]["gpu_matches"]
         assert g["nnz_equal"] is True and g["max_abs_out_diff"] <= 1e-2, name
         f = leg["hbm_bytes_per_layer"]
