@@ -265,7 +265,8 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const uint16_t* __restrict__ Wt,      // [KLpad][D]
     const float* __restrict__ wnorm,      // [KLpad]
     int64_t n, int K, int L, int tables_per_wg, int tiles_per_wg, int chunk_tiles, int wgs_x, int chunks,
-    int heads, int16_t* __restrict__ codes,   // [heads][L][n]
+    int heads, int groups,                    // persistent: `groups` groups of wgs_x workgroups per XCD walk the units
+    int16_t* __restrict__ codes,              // [heads][L][n]
     unsigned long long* __restrict__ stamp) {
     constexpr int KSTEPS = D / 16;
     constexpr int STRIDE = D + 8;
@@ -291,19 +292,19 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     // xcd for row chunk 8q + xcd), so the rows come from HBM once and from that XCD's L2 wgs_x - 1
     // times; with column-fastest numbering they landed on wgs_x different XCDs and HBM served every
     // copy (PMC: 1.29 GB read per layer at cfg 1 for 0.2 GB of keys).
+    // Round 6: the workgroups are PERSISTENT (grid = 8 XCDs x groups x wgs_x <= two per CU): a workgroup keeps its plane span
+    // -- 128 VGPRs of fragments per wave, loaded once -- and walks the units (kv head, row chunk) group, group + groups, ...
+    // of its XCD; the first two row tiles of the next unit are requested before the current one is flushed.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int colgrp = slot % wgs_x;
-    const int64_t unit = (int64_t)(slot / wgs_x) * 8 + xcd;   // (kv head, row chunk), chunk fastest
-    if (unit >= (int64_t)chunks * heads) return;
-    const int head = (int)(unit / chunks), chunk = (int)(unit % chunks);
+    const int colgrp = slot % wgs_x, group = slot / wgs_x;
+    const int64_t units = (int64_t)chunks * heads;
+    const int64_t unit_step = (int64_t)groups * 8;
+    int64_t unit = (int64_t)group * 8 + xcd;                  // (kv head, row chunk), chunk fastest
+    if (unit >= units) return;
     const int table0 = colgrp * tables_per_wg;
     const int col0 = table0 * K, KL = K * L;   // col0 is NOT tile aligned: Wt is row-per-plane, any start works
-    x += (int64_t)head * head_stride;
-    codes += (int64_t)head * L * n;
-    const int64_t row_base = (int64_t)chunk * CROWS;
-    int nt = (int)((n - row_base + SH_ROWS - 1) / SH_ROWS);
-    if (nt > chunk_tiles) nt = chunk_tiles;
-    if (tid == 0) s_qn = 0;
+    const uint16_t* xh = x + (int64_t)(unit / chunks) * head_stride;          // the unit whose tiles are being LOADED
+    int64_t row_base = (int64_t)(unit % chunks) * CROWS;
     MP_STAMP(stamp, 40);
 
     // column tile wave * SETS + st of the workgroup's span: planes col0 + 32 (wave SETS + st) + (lane & 31).  Tiles past
@@ -348,13 +349,16 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     // s_waitcnt vmcnt(0) at the join, which would serialise the prefetch.  Rows past n compute on duplicates
     // whose results are never stored.  Thread tid takes chunk tid % CPR of rows tid / CPR + q * (nthr / CPR).
     const int64_t last_row = n - 1;
-    const uint16_t* xcol = x + (tid % CPR) * 8;
     auto tile_load = [&](int t, u32x4 (&sreg)[QN]) {
+        // a uniform base (the unit's first row) + a 32-bit element offset per lane: a unit is <= 1 024 rows of <= 512 elements
+        const uint16_t* ubase = xh + row_base * row_stride;
+        const int lim = (int)(last_row - row_base);                       // last row of the head, relative to the unit
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
-            int64_t gr = row_base + (int64_t)t * SH_ROWS + (tid / CPR) + q * (NTHR / CPR);
-            gr = gr < last_row ? gr : last_row;
-            sreg[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xcol + gr * row_stride));
+            int r = t * SH_ROWS + (tid / CPR) + q * (NTHR / CPR);
+            r = r < lim ? r : lim;
+            const uint32_t off = (uint32_t)r * (uint32_t)row_stride + (uint32_t)((tid % CPR) * 8);
+            sreg[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ubase + off));
         }
     };
     auto tile_store = [&](int buf, const u32x4 (&sreg)[QN]) {
@@ -501,8 +505,15 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     u32x4 s0[QN], s1[QN];
     tile_load(0, s0);
     tile_load(1, s1);
+    for (;;) {
+    const uint16_t* const xcur = xh;                      // the unit being computed and flushed in this iteration
+    const int64_t row_base_cur = row_base;
+    int16_t* const codes_cur = codes + (int64_t)(unit / chunks) * L * n;
+    int nt = (int)((n - row_base_cur + SH_ROWS - 1) / SH_ROWS);
+    if (nt > chunk_tiles) nt = chunk_tiles;
+    if (tid == 0) s_qn = 0;                               // (everybody is past the last unit's exact pass: the barrier in front of its cut)
     tile_store(0, s0);
-    __syncthreads();
+    __syncthreads();                                      // ... and past its cut, which read the sign matrix
     MP_STAMP(stamp, 41);
 #if MP_SK_WHATIF == 3              // timing experiment only (racy): no barrier between the tiles
 #define MP_SK_TILE_BARRIER() do { } while (0)
@@ -524,6 +535,15 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
 #undef MP_SK_PHASE
     __syncthreads();
     MP_STAMP(stamp, 42);
+    // the next unit's first two row tiles travel while this one is flushed
+    unit += unit_step;
+    const bool more = unit < units;                       // uniform
+    if (more) {
+        xh = x + (int64_t)(unit / chunks) * head_stride;
+        row_base = (int64_t)(unit % chunks) * CROWS;
+        tile_load(0, s0);
+        tile_load(1, s1);
+    }
 
     // exact pass over the queued candidates: one 16-lane group per candidate
     const int nq = min(s_qn, SK_QCAP);
@@ -543,7 +563,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
 #endif
         double part = 0.0;
         for (int d8 = l16; d8 < CPR; d8 += 16) {
-            const u32x4 a = *reinterpret_cast<const u32x4*>(x + (row_base + crow) * row_stride + d8 * 8);
+            const u32x4 a = *reinterpret_cast<const u32x4*>(xcur + (row_base_cur + crow) * row_stride + d8 * 8);
             const u32x4 w = *reinterpret_cast<const u32x4*>(Wt + (int64_t)(col0 + coff) * D + d8 * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -564,10 +584,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
                       // its share of the bit matrix exactly -- slow, correct
         for (int p = tid; p < tables_per_wg * K * (nt * SH_ROWS); p += nthr) {
             const int coff = p / (nt * SH_ROWS), crow = p % (nt * SH_ROWS);
-            if (col0 + coff >= KL || row_base + crow >= n) continue;
+            if (col0 + coff >= KL || row_base_cur + crow >= n) continue;
             double ex = 0.0;
             for (int d = 0; d < D; ++d)
-                ex += (double)bf16_bits_to_f32(x[(row_base + crow) * row_stride + d]) *
+                ex += (double)bf16_bits_to_f32(xcur[(row_base_cur + crow) * row_stride + d]) *
                       (double)bf16_bits_to_f32(Wt[(int64_t)(col0 + coff) * D + d]);
             uint32_t* wd = &s_rowbits[crow * BW + (coff >> 5)];
             const uint32_t m = 1u << (coff & 31);
@@ -577,38 +597,39 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     __syncthreads();
     MP_STAMP(stamp, 43);
 
-    // long contiguous stores: row l of codes[L][n], tokens row_base .. row_base + ntok, as 8-byte
-    // groups of four codes aligned on the DESTINATION address (n is arbitrary, so the alignment of
-    // a row start differs from table to table); ragged ends go out as scalars.
-    const int ntok = (int)((n - row_base < (int64_t)nt * SH_ROWS) ? (n - row_base) : (int64_t)nt * SH_ROWS);
-    // the K-bit code of (row j, table tb) is cut out of the row's bits here, once per code, instead of
-    // once per tile into an intermediate block of codes
-    const int G = CROWS / 4 + 1;
-    for (int tb = wave; tb < tables_per_wg; tb += SK_WAVES) {
-        const int l = table0 + tb;
-        if (l >= L) break;
-        int16_t* dst = codes + (int64_t)l * n + row_base;
-        const int shift = (int)(((8u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 7u)) & 7u) >> 1);
-        const int bp = tb * K, bw = bp >> 5, sh = bp & 31;
-        auto code_at = [&](int j) -> uint32_t {
-            const uint32_t* rw = s_rowbits + j * BW + bw;
-            const unsigned long long two = (unsigned long long)rw[0] | ((unsigned long long)rw[1] << 32);
-            return (uint32_t)(two >> sh) & kmask;
-        };
-        for (int g = lane; g < G; g += WAVE) {
-            const int j0 = shift + 4 * (g - 1);
-            const int lo = j0 < 0 ? 0 : j0, hi = (j0 + 4 < ntok) ? j0 + 4 : ntok;
-            if (hi - lo == 4) {
-                uint2 v;
-                v.x = code_at(lo) | (code_at(lo + 1) << 16);
-                v.y = code_at(lo + 2) | (code_at(lo + 3) << 16);
-                *reinterpret_cast<uint2*>(dst + lo) = v;
-            } else {
-                for (int j = lo; j < hi; ++j) dst[j] = (int16_t)code_at(j);
+    // Cut the K-bit codes out of the sign matrix: a lane owns a ROW (its words sit 17 apart: no bank conflict), walks the
+    // workgroup's tables with a 64-bit window over the row's bits -- position and word index are uniform, so the window's
+    // bookkeeping is scalar -- and stores one code per table; for a table, the wave's 64 lanes write 128 contiguous bytes
+    // of codes[l][.].  (Through round 5 a lane cut four CONSECUTIVE rows of one table to store 8 bytes: lanes 4 x 17 words
+    // apart, a 4- to 8-way bank conflict on every read, 8.5 of a workgroup's 57 us.)
+    const int ntok = (int)((n - row_base_cur < (int64_t)nt * SH_ROWS) ? (n - row_base_cur) : (int64_t)nt * SH_ROWS);
+    const int tables_here = (L - table0 < tables_per_wg) ? L - table0 : tables_per_wg;
+    for (int r0 = wave * WAVE; r0 < ntok; r0 += SK_WAVES * WAVE) {
+        const int j = r0 + lane;
+        const bool live = j < ntok;
+        const uint32_t* rw = s_rowbits + (live ? j : 0) * BW;
+        uint32_t lo = rw[0], hi = rw[1];
+        int pos = 0, widx = 2;                                            // uniform
+        // the store: a descriptor over the table's ntok codes of this unit (uniform) + the lane's 32-bit offset; a lane past
+        // the unit's rows is out of range and the hardware drops its store: no branch
+        int16_t* tbase = codes_cur + (int64_t)table0 * n + row_base_cur;
+        for (int tb = 0; tb < tables_here; ++tb) {
+            const uint32_t c = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)pos) & kmask;
+            __builtin_amdgcn_raw_buffer_store_b16((short)c, __builtin_amdgcn_make_buffer_rsrc(tbase, 0, ntok * 2, 0x00020000),
+                                                  j * 2, 0, 0);
+            tbase += n;
+            pos += K;
+            if (pos >= 32) {
+                pos -= 32;
+                lo = hi;
+                hi = rw[widx < BW ? widx : BW - 1];                       // (the last window may ask one word past the row)
+                ++widx;
             }
         }
     }
     MP_STAMP(stamp, 44);
+    if (!more) break;
+    }
 }
 
 // ---------------------------------------------------------------- host launchers
@@ -686,18 +707,18 @@ static void simhash_keys_geometry(int K, int sets, int& tables_per_wg, int& tile
     tiles_per_wg = (tp * K + 31) / 32;
 }
 
-// Tiles per workgroup.  Workgroups are not persistent, so the launch runs in ceil(wgs / slots)
-// rounds of (per-tile time * tiles + fixed prologue/flush time): pick the chunk that minimises
-// that product (the constants are the measured 1.9 us per tile and 7 us per workgroup; only their
-// ratio matters).  The chunk's sign matrix [32 * tiles][9] words has to fit in LDS next to a second
-// workgroup.
-static int keys_chunk_tiles(int64_t n, int64_t wgs_x, int tables_per_wg, int sets) {
+// Tiles per unit (row chunk) and groups per XCD.  The workgroups are persistent: 8 x groups x wgs_x of them (two per CU at
+// most) walk ceil(units / (8 groups)) units each; pick the chunk that minimises rounds x (per-tile time x tiles + the flush's
+// fixed cost) -- only the ratio of the two constants matters.  The chunk's sign matrix [32 x tiles][17] words has to fit in
+// LDS next to a second workgroup.
+static void keys_chunk_tiles(int64_t n, int wgs_x, int heads, int sets, int& chunk_tiles, int& groups) {
     int cus = 256;
     hipDeviceProp_t prop;
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
         cus = prop.multiProcessorCount;
-    const int64_t slots = 2 * (int64_t)cus;
+    int g = (2 * cus / 8) / wgs_x;                        // groups per XCD
+    if (g < 1) g = 1;
     const int64_t tiles = (n + SH_ROWS - 1) / SH_ROWS;
     int best = 1;
     double best_cost = 1e300;
@@ -705,11 +726,15 @@ static int keys_chunk_tiles(int64_t n, int64_t wgs_x, int tables_per_wg, int set
         // the chunk's sign matrix next to a second workgroup's: 52 KB of the CU's 160 (the static stage, queue and norms
         // of a workgroup are ~24 KB at head_dim 128)
         if ((size_t)ch * SH_ROWS * (SK_WAVES * sets + 1) * sizeof(uint32_t) > 52u * 1024u) break;
-        const int64_t wgs = ((tiles + ch - 1) / ch) * wgs_x;
-        const double cost = (double)((wgs + slots - 1) / slots) * (1.9 * ch + 7.0);
+        const int64_t units = ((tiles + ch - 1) / ch) * heads;
+        const int64_t rounds = (units + 8 * (int64_t)g - 1) / (8 * (int64_t)g);
+        const double cost = (double)rounds * (1.9 * ch + 4.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = ch; }
     }
-    return best;
+    chunk_tiles = best;
+    const int64_t units = ((tiles + best - 1) / best) * heads;
+    const int64_t need = (units + 7) / 8;                 // groups per XCD that find a unit at all
+    groups = (int)(need < g ? need : g);
 }
 
 // keys [heads][n][D] -> codes int16 [heads][L][n]; all kv heads in ONE launch so that the tail
@@ -723,16 +748,15 @@ hipError_t launch_simhash_keys_strided(const uint16_t* keys, int64_t head_stride
     const int wgs_x = (L + tp - 1) / tp;
     if (heads < 1 || heads > 65535) return hipErrorInvalidValue;
     static thread_local int64_t memo_n = -1;
-    static thread_local int memo_x = 0, memo_tp = 0, memo_ch = 0;
-    if (memo_n != n || memo_x != wgs_x * heads || memo_tp != tp) {
-        memo_ch = keys_chunk_tiles(n, (int64_t)wgs_x * heads, tp, sets);
-        memo_n = n; memo_x = wgs_x * heads; memo_tp = tp;
+    static thread_local int memo_x = 0, memo_h = 0, memo_ch = 0, memo_g = 0;
+    if (memo_n != n || memo_x != wgs_x || memo_h != heads) {
+        keys_chunk_tiles(n, wgs_x, heads, sets, memo_ch, memo_g);
+        memo_n = n; memo_x = wgs_x; memo_h = heads;
     }
-    const int ch = memo_ch;
+    const int ch = memo_ch, groups = memo_g;
     const int64_t crows = (int64_t)ch * SH_ROWS;
     const int64_t chunks = (n + crows - 1) / crows;
-    const int64_t units = chunks * heads;
-    const int64_t blocks = ((units + 7) / 8) * wgs_x * 8;
+    const int64_t blocks = (int64_t)groups * wgs_x * 8;
     if (chunks > INT32_MAX || blocks > INT32_MAX) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks);
     dim3 block(64 * SK_WAVES);
@@ -741,7 +765,7 @@ hipError_t launch_simhash_keys_strided(const uint16_t* keys, int64_t head_stride
     if (D == DD) {                                                                                  \
         hipLaunchKernelGGL((simhash_keys_kernel<DD>), grid, block, lds, st, keys, head_stride,      \
                            row_stride, Wt, wnorm, n, K, L, tp, tiles, ch, wgs_x, (int)chunks, heads, \
-                           codes, g_stamp);                                                         \
+                           groups, codes, g_stamp);                                                         \
         return hipGetLastError();                                                                   \
     }
     MP_SK_CASE(128)
