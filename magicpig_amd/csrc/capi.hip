@@ -1,5 +1,6 @@
 // capi.hip -- the C ABI declared in include/magicpig_hip.h: handle state in HBM + launches.
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -122,6 +123,11 @@ struct DebugOptions {
     std::atomic<int> host_spec_hits{0};      // counter: attention calls served by the launch the retrieve had issued
     std::atomic<int> host_spec_misses{0};    // counter: such a launch existed but the call's arguments were not what it had assumed
     std::atomic<int> host_flag_timeouts{0};  // counter: a completion word did not arrive within ~5 ms (the stream was synchronised instead)
+    // where a MP_MEM_HOST batch_retrieve spends its time, ns summed over the calls since the last reset (scripts/host_mode_times.py):
+    // up to the last launch, waiting for its completion word, copying counts and rows out + bookkeeping
+    std::atomic<int> host_ret_calls{0}, host_ret_ns_enqueue{0}, host_ret_ns_wait{0}, host_ret_ns_copy{0};
+    std::atomic<int> host_copy_prefetch{48}; // the copy of the handed-out rows asks for the NEXT row while it copies one: the whole row up to
+                                             // this many 64-byte lines, the first 8 lines of a longer one; 0 = off (A/B: R6-2)
 };
 static DebugOptions g_opt;
 
@@ -150,6 +156,11 @@ static std::atomic<int>* debug_option(const char* name) {
     if (!strcmp(name, "host_spec_hits")) return &g_opt.host_spec_hits;
     if (!strcmp(name, "host_spec_misses")) return &g_opt.host_spec_misses;
     if (!strcmp(name, "host_flag_timeouts")) return &g_opt.host_flag_timeouts;
+    if (!strcmp(name, "host_copy_prefetch")) return &g_opt.host_copy_prefetch;
+    if (!strcmp(name, "host_ret_calls")) return &g_opt.host_ret_calls;
+    if (!strcmp(name, "host_ret_ns_enqueue")) return &g_opt.host_ret_ns_enqueue;
+    if (!strcmp(name, "host_ret_ns_wait")) return &g_opt.host_ret_ns_wait;
+    if (!strcmp(name, "host_ret_ns_copy")) return &g_opt.host_ret_ns_copy;
     return nullptr;
 }
 
@@ -393,7 +404,7 @@ struct mp_lsh {
         bool launched = false;             // the last batch_retrieve issued the attention launch
         int layer = -1;
         unsigned long long attn_seq = 0;   // attn->host_seq when it did: another call on the store since then owns its pinned block
-        std::vector<unsigned char> q_snap; // the query bytes as they were when the launch was issued
+        size_t q_bytes = 0;                // bytes of the query snapshot in the store's pinned block (AttnHostLayout::o_qsnap)
         bool prepared = false;             // the query's copy + norms are enqueued (in front of the retrieve kernel)
         unsigned int done_flag = 0;        // the store's completion word behind the launch (0: synchronise `stream` instead)
         hipStream_t stream = nullptr;
@@ -906,7 +917,7 @@ int mp_lsh_build(mp_lsh_t* h, int layer_id, int request_id, const int16_t* codes
 // the store's pinned block in host-buffer mode: (q | qn | nnz | offsets) up, (out | mve) down, and the ||q|| a
 // speculative launch computed
 struct AttnHostLayout {
-    size_t qbytes, o_q, o_qn, o_nnz, o_offs, o_out, o_mve, o_sqn, o_end;
+    size_t qbytes, o_q, o_qn, o_nnz, o_offs, o_out, o_mve, o_sqn, o_qsnap, o_end;
 };
 static AttnHostLayout attn_host_layout(int BH, int D, int query_dtype) {
     AttnHostLayout a;
@@ -917,18 +928,21 @@ static AttnHostLayout attn_host_layout(int BH, int D, int query_dtype) {
     a.o_offs = a.o_nnz + (size_t)BH * 4;
     a.o_out = (a.o_offs + (size_t)(BH + 1) * 4 + 15) & ~(size_t)15;
     a.o_mve = a.o_out + (size_t)BH * D * 2;
-    a.o_sqn = a.o_mve + (size_t)2 * BH * 4;
-    a.o_end = a.o_sqn + (size_t)BH * 4;
+    a.o_sqn = (a.o_mve + (size_t)2 * BH * 4 + 15) & ~(size_t)15;
+    a.o_qsnap = (a.o_sqn + (size_t)BH * 4 + 15) & ~(size_t)15;     // mp_lsh::Spec: the query bytes the launch ahead works on
+    a.o_end = a.o_qsnap + ((a.qbytes + 15) & ~(size_t)15);
     return a;
 }
 static int attn_run(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint16_t* output, float* mve, const void* query,
                     int query_dtype, const float* qn, const int32_t* ind, const int32_t* nnz, hipStream_t st);
 
-// mp_lsh::Spec, in two steps around the retrieve kernel's launch.  prepare (IN FRONT of it): is there a store to launch
-// for, is its caller's query tensor still pinned and mapped?  then snapshot the query bytes and enqueue the kernel that copies
-// the query rows to HBM and computes their norms -- from the retrieve call's return on, nothing enqueued reads the caller's
-// memory.  launch (BEHIND the retrieve kernel and the completion word the call waits for): the attention kernel on the copy,
-// then the store's own completion word.
+// mp_lsh::Spec, in two steps around the retrieve kernel's launch.  prepare (IN FRONT of it, host work only): is there a store
+// to launch for, is its caller's query tensor still pinned and mapped?  then snapshot the query bytes into the STORE's pinned
+// block -- nothing enqueued ever reads the caller's memory.  launch (BEHIND the retrieve kernel and the completion word the call
+// waits for, so none of it is on the retrieve's way): the kernel that brings the snapshot into HBM and computes the rows'
+// norms, the attention kernel on that copy, the store's own completion word.  (Through the first version the copy + norm kernel
+// read the caller's tensor and therefore ran in FRONT of the retrieve kernel: 4 us of kernel and launch gap on the call's path,
+// and the host enqueued two launches before the one it was going to wait for -- EXPERIMENTS.md R6-2.)
 static bool lsh_spec_prepare(mp_lsh_t* h, int layer_id, hipStream_t st) {
     h->spec.launched = h->spec.prepared = false;
     if (g_opt.host_speculate.load() == 0 || h->hr_rows == nullptr) return false;
@@ -960,15 +974,9 @@ static bool lsh_spec_prepare(mp_lsh_t* h, int layer_id, hipStream_t st) {
             return false;
         }
     }
-    const unsigned char* qh = reinterpret_cast<const unsigned char*>(h->spec.q_host);
-    h->spec.q_snap.assign(qh, qh + lo.qbytes);                    // what the launch will have read
-    char* hd = reinterpret_cast<char*>(a->small.hd);
-    char* dp = reinterpret_cast<char*>(a->small.dp);
-    if (launch_row_norm(qdev, h->spec.q_dtype == MP_DTYPE_BF16, BH, a->D, a->spec_qn, reinterpret_cast<float*>(hd + lo.o_sqn),
-                        dp + lo.o_q, st) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
+    (void)st;
+    memcpy(reinterpret_cast<char*>(a->small.hp) + lo.o_qsnap, h->spec.q_host, lo.qbytes);    // what the launch will work on
+    h->spec.q_bytes = lo.qbytes;
     h->spec.prepared = true;
     return true;
 }
@@ -986,10 +994,48 @@ static bool lsh_spec_launch(mp_lsh_t* h, int layer_id, hipStream_t st) {
     const int32_t* keep_lastz = a->lastz;
     const int keep_state = a->score_state, keep_R = a->seg_R;
     const int* keep_seg = a->seg_cnt;
+    // Few heads (B*H <= 64, as in the attention entry): the rows' norms are computed HERE, on the host, while the retrieve kernel
+    // runs -- f32 partial sums in 16 lanes, the device kernel's precision -- and the attention kernel's workgroups read
+    // (q | ||q||) straight from the pinned snapshot: no launch in front of it.  Many heads: one kernel brings the snapshot into
+    // HBM and computes the norms there.
+    const bool direct = BH <= 64;
+    const void* q_src = dp + lo.o_q;
+    const float* qn_src = a->spec_qn;
+    if (direct) {
+        const char* hp = reinterpret_cast<const char*>(a->small.hp);
+        float* sq = reinterpret_cast<float*>(const_cast<char*>(hp) + lo.o_sqn);
+        const int D = a->D;
+        for (int r = 0; r < BH; ++r) {
+            float acc[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (h->spec.q_dtype == MP_DTYPE_BF16) {
+                const uint16_t* x = reinterpret_cast<const uint16_t*>(hp + lo.o_qsnap) + (size_t)r * D;
+                for (int d = 0; d + 16 <= D; d += 16)
+                    for (int j = 0; j < 16; ++j) {
+                        const uint32_t b = (uint32_t)x[d + j] << 16;
+                        float f;
+                        memcpy(&f, &b, 4);
+                        acc[j] += f * f;
+                    }
+            } else {
+                const float* x = reinterpret_cast<const float*>(hp + lo.o_qsnap) + (size_t)r * D;
+                for (int d = 0; d + 16 <= D; d += 16)
+                    for (int j = 0; j < 16; ++j) acc[j] += x[d + j] * x[d + j];
+            }
+            double sum = 0.0;
+            for (int j = 0; j < 16; ++j) sum += (double)acc[j];
+            sq[r] = (float)sqrt(sum);
+        }
+        q_src = hd + lo.o_qsnap;
+        qn_src = reinterpret_cast<const float*>(hd + lo.o_sqn);
+    } else if (launch_row_norm(hd + lo.o_qsnap, h->spec.q_dtype == MP_DTYPE_BF16, BH, a->D, a->spec_qn,
+                               reinterpret_cast<float*>(hd + lo.o_sqn), dp + lo.o_q, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
     std::swap(a->score, a->score_alt);
     std::swap(a->head_mz, a->head_mz_alt);
     const int arc = attn_run(a, layer_id, false, h->spec.K, h->spec.L, reinterpret_cast<uint16_t*>(hd + lo.o_out),
-                             reinterpret_cast<float*>(hd + lo.o_mve), dp + lo.o_q, h->spec.q_dtype, a->spec_qn, h->hr_rows,
+                             reinterpret_cast<float*>(hd + lo.o_mve), q_src, h->spec.q_dtype, qn_src, h->hr_rows,
                              h->hr_nnz, st);
     std::swap(a->score, a->score_alt);
     std::swap(a->head_mz, a->head_mz_alt);
@@ -1067,10 +1113,10 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
             }
         }
         if (res_dev != nullptr) {
+            const auto t_in = std::chrono::steady_clock::now();
             char* hp = reinterpret_cast<char*>(h->small.hp);
             char* hd = reinterpret_cast<char*>(h->small.hd);
             memcpy(hp + o_codes, query, qb);
-            const bool spec = lsh_spec_prepare(h, layer_id, st);            // (mp_lsh::Spec: query copy + norms, in front)
             h->lastq = reinterpret_cast<const int32_t*>(hd + o_codes);      // (get_mask reads them again)
             h->last_layer = layer_id;
             h->last_lean = false;
@@ -1083,11 +1129,15 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
                                              reinterpret_cast<int32_t*>(res_dev), reinterpret_cast<int32_t*>(hd), BH,
                                              h->G, h->L, h->NB, h->M, h->R, h->idbits_dev + layer_id, h->hr_rows, h->hr_nnz,
                                              reinterpret_cast<uint32_t*>(hd + o_sums), st));
-            if (spec) {
+            auto t_enq = std::chrono::steady_clock::now();
+            h->spec.prepared = false;
+            if (g_opt.host_speculate.load() != 0 && h->hr_rows != nullptr && h->spec.attn != nullptr && h->spec.q_host != nullptr) {
                 // the call waits for ITS kernel's completion word; the paired store's attention launch rides behind that word
-                // and is waited for by the attention call (or by whatever synchronises the stream next)
+                // and is waited for by the attention call (or by whatever synchronises the stream next).  Everything of it --
+                // the snapshot of the caller's query too -- happens behind the retrieve kernel's launch, while that runs
                 const unsigned int mine = h->hostflag.arm(st);
-                (void)lsh_spec_launch(h, layer_id, st);
+                if (lsh_spec_prepare(h, layer_id, st)) (void)lsh_spec_launch(h, layer_id, st);
+                t_enq = std::chrono::steady_clock::now();
                 if (!h->hostflag.reached(mine)) {
                     if (mine != 0u) g_opt.host_flag_timeouts.fetch_add(1, std::memory_order_relaxed);
                     MP_HIP_CHECK(hipStreamSynchronize(st));
@@ -1095,12 +1145,32 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
             } else if ((rc = h->hostflag.wait(st, g_opt.host_flag_wait.load() != 0)) != MP_OK) {
                 return rc;
             }
+            const auto t_got = std::chrono::steady_clock::now();
             memcpy(nnz, hp, (size_t)BH * 4);
             if (mirror) {                         // only the first nnz[h] entries of a row mean anything
+                // (the rows sit max_length apart and the GPU has just written them: every row starts cold, and the hardware
+                // prefetcher trains anew on each -- the next row's lines are asked for while this one is copied)
                 const int32_t* rows = reinterpret_cast<const int32_t*>(h->big.hp);
+                auto live = [&](int i) -> int64_t {
+                    const int64_t z = nnz[i];
+                    return z < 0 ? 0 : (z > h->M ? h->M : z);
+                };
+                const int pf_lines = g_opt.host_copy_prefetch.load(std::memory_order_relaxed);
+                auto prefetch_row = [&](int i) {
+#if defined(__x86_64__)
+                    const char* p = reinterpret_cast<const char*>(rows + (size_t)i * h->M);
+                    int64_t bytes = live(i) * 4;
+                    if (bytes > (int64_t)pf_lines * 64) bytes = 8 * 64;      // a long row: its start only, the prefetcher does the rest
+                    for (int64_t o = 0; o < bytes; o += 64) __builtin_prefetch(p + o, 0, 2);
+#else
+                    (void)i;
+#endif
+                };
+                const bool pf = pf_lines > 0;
+                if (pf && BH > 0) prefetch_row(0);
                 for (int i = 0; i < BH; ++i) {
-                    int64_t z = nnz[i];
-                    z = z < 0 ? 0 : (z > h->M ? h->M : z);
+                    if (pf && i + 1 < BH) prefetch_row(i + 1);
+                    const int64_t z = live(i);
                     if (z > 0) memcpy(results + (size_t)i * h->M, rows + (size_t)i * h->M, (size_t)z * 4);
                 }
             }
@@ -1114,6 +1184,16 @@ int mp_lsh_batch_retrieve(mp_lsh_t* h, int layer_id, const int32_t* query, int32
                 h->host_ret.kept = mirror ? reinterpret_cast<const int32_t*>(h->big.hp) : nullptr;
                 h->host_ret.valid = true;
                 g_host_ret_lsh = h;
+            }
+            {
+                const auto t_out = std::chrono::steady_clock::now();
+                auto ns = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+                    return (int)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
+                };
+                g_opt.host_ret_calls.fetch_add(1, std::memory_order_relaxed);
+                g_opt.host_ret_ns_enqueue.fetch_add(ns(t_in, t_enq), std::memory_order_relaxed);
+                g_opt.host_ret_ns_wait.fetch_add(ns(t_enq, t_got), std::memory_order_relaxed);
+                g_opt.host_ret_ns_copy.fetch_add(ns(t_got, t_out), std::memory_order_relaxed);
             }
             return MP_OK;
         }
@@ -1653,16 +1733,18 @@ static int attn_entry(mp_attn_t* h, int layer_id, bool dense, int K, int L, uint
             l->spec.launched = false;                              // (a launch serves one call)
             bool hit = l->spec.attn == h && l->spec.attn_seq == seq_at_entry && l->spec.layer == layer_id && l->spec.K == K &&
                        l->spec.L == L && l->spec.q_dtype == query_dtype && l->spec.q_host == query &&
-                       l->spec.q_snap.size() == qbytes && memcmp(query, l->spec.q_snap.data(), qbytes) == 0;
-            if (hit) {
-                const float* sq = reinterpret_cast<const float*>(hp + o_sqn);        // (written in front of the retrieve kernel)
-                for (int i = 0; i < BH && hit; ++i) hit = fabsf(qn[i] - sq[i]) <= 2e-6f * fabsf(sq[i]);
-            }
+                       l->spec.q_bytes == qbytes && memcmp(query, hp + lo.o_qsnap, qbytes) == 0;
             if (hit && rows_untouched()) {
                 if (!h->hostflag.reached(l->spec.done_flag)) {
                     if (l->spec.done_flag != 0u) g_opt.host_flag_timeouts.fetch_add(1, std::memory_order_relaxed);
                     MP_HIP_CHECK(hipStreamSynchronize(l->spec.stream));
                 }
+                const float* sq = reinterpret_cast<const float*>(hp + o_sqn);        // (the launch's norms: written behind the retrieve)
+                for (int i = 0; i < BH && hit; ++i) hit = fabsf(qn[i] - sq[i]) <= 2e-6f * fabsf(sq[i]);
+            } else {
+                hit = false;
+            }
+            if (hit) {
                 g_opt.host_spec_hits.fetch_add(1, std::memory_order_relaxed);
                 g_opt.host_fast_hits.fetch_add(1, std::memory_order_relaxed);
                 std::swap(h->score, h->score_alt);                 // the launch's logits and (max, Z) are the last call's now

@@ -99,3 +99,5 @@ print("max |host - device| output:", float((a.float() - d_out.float()).abs().max
 import magicpig_amd._lib as _L
 print("attention calls served:", {n: _L.get_option("host_fast_" + n) for n in ("hits", "edited", "unpaired")},
       "by the launch behind the retrieve:", {n: _L.get_option("host_" + n) for n in ("spec_hits", "spec_misses", "flag_timeouts")})
+calls = max(1, _L.get_option("host_ret_calls"))
+print("inside batch_retrieve (host buffers), us per call:", {n: round(_L.get_option("host_ret_ns_" + n) / calls / 1e3, 1) for n in ("enqueue", "wait", "copy")}, f"over {calls} calls")
