@@ -11,9 +11,6 @@
 #pragma once
 #include "common.h"
 
-#ifndef MP_NT_STORES
-#define MP_NT_STORES 0     // `nt` on the by-product stores of the decode kernel (result rows, logits): A/B after R4-15
-#endif
 
 namespace mp {
 
@@ -269,11 +266,7 @@ __device__ __forceinline__ void attn_head_fold(
             } else {
                 z = importance_logit(sc, qn_h * kn_my, inv_sqrt_d, K, L);
             }
-#if MP_NT_STORES
-            if (score_h != nullptr && (c % DUP) == 0) __builtin_nontemporal_store(z, score_h + j_my);
-#else
             if (score_h != nullptr && (c % DUP) == 0) score_h[j_my] = z;
-#endif
         }
         const float m_w = wave_max(z);
         const float p_my = valid_my ? __expf(z - m_w) : 0.f;    // slice non-empty => m_w finite
@@ -497,7 +490,7 @@ __device__ __forceinline__ void attn_head_merge(const AhState& st, float* s_merg
     }
 }
 
-// The same meeting WITHOUT the workgroup barrier (the decode kernel, -DMP_MERGE_TICKET=1): every wave
+// The same meeting WITHOUT the workgroup barrier (the decode kernel): every wave
 // leaves its state in LDS and draws an LDS ticket; the wave that draws the last one holds the merged state on return
 // (true), the others are done (false) -- the workgroup then waits for its slowest wave's rows once, in that wave, instead
 // of rows -> barrier -> wave 0's wake-up.  Ordering: a wave's LDS instructions execute in issue order, so its ticket is

@@ -104,32 +104,8 @@ hipError_t set_stamp_stride(int stride) {
 constexpr int RT_THREADS = MP_RT_THREADS;  // 16 waves: one workgroup per query head (A/B builds: 512, two per CU)
 constexpr int RT_WAVES = RT_THREADS / 64;
 constexpr int RT_GROUP = 12;               // buckets in flight per wave per round (x 2 chunks of 64 ids)
-#ifndef MP_MERGE_TICKET
-#define MP_MERGE_TICKET 1                  // the waves' states meet behind an LDS ticket instead of a workgroup barrier (round 5:
-                                           // -0.07 us per layer at cfg 1 / cfg 4, -0.45 at cfg 0, -0.03 at cfg 3; A/B: -DMP_MERGE_TICKET=0,
-                                           // which the stamp build uses -- its "states met" stamp belongs to wave 0)
-#endif
-#ifndef MP_LEAN_GREEDY
-#define MP_LEAN_GREEDY 0                   // LEAN, A/B (-DMP_LEAN_GREEDY=1, measured slower: EXPERIMENTS.md R6-1): an idle wave takes what the
-#endif                                     // list holds (>= MP_LEAN_MIN entries, compare-and-swap on the head) instead of waiting for a full slice
-#ifndef MP_LEAN_MIN
-#define MP_LEAN_MIN 8
-#endif
-#ifndef MP_SETPRIO_WAVE0
-#define MP_SETPRIO_WAVE0 0                 // s_setprio 3 on wave 0 while it normalises the query row (A/B)
-#endif
-#ifndef MP_LDS_BARRIERS
-#define MP_LDS_BARRIERS 1                  // round 5: the barriers of the decode chain that protect LDS data only wait for LDS only
-#endif                                     // (__syncthreads() also waits for vmcnt(0): the acknowledgement of every by-product
-#if MP_LDS_BARRIERS                        // store -- codes, result rows -- issued in front of it); A/B: -DMP_LDS_BARRIERS=0
-#define MP_CHAIN_BARRIER() lds_barrier()
-#else
-#define MP_CHAIN_BARRIER() __syncthreads()
-#endif
-#ifndef MP_STREAM_ONE_TRIP
-#define MP_STREAM_ONE_TRIP 2               // sub-bounds path: both 64-id chunks of every piece of a wave requested together (2);
-                                           // 1 = the pool's first round with them too (measured slower), 0 = round 4's form
-#endif
+// The barriers of the decode chain that order LDS data only are lds_barrier() (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads()
+// also waits for vmcnt(0), i.e. for the acknowledgement of every by-product store in front of it (EXPERIMENTS.md R5-4).
 // Table-side loads -- direct slots, bucket records, table ids: every line of them is read once per launch, by one CU -- are
 // non-temporal (`nt`: no claim on the L2 the K / V rows and the hyperplanes live in).  Round 4, same instruction schedule with
 // and without the bit on these 121 loads: cfg 3 29.77 -> 29.13 us per layer, cfg 1 and cfg 4 within +-0.1 (EXPERIMENTS.md R4-15).
@@ -874,7 +850,7 @@ __device__ __forceinline__ void lsh_head_body(
     if (padding_block) return;
     if (tid == 0) {
         *s_ntail = 0;
-        if (AD > 0) s_tk[0] = 0;                                  // (MP_MERGE_TICKET: the waves' LDS ticket)
+        if (AD > 0) s_tk[0] = 0;                                  // (the waves' LDS ticket)
         s_tmp[30] = 0;                                            // pieces that overflow their direct slot
         s_tmp[29] = 1;                                            // split hash: every word of the head arrived
         s_tmp[27] = 0;                                            // LEAN: entries reserved in the workgroup's list (= tokens selected)
@@ -960,9 +936,6 @@ __device__ __forceinline__ void lsh_head_body(
         // -- normalise the query row (QUAD: waves 0 .. 3 one row of the quad each; wave qm's is this head's own)
         const bool own_row = !QUAD || wave == qm;
         if (wave < (QUAD ? 4 : 1)) {
-#if MP_SETPRIO_WAVE0
-            __builtin_amdgcn_s_setprio(3);     // the one wave everybody waits for: ahead of its 15 siblings at the issue ports
-#endif
             const uint16_t e[4] = {(uint16_t)(e01 & 0xffffu), (uint16_t)(e01 >> 16),
                                    (uint16_t)(e23 & 0xffffu), (uint16_t)(e23 >> 16)};
             // The definition (what torch computes on bf16 tensors, pinned by the qhash_* fixtures): nrm = f32 sqrt of the
@@ -1039,9 +1012,6 @@ __device__ __forceinline__ void lsh_head_body(
                 }
             }
             MP_STAMP(stamp, 29);                               // normalised row written to LDS
-#if MP_SETPRIO_WAVE0
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
         __syncthreads();
         MP_STAMP(stamp, 22);
@@ -1352,11 +1322,10 @@ __device__ __forceinline__ void lsh_head_body(
         idmask = idbits ? ((1u << idbits) - 1u) : 0xffffffffu;
     }
     const int32_t* slots = (AD > 0) ? aa.slots : nullptr;
-    bool tail_first_done = false;   // uniform: the pool's first round went out with the pieces' own loads (sub-bounds path)
     // direct pieces: the barrier behind the pass, and the chunk pool of what is longer than slot + follow-up (skewed data)
     // (LEAN: run by ONE wave -- the one that drew the last ticket, behind everybody's counting -- without barriers)
     auto direct_pool_build = [&]() {
-        if constexpr (!LEAN) MP_CHAIN_BARRIER();
+        if constexpr (!LEAN) lds_barrier();
         MP_STAMP(stamp, 17);
         if (s_tmp[30] > 0) {                                            // uniform; pieces longer than 30 + 96 ids
             for (int l = LEAN ? lane : tid; l < L; l += LEAN ? WAVE : RT_THREADS) {
@@ -1560,7 +1529,7 @@ __device__ __forceinline__ void lsh_head_body(
                 s_tail[base + c] = ((uint32_t)l << 16) | (uint32_t)(c + 2);
         }
     }
-    MP_CHAIN_BARRIER();
+    lds_barrier();
     MP_STAMP(stamp, 17);
     MP_STAMP(stamp, 18);
 
@@ -1568,7 +1537,7 @@ __device__ __forceinline__ void lsh_head_body(
     // flight, then applies them.  Straight-line rounds: all (start, length) pairs out of LDS, then all loads, then all
     // applies.  As one loop body per piece with the loads under lane-divergent branches the compiler put an
     // s_waitcnt vmcnt(0) between the pieces: two, not twelve, were in flight.
-    // Round 5 -- both chunks of every piece in ONE round trip (MP_STREAM_ONE_TRIP = 2).  Until round 4 the second 64 ids of a
+    // Round 5 -- both chunks of every piece in ONE round trip.  Until round 4 the second 64 ids of a
     // piece were requested only behind the first chunks' applies: SimHash buckets are wide (p99 of a probed piece = 2.3 x
     // its mean; mean 32 ids at cfg 2 / 3), so ~4 % of the pieces are longer than 64 ids, almost every workgroup holds a
     // wave with such a piece, and the launch waits for the workgroup that paid the second dependent round trip.  Now both
@@ -1582,16 +1551,14 @@ __device__ __forceinline__ void lsh_head_body(
     // the applies of everybody's first chunk: cfg 3 28.90, cfg 2 32.07, clustered 41.46 -- no better than round 4's form.
     {
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-#if MP_STREAM_ONE_TRIP
     const uint64_t tab_bytes = (uint64_t)L * (uint64_t)M * 4ull;
     if (tab_bytes < (1ull << 32)) {                                          // uniform: 32-bit offsets cover the group's rows
         const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(tab), 0,
                                                                             (int)(uint32_t)tab_bytes, 0x00020000);
         constexpr int kNt = 2;                                               // aux bit 1 = nt on gfx940+
         constexpr uint32_t kOut = 0xfffffff0u;                               // beyond any num_records: no request, returns 0
-        const int ntail0 = __builtin_amdgcn_readfirstlane(*s_ntail);
         for (int l0 = wave_s; l0 < L; l0 += RT_WAVES * RT_GROUP) {
-            int32_t id0[RT_GROUP], id1[RT_GROUP], idt[RT_TAIL_UNROLL];
+            int32_t id0[RT_GROUP], id1[RT_GROUP];
             int ln[RT_GROUP];
             uint32_t wb[RT_GROUP];
 #pragma unroll
@@ -1614,23 +1581,8 @@ __device__ __forceinline__ void lsh_head_body(
             for (int b = 0; b < RT_GROUP; ++b)
                 id1[b] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(
                     rt, lane + 64 < ln[b] ? (wb[b] + (uint32_t)lane + 64u) << 2 : kOut, 0, kNt);
-            // the pool's first round rides along (this wave's chunks wave, wave + 16, ...): descriptors out of LDS
-            const bool tails_now = MP_STREAM_ONE_TRIP == 1 && l0 == wave_s && ntail0 > 0 && ntail0 <= RT_TAIL_CAP;   // uniform
-            // (-DMP_STREAM_ONE_TRIP=2: both chunks of every piece together, the pool behind them as before)
-            uint32_t tin = 0u;                                               // per lane: bit u = chunk u holds an id for it
-            if (tails_now) {
-#pragma unroll
-                for (int u = 0; u < RT_TAIL_UNROLL; ++u) {
-                    const int c = wave_s + u * RT_WAVES;
-                    const uint32_t d = s_tail[c < ntail0 ? c : 0];
-                    const int l = (int)(d >> 16), j = (int)((d & 0xffffu) << 6) + lane;
-                    const bool in = c < ntail0 && j < s_len[l];
-                    idt[u] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(
-                        rt, in ? ((uint32_t)l * (uint32_t)M + (uint32_t)s_start[l] + (uint32_t)j) << 2 : kOut, 0, kNt);
-                    tin |= (in ? 1u : 0u) << u;      // (not written into idt[u] here: that would wait for the load)
-                }
-                tail_first_done = true;
-            }
+            // (the pool behind them as before: with its first round in this batch too -- form 1 of R5-1 -- its descriptors,
+            // three dependent LDS reads per chunk, stood in front of everybody's first chunk and cost what the trip saved)
             // applied in issue order: the first piece's ids are counted while the last piece's are still on their way
             bool longer = false;
 #pragma unroll
@@ -1651,10 +1603,6 @@ __device__ __forceinline__ void lsh_head_body(
                     }
                     lean_rest(id1, lu, lo, false);
                 }
-                if (tails_now) {
-#pragma unroll
-                    for (int u = 0; u < RT_TAIL_UNROLL; ++u) lean_apply1((tin >> u) & 1u ? idt[u] : -1, false);
-                }
             } else {
 #pragma unroll
             for (int b = 0; b < RT_GROUP; ++b) apply(lane < ln[b] ? id0[b] : -1);
@@ -1662,14 +1610,9 @@ __device__ __forceinline__ void lsh_head_body(
 #pragma unroll
                 for (int b = 0; b < RT_GROUP; ++b) apply(lane + 64 < ln[b] ? id1[b] : -1);
             }
-            if (tails_now) {
-#pragma unroll
-                for (int u = 0; u < RT_TAIL_UNROLL; ++u) apply((tin >> u) & 1u ? idt[u] : -1);
-            }
             }
         }
     } else
-#endif
     for (int l0 = wave_s; l0 < L; l0 += RT_WAVES * RT_GROUP) {
         int32_t id0[RT_GROUP], id1[RT_GROUP];
         int ln[RT_GROUP], sa[RT_GROUP];
@@ -1735,51 +1678,14 @@ __device__ __forceinline__ void lsh_head_body(
         const uint16_t* kv_l = aa.kv + g * M * 2 * ADL;
         const float* kn_l = aa.kn + g * M;
         constexpr int SHORT_L = (ADL == 128) ? 16 : AH_SLICE;
-#ifndef MP_LEAN_CL
-#define MP_LEAN_CL SHORT_L                 // A/B: entries per claim where a head is a cluster (12: a claim = what a wave adds on average)
-#endif
         // (the launcher uses this form only where a head is a cluster: the step is the short one -- 16 tokens at head_dim 128 --
         // and no 32-token instantiation of the fold sits in this kernel: its registers were the kernel's spills)
-        const int CL = SHORT_L < AH_SLICE ? MP_LEAN_CL : AH_SLICE;                  // uniform: entries per claim
+        // entries per claim = one step of the fold (claims of 12 -- what a wave adds on average -- were +0.2 us: a step's cost is
+        // per step, R6-1)
+        const int CL = SHORT_L;
         int folded = 0;
         for (;;) {
             int start = 0, nh = 0;
-#if MP_LEAN_GREEDY
-            // take what is there: a full slice, or -- rather than wait for one -- at least MP_LEAN_MIN entries, or whatever
-            // is left once nobody counts any more (then `res` is final: a wave's last reservation precedes its "done").
-            // The claim is a compare-and-swap on the list's head: several idle waves look at the same entries.
-            bool over = false;
-            for (;;) {
-                const int done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                int res = __hip_atomic_load(s_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int head = __builtin_amdgcn_readfirstlane(__hip_atomic_load(s_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                res = __builtin_amdgcn_readfirstlane(res);
-                const bool fin = __builtin_amdgcn_readfirstlane(done) >= RT_WAVES;
-                const int avail = (res < lcap ? res : lcap) - head;
-                if (avail >= MP_LEAN_MIN || (fin && avail > 0)) {
-                    const int n = avail < CL ? avail : CL;
-                    int seen = head;
-                    if (lane == 0) {
-                        int expect = head;
-                        (void)__hip_atomic_compare_exchange_strong(s_head, &expect, head + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-                        seen = expect;
-                    }
-                    if (__builtin_amdgcn_readfirstlane(seen) == head) {
-                        start = head;
-                        nh = n;
-                        break;
-                    }
-                    continue;                                            // another wave took them: look again
-                }
-                if (fin) {                                               // nothing left, nothing to come
-                    over = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (over) break;
-#else
             // (the first look at the two counters travels with the claim: one LDS round trip, not two)
             int done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             int res = __hip_atomic_load(s_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1800,21 +1706,6 @@ __device__ __forceinline__ void lsh_head_body(
             nh = (res < lcap ? res : lcap) - start;
             if (nh <= 0) break;
             nh = nh < CL ? nh : CL;
-#endif
-#if MP_LEAN_GREEDY
-            // reserved is not written: the reserving wave stores its entries right behind its atomic
-            for (;;) {
-                const int32_t w = lane < nh ? __hip_atomic_load(s_ids + start + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
-                if (__ballot(w == -1) == 0ull) break;
-            }
-            // (a greedy claim starts anywhere: four 4-byte reads, not one that needs 16-byte alignment)
-            auto slice = [&](int j) {
-                const int32_t* e = s_ids + start + j;
-                return u32x4{(uint32_t)e[0], (uint32_t)e[1], (uint32_t)e[2], (uint32_t)e[3]};
-            };
-            attn_head_fold_lean<ADL, SHORT_L>(st_own, kv_l, kn_l, qv_l, s_rn[1], nh, M, ha.K, L, 0, 1, slice, idmask, idbits, pay,
-                                              stamp);
-#else
             // reserved is not written: the reserving wave stores its entries right behind its atomic.  The gather's own
             // read of the slice is the check -- row group r of the step reads entries r UPS .. r UPS + UPS - 1 (attn_head_fold_lean);
             // an entry of the slice that still says "not written" (-1) means: read again.  The fold gets the registers.
@@ -1845,7 +1736,6 @@ __device__ __forceinline__ void lsh_head_body(
             read_slice(std::integral_constant<int, UPS_S>{});
             attn_head_fold_lean<ADL, SHORT_L>(st_own, kv_l, kn_l, qv_l, s_rn[1], nh, M, ha.K, L, 0, 1, slice, idmask, idbits, pay,
                                               stamp);
-#endif
             folded += nh;
         }
         if (WIN && aa.win_kv != nullptr) {      // the static window: dense slices rank, rank + R, ... over the waves
@@ -1890,8 +1780,7 @@ __device__ __forceinline__ void lsh_head_body(
     // round-robin with RT_TAIL_UNROLL loads in flight
     const int ntail = (LEAN && !rare) ? 0 : __builtin_amdgcn_readfirstlane(*s_ntail);
     if (ntail <= RT_TAIL_CAP) {
-        // (sub-bounds path, one-trip stream: the first round of the pool went out with the pieces' own loads)
-        for (int c0 = pw + (tail_first_done ? PN * RT_TAIL_UNROLL : 0); c0 < ntail; c0 += PN * RT_TAIL_UNROLL) {
+        for (int c0 = pw; c0 < ntail; c0 += PN * RT_TAIL_UNROLL) {
             int32_t idt[RT_TAIL_UNROLL];
 #pragma unroll
             for (int u = 0; u < RT_TAIL_UNROLL; ++u) {
@@ -1931,7 +1820,7 @@ __device__ __forceinline__ void lsh_head_body(
         if (spilled) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the pool's finds: this wave's own stores)
     } else {
     // (direct pass without pooled chunks: nothing was counted since the barrier behind the pass)
-    if (!(direct_path && ntail == 0)) MP_CHAIN_BARRIER();
+    if (!(direct_path && ntail == 0)) lds_barrier();
     }
     MP_STAMP(stamp, 19);
 
@@ -1954,7 +1843,7 @@ __device__ __forceinline__ void lsh_head_body(
     if (ordered) {
         for (int k = 0; k < wpt; ++k)
             if (w0 + k < nsw) cnt += __popc(bmB[w0 + k]);
-        off = block_excl_scan<MP_LDS_BARRIERS != 0>(cnt, s_tmp, total);
+        off = block_excl_scan<true>(cnt, s_tmp, total);
     }
     MP_STAMP(stamp, 20);
     // AD: the member's ids stay in LDS; a list longer than the stage (cap ids) is read back from HBM
@@ -1968,11 +1857,7 @@ __device__ __forceinline__ void lsh_head_body(
         while (bits) {
             const int p = __ffs((int)bits) - 1;
             bits &= bits - 1;
-#if MP_NT_STORES
-            __builtin_nontemporal_store((int32_t)(base + p), out + off);
-#else
             out[off] = base + p;
-#endif
             if (AD > 0 && off < aa.cap) s_ids[off] = base + p;
             if (AD == 0 && out2 != nullptr) {
                 out2[off] = base + p;
@@ -2023,7 +1908,7 @@ __device__ __forceinline__ void lsh_head_body(
     // acknowledged ~0.5 us after they were issued, and this barrier sits on the path to the first row request
     // (LEAN, list in the stage: the counting barrier already ordered the appended ids in front of everything below)
     if constexpr (!LEAN) {
-        if (spill || !MP_LDS_BARRIERS) __syncthreads();
+        if (spill) __syncthreads();
         else lds_barrier();
     }
     MP_STAMP(stamp, 33);
@@ -2075,7 +1960,6 @@ __device__ __forceinline__ void lsh_head_body(
             attn_head_merge_read<ADD, RT_WAVES>(s_merge, m, Z, o0, o1);
         }
     } else {
-#if MP_MERGE_TICKET
     // no workgroup barrier: the wave that draws the last LDS ticket merges and goes on to the hand-off -- ONE wave from
     // here on, whichever it is (round 5; EXPERIMENTS.md R5-2)
     if (!attn_head_merge_ticket<ADD, RT_WAVES>(st, s_merge, s_tk, m, Z, o0, o1)) {
@@ -2083,13 +1967,6 @@ __device__ __forceinline__ void lsh_head_body(
         return;
     }
     MP_STAMP_L(stamp, 40);
-#else
-    attn_head_merge<ADD, RT_WAVES, true>(st, s_merge, m, Z, o0, o1);
-    MP_STAMP(stamp, 40);   // the waves' states have met in LDS (the barrier waits for the wave whose rows came last)
-    // from here on WAVE 0 alone holds the workgroup's state: one wave needs no workgroup barrier to order its
-    // own stores, ticket and loads, and the other fifteen are done
-    if (wave != 0) return;
-#endif
     }
     if (clog == 0) {
         attn_head_finalize<ADD>(m, Z, o0, o1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);
