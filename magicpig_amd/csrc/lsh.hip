@@ -744,6 +744,213 @@ struct AttnArgs {
     // cost cfg 1 0.1 us per launch)
 };
 
+// ---- emission of a workgroup's selected tokens in ASCENDING order (everything but the lean decode): every thread counts the set
+// bits of its contiguous words of bitmap B, a block-wide exclusive scan gives it its place, and it writes its tokens' ids to the
+// head's row in HBM (`out`: the stand-alone retrieve's result, the decode's by-product), to the gather's stage in LDS (AD > 0:
+// the first `cap` of them) and -- host-buffer mode of the stand-alone retrieve -- to a second row in HBM with two checksums.
+// Returns the number of tokens selected.
+template <int AD>
+__device__ __forceinline__ int emit_ordered(const uint32_t* bmB, int words, int T0, int32_t* __restrict__ out, int32_t* s_ids, int cap,
+                                            int32_t* __restrict__ out2, int* s_tmp, uint32_t& cs1, uint32_t& cs2,
+                                            unsigned long long* __restrict__ stamp) {
+    const int tid = threadIdx.x;
+    const int nsw = words;
+    const int wpt = (nsw + RT_THREADS - 1) / RT_THREADS;
+    const int w0 = tid * wpt;
+    int cnt = 0, total = 0;
+    for (int k = 0; k < wpt; ++k)
+        if (w0 + k < nsw) cnt += __popc(bmB[w0 + k]);
+    int off = block_excl_scan<true>(cnt, s_tmp, total);
+    MP_STAMP(stamp, 20);
+    for (int k = 0; k < wpt; ++k) {
+        if (w0 + k >= nsw) break;
+        uint32_t bits = bmB[w0 + k];
+        const int base = T0 + ((w0 + k) << 5);
+        while (bits) {
+            const int p = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            out[off] = base + p;
+            if (AD > 0 && off < cap) s_ids[off] = base + p;
+            if (AD == 0 && out2 != nullptr) {
+                out2[off] = base + p;
+                cs1 += row_mix((uint32_t)(base + p + 1), (uint32_t)(off + 1));
+                cs2 += (uint32_t)(base + p + 1) * (uint32_t)(off + 1);
+            }
+            ++off;
+        }
+    }
+    return total;
+}
+
+// ---- last phase of a head that is served by a cluster: ONE wave of every member -- the one that merged its workgroup's waves --
+// arrives here with the member's softmax state (m, Z, this lane's elements o0 | o1 of the partial output) and its count.
+// (Round 6, VERDICT r05 item 8: split out of lsh_head_body -- one instruction of difference in the kernels' ISA.  The query-hash
+// phase was split out the same way and put back: as a function of its own the compiler issued the kernel-argument loads in front
+// of the query row's request again -- +0.1 us per launch on every configuration; scripts/experiments/r06_hash_phase_as_function.patch,
+// profiles/r06_ab_refactor.txt.)
+template <int ADD>
+__device__ __forceinline__ void cluster_handoff(const AttnArgs& aa, int64_t h, int rank, int clog, float m, float Z, float o0, float o1,
+                                                int total, uint16_t* out_h, int32_t* __restrict__ nnz,
+                                                unsigned long long* __restrict__ stamp) {
+    const int lane = threadIdx.x & 63;
+    // ---- cluster > 1: publish this member's state (a member without tokens publishes m = -inf, Z = 0), drain,
+    // take an arrival ticket; the member that draws the last ticket merges (hand-off recipe:
+    // cdna_hip_programming.md G16, as attn_sparse_kernel).  Block b runs on XCD b % 8, so when B*H is a multiple
+    // of 8 the members of a cluster (blocks h, h + BH, ...) share ONE XCD and its L2: the hand-off then only has
+    // to bypass the per-CU L1 (sc0, the workgroup scope of a split workgroup) instead of writing through to the
+    // memory side (sc1), which takes three ~0.6 us L2 round trips instead of three ~1.8 us ones.  The
+    // host enables it only after xcd_round_robin_verified() has seen the placement on this device, and every
+    // launch re-checks that the members of a cluster really ran on ONE XCD: each publishes its XCC_ID next to its
+    // count and the merger compares (err bit 4 otherwise: mp_attn_check reports it).  That comparison needs a merger:
+    // members spread over several XCDs draw their tickets from different L2s, nobody draws the last one, nothing is
+    // merged -- the counters left standing are what mp_attn_check looks for (attn_ticket_check_kernel, err bit 8) and
+    // resets.  WHICH XCD a residue lands on
+    // is not fixed -- under graph replay the round robin was observed to start elsewhere than in the probe
+    // launches -- only that blocks b and b + 8k share one matters.
+    constexpr int VPL = ADD / 64;
+    const int nmem = 1 << clog;
+    const int64_t pre = h * aa.maxs;
+    int ticket = 0;
+    uint32_t my_xcc = 0;
+    if (aa.same_xcd) {
+        // every member publishes the XCD it ran on next to its count; the merger compares them with its own
+        my_xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]
+        constexpr int kSc0 = 1;   // aux bit 0 = sc0 on gfx940+
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+            aa.part_o + pre * ADD, 0, (int)(aa.maxs * ADD * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<float*>(aa.part_ml + pre), 0, (int)(aa.maxs * 8), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(aa.part_cnt + h * CLUSTER_MAX, 0,
+                                                                            CLUSTER_MAX * 4, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), ro, (rank * ADD + lane * VPL) * 4, 0, kSc0);
+        if (VPL == 2)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1), ro, (rank * ADD + lane * 2 + 1) * 4, 0, kSc0);
+        if (lane == 0) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rm, rank * 8, 0, kSc0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Z), rm, rank * 8 + 4, 0, kSc0);
+            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)total | (my_xcc << 24), rc, rank * 4, 0, kSc0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing lane of this wave drained
+        MP_STAMP_L(stamp, 41);
+        if (lane == 0)
+            ticket = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        MP_STAMP_L(stamp, 38);
+        if (ticket != nmem - 1) {
+            MP_STAMP_FLUSH_L(stamp);
+            return;
+        }
+        if (lane == 0) {
+            __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // split hash: every member is past the exchange -- the next launch gets a new sequence number
+            if (aa.xseq != nullptr) __hip_atomic_fetch_add(aa.xseq + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+        __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + lane * VPL),
+                           __float_as_uint(o0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (VPL == 2)
+            __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + lane * 2 + 1),
+                               __float_as_uint(o1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(aa.part_ml + pre + rank),
+                               (unsigned long long)__float_as_uint(m) | ((unsigned long long)__float_as_uint(Z) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(aa.part_cnt + h * CLUSTER_MAX + rank, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            ticket = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        MP_STAMP_L(stamp, 38);
+        if (ticket != nmem - 1) {
+            MP_STAMP_FLUSH_L(stamp);
+            return;
+        }
+        if (lane == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the last arriver merges the R records in rank order (bit-identical whoever merges).  Lane u < R reads member
+    // u's (m, Z, count) -- one round of loads for any R up to 32 -- and every lane reads its two elements of all R
+    // partial outputs; everything is requested before anything is used (a use inside the loading loop made every
+    // member's loads wait for the previous member's: R dependent L2 round trips).  The scales exp(m_u - max) are computed
+    // once, by lane u, and broadcast with v_readlane.  (Measured and rejected, round 4: the wave's two halves taking half
+    // of the members each with 16-byte loads -- R / 2 load instructions instead of 2 R -- and one cross-half add: cfg 1
+    // 19.42 against 19.27 us per layer, cfg 4 at R = 16 17.23 against 16.98; EXPERIMENTS.md R4-4.)
+    float mm = -INFINITY, ZZ = 0.f, q0 = 0.f, q1 = 0.f;
+    int csum = 0;
+    auto merge_records = [&](auto n_tag) {
+        constexpr int NM = decltype(n_tag)::value;                    // 8, 16 or 32 >= nmem: loads past nmem re-read member 0
+        const int lu = lane < nmem ? lane : 0;
+        float m_u, z_u;
+        int c_u;
+        float oa[NM], ob[NM];
+        if (aa.same_xcd) {
+            constexpr int kSc0 = 1;
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+                aa.part_o + pre * ADD, 0, (int)(aa.maxs * ADD * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<float*>(aa.part_ml + pre), 0, (int)(aa.maxs * 8), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(aa.part_cnt + h * CLUSTER_MAX, 0,
+                                                                                CLUSTER_MAX * 4, 0x00020000);
+            m_u = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, lu * 8, 0, kSc0));
+            z_u = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, lu * 8 + 4, 0, kSc0));
+            c_u = (int)__builtin_amdgcn_raw_buffer_load_b32(rc, lu * 4, 0, kSc0);
+#pragma unroll
+            for (int u = 0; u < NM; ++u) {
+                const int uu = u < nmem ? u : 0;
+                oa[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (uu * ADD + lane * VPL) * 4, 0, kSc0));
+                ob[u] = VPL == 2 ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (uu * ADD + lane * 2 + 1) * 4, 0, kSc0))
+                                 : 0.f;
+            }
+        } else {
+            const unsigned long long pk = __hip_atomic_load(
+                reinterpret_cast<unsigned long long*>(aa.part_ml + pre + lu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m_u = __uint_as_float((uint32_t)pk);
+            z_u = __uint_as_float((uint32_t)(pk >> 32));
+            c_u = __hip_atomic_load(aa.part_cnt + h * CLUSTER_MAX + lu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < NM; ++u) {
+                const int uu = u < nmem ? u : 0;
+                oa[u] = __uint_as_float(__hip_atomic_load(
+                    reinterpret_cast<unsigned int*>(aa.part_o + (pre + uu) * ADD + lane * VPL), __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT));
+                ob[u] = VPL == 2 ? __uint_as_float(__hip_atomic_load(
+                                       reinterpret_cast<unsigned int*>(aa.part_o + (pre + uu) * ADD + lane * 2 + 1),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                 : 0.f;
+            }
+        }
+        if (lane >= nmem) {
+            m_u = -INFINITY;
+            z_u = 0.f;
+            c_u = 0;
+        }
+        // a member on another XCD (a placement the host did not observe): its partial may be stale in this L2
+        if (aa.same_xcd) {
+            const bool off = lane < nmem && ((uint32_t)c_u >> 24) != my_xcc;
+            if (__ballot(off) != 0ull && lane == 0) atomicOr(aa.err, 4);
+        }
+        c_u &= 0xffffff;
+        mm = wave_max(m_u);
+        const float e_u = (m_u != -INFINITY) ? __expf(m_u - mm) : 0.f;   // a member without tokens: weight 0
+        const float ez_u = e_u * z_u;
+#pragma unroll
+        for (int u = 0; u < NM; ++u) {
+            const float e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_u), u));     // 0 past nmem
+            ZZ += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ez_u), u));
+            csum += __builtin_amdgcn_readlane(c_u, u);
+            q0 = fmaf(e, oa[u], q0);
+            q1 = fmaf(e, ob[u], q1);
+        }
+    };
+    if (nmem <= 8) merge_records(std::integral_constant<int, 8>{});
+    else if (nmem <= 16) merge_records(std::integral_constant<int, 16>{});
+    else merge_records(std::integral_constant<int, 32>{});
+    attn_head_finalize<ADD>(mm, ZZ, q0, q1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);   // ZZ = 0: no member had a token
+    if (lane == 0) nnz[h] = csum;
+    MP_STAMP_L(stamp, 39);
+    MP_STAMP_FLUSH_L(stamp);
+}
+
 // HASH: 0 = the codes are given (`query`), 1 = fused SimHash prologue, 3 = the same with the planes split over the
 // members of the head's cluster (decode only, clusters on one XCD), 2 = (decode only) codes + ||q|| were written
 // to ha.codes_out / ha.qnorm_out by simhash_query_kernel (the MFMA kernel) in a launch of its own: the A/B
@@ -1824,49 +2031,23 @@ __device__ __forceinline__ void lsh_head_body(
     }
     MP_STAMP(stamp, 19);
 
-    // sweep B: contiguous words per thread, block-wide exclusive scan, ascending emission
-    int cnt = 0;
     // the stand-alone retrieve writes the head's list; a decode member writes ITS list at column t0 of the
     // head's row (a by-product: get_score's order, the spill path below), nnz is summed at the hand-off
     int32_t* out = results + h * M + t0;
-    const int nsw = words;
-    const int wpt = (nsw + RT_THREADS - 1) / RT_THREADS;
-    const int w0 = tid * wpt;
     // LEAN: there is no list to emit -- the waves have gathered it slice by slice; the count is what was reserved
-    int total = 0, off = 0;
-    constexpr bool ordered = !LEAN;
+    int total = 0;
     int nspill = 0;                                                  // uniform
+    uint32_t cs1 = 0u, cs2 = 0u;            // stand-alone retrieve: checksum of this thread's entries (host-buffer mode)
+    int32_t* out2 = (AD == 0 && aa.rows2 != nullptr) ? aa.rows2 + h * M : nullptr;
     if constexpr (LEAN) {
         total = pre_total + nsp - (pre_total > lcap ? pre_total - lcap : 0);    // + the pool's finds
         nspill = nsp;
+        MP_STAMP(stamp, 20);
+    } else {
+        total = emit_ordered<AD>(bmB, words, (int)T0, out, s_ids, AD > 0 ? aa.cap : 0, out2, s_tmp, cs1, cs2, stamp);
     }
-    if (ordered) {
-        for (int k = 0; k < wpt; ++k)
-            if (w0 + k < nsw) cnt += __popc(bmB[w0 + k]);
-        off = block_excl_scan<true>(cnt, s_tmp, total);
-    }
-    MP_STAMP(stamp, 20);
     // AD: the member's ids stay in LDS; a list longer than the stage (cap ids) is read back from HBM
     const bool spill = !LEAN && AD > 0 && total > aa.cap;
-    uint32_t cs1 = 0u, cs2 = 0u;            // stand-alone retrieve: checksum of this thread's entries (host-buffer mode)
-    int32_t* out2 = (AD == 0 && aa.rows2 != nullptr) ? aa.rows2 + h * M : nullptr;
-    for (int k = 0; k < wpt && ordered; ++k) {
-        if (w0 + k >= nsw) break;
-        uint32_t bits = bmB[w0 + k];
-        const int base = (int)T0 + ((w0 + k) << 5);
-        while (bits) {
-            const int p = __ffs((int)bits) - 1;
-            bits &= bits - 1;
-            out[off] = base + p;
-            if (AD > 0 && off < aa.cap) s_ids[off] = base + p;
-            if (AD == 0 && out2 != nullptr) {
-                out2[off] = base + p;
-                cs1 += row_mix((uint32_t)(base + p + 1), (uint32_t)(off + 1));
-                cs2 += (uint32_t)(base + p + 1) * (uint32_t)(off + 1);
-            }
-            ++off;
-        }
-    }
     if ((LEAN ? lane : tid) == 0 && (AD == 0 || clog == 0)) {
         nnz[h] = total;
         if (AD == 0 && aa.rows2 != nullptr && aa.part_cnt != nullptr) aa.part_cnt[h] = total;
@@ -1974,162 +2155,7 @@ __device__ __forceinline__ void lsh_head_body(
         MP_STAMP_FLUSH_L(stamp);
         return;
     }
-    // ---- cluster > 1: publish this member's state (a member without tokens publishes m = -inf, Z = 0), drain,
-    // take an arrival ticket; the member that draws the last ticket merges (hand-off recipe:
-    // cdna_hip_programming.md G16, as attn_sparse_kernel).  Block b runs on XCD b % 8, so when B*H is a multiple
-    // of 8 the members of a cluster (blocks h, h + BH, ...) share ONE XCD and its L2: the hand-off then only has
-    // to bypass the per-CU L1 (sc0, the workgroup scope of a split workgroup) instead of writing through to the
-    // memory side (sc1), which takes three ~0.6 us L2 round trips instead of three ~1.8 us ones.  The
-    // host enables it only after xcd_round_robin_verified() has seen the placement on this device, and every
-    // launch re-checks that the members of a cluster really ran on ONE XCD: each publishes its XCC_ID next to its
-    // count and the merger compares (err bit 4 otherwise: mp_attn_check reports it).  That comparison needs a merger:
-    // members spread over several XCDs draw their tickets from different L2s, nobody draws the last one, nothing is
-    // merged -- the counters left standing are what mp_attn_check looks for (attn_ticket_check_kernel, err bit 8) and
-    // resets.  WHICH XCD a residue lands on
-    // is not fixed -- under graph replay the round robin was observed to start elsewhere than in the probe
-    // launches -- only that blocks b and b + 8k share one matters.
-    constexpr int VPL = ADD / 64;
-    const int nmem = 1 << clog;
-    const int64_t pre = h * aa.maxs;
-    int ticket = 0;
-    uint32_t my_xcc = 0;
-    if (aa.same_xcd) {
-        // every member publishes the XCD it ran on next to its count; the merger compares them with its own
-        my_xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]
-        constexpr int kSc0 = 1;   // aux bit 0 = sc0 on gfx940+
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-            aa.part_o + pre * ADD, 0, (int)(aa.maxs * ADD * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<float*>(aa.part_ml + pre), 0, (int)(aa.maxs * 8), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(aa.part_cnt + h * CLUSTER_MAX, 0,
-                                                                            CLUSTER_MAX * 4, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), ro, (rank * ADD + lane * VPL) * 4, 0, kSc0);
-        if (VPL == 2)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1), ro, (rank * ADD + lane * 2 + 1) * 4, 0, kSc0);
-        if (lane == 0) {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rm, rank * 8, 0, kSc0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Z), rm, rank * 8 + 4, 0, kSc0);
-            __builtin_amdgcn_raw_buffer_store_b32((uint32_t)total | (my_xcc << 24), rc, rank * 4, 0, kSc0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing lane of this wave drained
-        MP_STAMP_L(stamp, 41);
-        if (lane == 0)
-            ticket = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        ticket = __builtin_amdgcn_readfirstlane(ticket);
-        MP_STAMP_L(stamp, 38);
-        if (ticket != nmem - 1) {
-            MP_STAMP_FLUSH_L(stamp);
-            return;
-        }
-        if (lane == 0) {
-            __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            // split hash: every member is past the exchange -- the next launch gets a new sequence number
-            if (aa.xseq != nullptr) __hip_atomic_fetch_add(aa.xseq + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    } else {
-        __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + lane * VPL),
-                           __float_as_uint(o0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (VPL == 2)
-            __hip_atomic_store(reinterpret_cast<unsigned int*>(aa.part_o + (pre + rank) * ADD + lane * 2 + 1),
-                               __float_as_uint(o1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0) {
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(aa.part_ml + pre + rank),
-                               (unsigned long long)__float_as_uint(m) | ((unsigned long long)__float_as_uint(Z) << 32),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(aa.part_cnt + h * CLUSTER_MAX + rank, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
-            ticket = __hip_atomic_fetch_add(aa.head_cnt + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ticket = __builtin_amdgcn_readfirstlane(ticket);
-        MP_STAMP_L(stamp, 38);
-        if (ticket != nmem - 1) {
-            MP_STAMP_FLUSH_L(stamp);
-            return;
-        }
-        if (lane == 0) __hip_atomic_store(aa.head_cnt + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // ---- the last arriver merges the R records in rank order (bit-identical whoever merges).  Lane u < R reads member
-    // u's (m, Z, count) -- one round of loads for any R up to 32 -- and every lane reads its two elements of all R
-    // partial outputs; everything is requested before anything is used (a use inside the loading loop made every
-    // member's loads wait for the previous member's: R dependent L2 round trips).  The scales exp(m_u - max) are computed
-    // once, by lane u, and broadcast with v_readlane.  (Measured and rejected, round 4: the wave's two halves taking half
-    // of the members each with 16-byte loads -- R / 2 load instructions instead of 2 R -- and one cross-half add: cfg 1
-    // 19.42 against 19.27 us per layer, cfg 4 at R = 16 17.23 against 16.98; EXPERIMENTS.md R4-4.)
-    float mm = -INFINITY, ZZ = 0.f, q0 = 0.f, q1 = 0.f;
-    int csum = 0;
-    auto merge_records = [&](auto n_tag) {
-        constexpr int NM = decltype(n_tag)::value;                    // 8, 16 or 32 >= nmem: loads past nmem re-read member 0
-        const int lu = lane < nmem ? lane : 0;
-        float m_u, z_u;
-        int c_u;
-        float oa[NM], ob[NM];
-        if (aa.same_xcd) {
-            constexpr int kSc0 = 1;
-            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-                aa.part_o + pre * ADD, 0, (int)(aa.maxs * ADD * 4), 0x00020000);
-            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<float*>(aa.part_ml + pre), 0, (int)(aa.maxs * 8), 0x00020000);
-            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(aa.part_cnt + h * CLUSTER_MAX, 0,
-                                                                                CLUSTER_MAX * 4, 0x00020000);
-            m_u = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, lu * 8, 0, kSc0));
-            z_u = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, lu * 8 + 4, 0, kSc0));
-            c_u = (int)__builtin_amdgcn_raw_buffer_load_b32(rc, lu * 4, 0, kSc0);
-#pragma unroll
-            for (int u = 0; u < NM; ++u) {
-                const int uu = u < nmem ? u : 0;
-                oa[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (uu * ADD + lane * VPL) * 4, 0, kSc0));
-                ob[u] = VPL == 2 ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (uu * ADD + lane * 2 + 1) * 4, 0, kSc0))
-                                 : 0.f;
-            }
-        } else {
-            const unsigned long long pk = __hip_atomic_load(
-                reinterpret_cast<unsigned long long*>(aa.part_ml + pre + lu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            m_u = __uint_as_float((uint32_t)pk);
-            z_u = __uint_as_float((uint32_t)(pk >> 32));
-            c_u = __hip_atomic_load(aa.part_cnt + h * CLUSTER_MAX + lu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int u = 0; u < NM; ++u) {
-                const int uu = u < nmem ? u : 0;
-                oa[u] = __uint_as_float(__hip_atomic_load(
-                    reinterpret_cast<unsigned int*>(aa.part_o + (pre + uu) * ADD + lane * VPL), __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT));
-                ob[u] = VPL == 2 ? __uint_as_float(__hip_atomic_load(
-                                       reinterpret_cast<unsigned int*>(aa.part_o + (pre + uu) * ADD + lane * 2 + 1),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                                 : 0.f;
-            }
-        }
-        if (lane >= nmem) {
-            m_u = -INFINITY;
-            z_u = 0.f;
-            c_u = 0;
-        }
-        // a member on another XCD (a placement the host did not observe): its partial may be stale in this L2
-        if (aa.same_xcd) {
-            const bool off = lane < nmem && ((uint32_t)c_u >> 24) != my_xcc;
-            if (__ballot(off) != 0ull && lane == 0) atomicOr(aa.err, 4);
-        }
-        c_u &= 0xffffff;
-        mm = wave_max(m_u);
-        const float e_u = (m_u != -INFINITY) ? __expf(m_u - mm) : 0.f;   // a member without tokens: weight 0
-        const float ez_u = e_u * z_u;
-#pragma unroll
-        for (int u = 0; u < NM; ++u) {
-            const float e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_u), u));     // 0 past nmem
-            ZZ += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ez_u), u));
-            csum += __builtin_amdgcn_readlane(c_u, u);
-            q0 = fmaf(e, oa[u], q0);
-            q1 = fmaf(e, ob[u], q1);
-        }
-    };
-    if (nmem <= 8) merge_records(std::integral_constant<int, 8>{});
-    else if (nmem <= 16) merge_records(std::integral_constant<int, 16>{});
-    else merge_records(std::integral_constant<int, 32>{});
-    attn_head_finalize<ADD>(mm, ZZ, q0, q1, out_h, aa.mve, aa.BH, (int)h, aa.head_mz);   // ZZ = 0: no member had a token
-    if (lane == 0) nnz[h] = csum;
-    MP_STAMP_L(stamp, 39);
-    MP_STAMP_FLUSH_L(stamp);
+    cluster_handoff<ADD>(aa, h, rank, clog, m, Z, o0, o1, total, out_h, nnz, stamp);
 }
 
 // LSH::batch_retrieve (optionally with the query hash as its prologue)
