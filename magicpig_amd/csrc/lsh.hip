@@ -744,6 +744,77 @@ struct AttnArgs {
     // cost cfg 1 0.1 us per launch)
 };
 
+// ---- the lean decode's gather (EXPERIMENTS.md R6-1): a wave that is done counting CLAIMS slices of the workgroup's list of selected
+// table words -- SHORT_L entries, one step of the fold, by fetch_add on the list's head -- waits until its slice is reserved in
+// full or nobody counts any more, reads it (the read is the written-yet check: an entry still says -1) and folds its rows into the
+// wave's running softmax; again, until the list is used up.  Returns the entries this wave folded.
+template <int ADL, int SHORT_L>
+__device__ __forceinline__ int lean_claim_and_gather(AhState& st_own, int* s_done, int* s_res, int* s_head, const int32_t* s_ids, int lcap,
+                                                     const uint16_t* kv_l, const float* kn_l, const u32x4& qv_l, const float* qn_lds, int64_t M,
+                                                     int K, int L, uint32_t idmask, int idbits, bool pay,
+                                                     unsigned long long* __restrict__ stamp) {
+    const int lane = threadIdx.x & 63;
+    // entries per claim = one step of the fold (claims of 12 -- what a wave adds on average -- were +0.2 us: a step's cost is
+    // per step, R6-1)
+    const int CL = SHORT_L;
+    int folded = 0;
+    for (;;) {
+        int start = 0, nh = 0;
+        // (the first look at the two counters travels with the claim: one LDS round trip, not two)
+        int done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int res = __hip_atomic_load(s_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) start = __hip_atomic_fetch_add(s_head, CL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        start = __builtin_amdgcn_readfirstlane(start);
+        if (start >= lcap) break;                                    // (beyond the stage: the spill list, below)
+        // until the slice is reserved in full, or nobody counts any more (then `res` is final: a wave's last
+        // reservation precedes its "done", and `done` is read first)
+        for (;;) {
+            if (res >= start + CL || done >= RT_WAVES) break;
+            // a poll is an instruction the counting waves of this SIMD do not issue: far from its turn a wave sleeps longer
+            if (start + CL - res > 2 * CL) __builtin_amdgcn_s_sleep(8);
+            else __builtin_amdgcn_s_sleep(1);
+            done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            res = __hip_atomic_load(s_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        res = __builtin_amdgcn_readfirstlane(res);
+        nh = (res < lcap ? res : lcap) - start;
+        if (nh <= 0) break;
+        nh = nh < CL ? nh : CL;
+        // reserved is not written: the reserving wave stores its entries right behind its atomic.  The gather's own
+        // read of the slice is the check -- row group r of the step reads entries r UPS .. r UPS + UPS - 1 (attn_head_fold_lean);
+        // an entry of the slice that still says "not written" (-1) means: read again.  The fold gets the registers.
+        constexpr int LPRc = ADL / 8, RPLc = 64 / LPRc;
+        u32x4 pre0 = {0u, 0u, 0u, 0u}, pre1 = {0u, 0u, 0u, 0u};      // (two named registers: an array here went to scratch)
+        auto read_slice = [&](auto ups_tag) {
+            constexpr int UPSc = decltype(ups_tag)::value;
+            const int e0 = (lane / LPRc) * UPSc;
+            for (;;) {
+                bool missing = false;
+                pre0 = *reinterpret_cast<const volatile u32x4*>(s_ids + start + e0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) missing = missing || (e0 + e < nh && pre0[e] == 0xffffffffu);
+                if constexpr (UPSc > 4) {
+                    pre1 = *reinterpret_cast<const volatile u32x4*>(s_ids + start + e0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) missing = missing || (e0 + 4 + e < nh && pre1[e] == 0xffffffffu);
+                }
+                if (__ballot(missing) == 0ull) break;            // wave-uniform
+            }
+        };
+        constexpr int UPS_S = SHORT_L / RPLc;                        // entries a row group reads: 4 (or 8: two registers)
+        const int e0s = (lane / LPRc) * UPS_S;
+        auto slice = [&](int j) {                                    // (the fold asks for entries e0 and, UPS = 8, e0 + 4)
+            if constexpr (UPS_S > 4) return (j - e0s) >= 4 ? pre1 : pre0;
+            else return pre0;
+        };
+        read_slice(std::integral_constant<int, UPS_S>{});
+        attn_head_fold_lean<ADL, SHORT_L>(st_own, kv_l, kn_l, qv_l, *qn_lds, nh, M, K, L, 0, 1, slice, idmask, idbits, pay,
+                                          stamp);
+        folded += nh;
+    }
+    return folded;
+}
+
 // ---- emission of a workgroup's selected tokens in ASCENDING order (everything but the lean decode): every thread counts the set
 // bits of its contiguous words of bitmap B, a block-wide exclusive scan gives it its place, and it writes its tokens' ids to the
 // head's row in HBM (`out`: the stand-alone retrieve's result, the decode's by-product), to the gather's stage in LDS (AD > 0:
@@ -1887,64 +1958,8 @@ __device__ __forceinline__ void lsh_head_body(
         constexpr int SHORT_L = (ADL == 128) ? 16 : AH_SLICE;
         // (the launcher uses this form only where a head is a cluster: the step is the short one -- 16 tokens at head_dim 128 --
         // and no 32-token instantiation of the fold sits in this kernel: its registers were the kernel's spills)
-        // entries per claim = one step of the fold (claims of 12 -- what a wave adds on average -- were +0.2 us: a step's cost is
-        // per step, R6-1)
-        const int CL = SHORT_L;
-        int folded = 0;
-        for (;;) {
-            int start = 0, nh = 0;
-            // (the first look at the two counters travels with the claim: one LDS round trip, not two)
-            int done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            int res = __hip_atomic_load(s_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (lane == 0) start = __hip_atomic_fetch_add(s_head, CL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            start = __builtin_amdgcn_readfirstlane(start);
-            if (start >= lcap) break;                                    // (beyond the stage: the spill list, below)
-            // until the slice is reserved in full, or nobody counts any more (then `res` is final: a wave's last
-            // reservation precedes its "done", and `done` is read first)
-            for (;;) {
-                if (res >= start + CL || done >= RT_WAVES) break;
-                // a poll is an instruction the counting waves of this SIMD do not issue: far from its turn a wave sleeps longer
-                if (start + CL - res > 2 * CL) __builtin_amdgcn_s_sleep(8);
-                else __builtin_amdgcn_s_sleep(1);
-                done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                res = __hip_atomic_load(s_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            res = __builtin_amdgcn_readfirstlane(res);
-            nh = (res < lcap ? res : lcap) - start;
-            if (nh <= 0) break;
-            nh = nh < CL ? nh : CL;
-            // reserved is not written: the reserving wave stores its entries right behind its atomic.  The gather's own
-            // read of the slice is the check -- row group r of the step reads entries r UPS .. r UPS + UPS - 1 (attn_head_fold_lean);
-            // an entry of the slice that still says "not written" (-1) means: read again.  The fold gets the registers.
-            constexpr int LPRc = ADL / 8, RPLc = 64 / LPRc;
-            u32x4 pre0 = {0u, 0u, 0u, 0u}, pre1 = {0u, 0u, 0u, 0u};      // (two named registers: an array here went to scratch)
-            auto read_slice = [&](auto ups_tag) {
-                constexpr int UPSc = decltype(ups_tag)::value;
-                const int e0 = (lane / LPRc) * UPSc;
-                for (;;) {
-                    bool missing = false;
-                    pre0 = *reinterpret_cast<const volatile u32x4*>(s_ids + start + e0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) missing = missing || (e0 + e < nh && pre0[e] == 0xffffffffu);
-                    if constexpr (UPSc > 4) {
-                        pre1 = *reinterpret_cast<const volatile u32x4*>(s_ids + start + e0 + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) missing = missing || (e0 + 4 + e < nh && pre1[e] == 0xffffffffu);
-                    }
-                    if (__ballot(missing) == 0ull) break;            // wave-uniform
-                }
-            };
-            constexpr int UPS_S = SHORT_L / RPLc;                        // entries a row group reads: 4 (or 8: two registers)
-            const int e0s = (lane / LPRc) * UPS_S;
-            auto slice = [&](int j) {                                    // (the fold asks for entries e0 and, UPS = 8, e0 + 4)
-                if constexpr (UPS_S > 4) return (j - e0s) >= 4 ? pre1 : pre0;
-                else return pre0;
-            };
-            read_slice(std::integral_constant<int, UPS_S>{});
-            attn_head_fold_lean<ADL, SHORT_L>(st_own, kv_l, kn_l, qv_l, s_rn[1], nh, M, ha.K, L, 0, 1, slice, idmask, idbits, pay,
-                                              stamp);
-            folded += nh;
-        }
+        const int folded = lean_claim_and_gather<ADL, SHORT_L>(st_own, s_done, s_res, s_head, s_ids, lcap, kv_l, kn_l, qv_l, s_rn + 1, M,
+                                                               ha.K, L, idmask, idbits, pay, stamp);
         if (WIN && aa.win_kv != nullptr) {      // the static window: dense slices rank, rank + R, ... over the waves
             int wl = aa.win_len[h];
             wl = wl < 0 ? 0 : (wl > aa.win_M ? (int)aa.win_M : wl);
