@@ -12,511 +12,12 @@
 
 #include "common.h"
 
-namespace mp {
-
-// ---- kernels' host launchers (simhash.hip, lsh.hip, attention.hip)
-int simhash_padded_cols(int K, int L);
-int simhash_supported(int D, int K);
-hipError_t launch_simhash_prepare(const uint16_t*, int, int, int, uint16_t*, uint16_t*, float*, hipStream_t);
-hipError_t launch_simhash_query(const uint16_t*, const uint16_t*, const float*, int, int, int, int,
-                                int32_t*, float*, float*, hipStream_t);
-hipError_t launch_simhash_keys(const uint16_t*, const uint16_t*, const float*, int, int64_t, int,
-                               int, int, int16_t*, hipStream_t);
-size_t retrieve_lds_bytes(int64_t M, int L);
-size_t lsh_lds_limit();
-int lsh_range_len(int64_t M, int R);
-bool lsh_decode_supported(int64_t M, int L, int D, int R);
-bool xcd_round_robin_verified();
-hipError_t launch_lsh_decode(const int32_t*, const int32_t*, const uint16_t*, const uint16_t*, const float*, int,
-                             int, int, int32_t*, float*, int32_t*, int32_t*, const uint16_t*, const float*,
-                             float*, float2*, int*, int*, uint16_t*, float*, float2*, const int32_t*, int, float*, int*,
-                             int, int, bool, const uint16_t*, const int32_t*, int64_t, int, int, int, int, int64_t,
-                             bool, unsigned long long*, unsigned int*, int, int, int, const int*, const int*, const unsigned int*,
-                             const unsigned int*, bool, bool*, const uint16_t*, int, hipStream_t);
-hipError_t set_stamp_stride(int);
-void set_exact_norm(int);
-void set_slot_log2(int);
-hipError_t launch_lsh_slots(const int32_t*, const int32_t*, int32_t*, int, int, int, int64_t, int, hipStream_t);
-int get_slot_log2();
-int lsh_slot_log2(int64_t M, int NB, int R);
-hipError_t launch_lsh_fill(const int16_t*, const int32_t*, int, int64_t, int, int64_t, int, int32_t*,
-                           int32_t*, int*, hipStream_t);
-hipError_t launch_lsh_unsort(const int16_t*, const int32_t*, int, int64_t, int16_t*, int*, hipStream_t);
-hipError_t launch_lsh_subbounds(const int32_t*, int32_t*, int, int, int, int64_t, int, hipStream_t);
-hipError_t launch_lsh_build(const int16_t*, int, int64_t, int, int64_t, int, int32_t*, int32_t*, int*, const float*, int,
-                            int, int*, bool*, bool*, bool, hipStream_t);
-hipError_t launch_lsh_retrieve(const int32_t*, const int32_t*, const int32_t*, int32_t*, int32_t*, int,
-                               int, int, int, int64_t, int, const int*, int32_t*, int32_t*, uint32_t*, hipStream_t);
-hipError_t launch_lsh_attach_norms(int32_t*, const float*, int, int, int64_t, int, int*, hipStream_t);
-hipError_t launch_lsh_hash_retrieve(const int32_t*, const int32_t*, const uint16_t*, const uint16_t*,
-                                    const float*, int, int, int, int32_t*, float*, int32_t*, int32_t*,
-                                    int, int, int, int, int64_t, int, const int*, hipStream_t);
-hipError_t launch_lsh_compact(uint32_t*, const int*, int, int, int64_t, hipStream_t);
-hipError_t launch_lsh_hash_only(const uint16_t*, const uint16_t*, const float*, int, int, int, int32_t*, float*, int, int,
-                                hipStream_t);
-hipError_t launch_lsh_mask(const int32_t*, const int32_t*, const int32_t*, int8_t*, int, int, int, int,
-                           int64_t, int, int, hipStream_t);
-int attn_slices_per_head(int64_t M);
-int attn_supported_head_dim(int D);
-hipError_t launch_attn_sparse(int, bool, bool, const uint16_t*, const float*, const void*, const float*,
-                              const int32_t*, const int32_t*, float*, float2*, int*, uint16_t*, float*,
-                              float2*, float*, int, int, int64_t, int, int, int, bool, hipStream_t);
-bool launch_attn_dense(int, int, bool, const uint16_t*, const void*, const int32_t*, float*, float2*, int*, uint16_t*,
-                       float*, float2*, float*, int, int64_t, int, hipStream_t, hipError_t*);
-hipError_t launch_attn_normalize(float*, const int32_t*, const float2*, int, int64_t, hipStream_t);
-hipError_t launch_attn_fill(const uint16_t*, const uint16_t*, const float*, int, int64_t, int,
-                            int64_t, uint16_t*, float*, hipStream_t);
-hipError_t launch_key_centre_fill(const uint16_t*, const uint16_t*, int64_t, int64_t, int, int, int64_t, double*, int,
-                                  uint16_t*, uint16_t*, float*, hipStream_t);
-hipError_t launch_simhash_keys_strided(const uint16_t*, int64_t, int64_t, const uint16_t*, const float*, int, int64_t,
-                                       int, int, int, int16_t*, hipStream_t);
-hipError_t launch_ragged_offsets(const int32_t*, int, int64_t, int32_t*, hipStream_t);
-hipError_t launch_ragged_copy(bool, int32_t*, int32_t*, const int32_t*, int, int64_t, hipStream_t);
-hipError_t launch_merge_state(const uint16_t*, const float*, const uint16_t*, const float*, int,
-                              int, uint16_t*, float*, hipStream_t);
-hipError_t launch_attn_append(const uint16_t*, const uint16_t*, const int32_t*, int, const uint16_t*, int, int, int, int64_t,
-                              uint16_t*, float*, unsigned int*, int*, hipStream_t);
-bool lsh_hash_only_supported(int L);
-hipError_t launch_attn_ticket_check(int*, int, int*, hipStream_t);
-hipError_t launch_relay(const void*, void*, size_t, hipStream_t);
-hipError_t launch_row_norm(const void*, bool, int, int, float*, float*, void*, hipStream_t);
-hipError_t launch_host_flag(unsigned int*, unsigned int, hipStream_t);
-hipError_t launch_host_rows(const int32_t*, const int32_t*, int32_t*, int64_t, int, const void*, void*, size_t, int,
-                            hipStream_t);
-
-extern unsigned long long* g_stamp;
-
-// ---- error text (thread local)
-static thread_local std::string g_err;
-void set_error(const std::string& msg) { g_err = msg; }
-int fail(int code, const std::string& msg) {
-    g_err = msg;
-    return code;
-}
-
-// ---- debug / A-B options (mp_debug_set_option): process-wide, read at call time
-struct DebugOptions {
-    std::atomic<int> decode_two_launch{0};   // 1: hash+retrieve launch, then attention launch
-    std::atomic<int> decode_cluster{0};      // 0 = auto, else workgroups per head (clamped to [1, min(32, slices)])
-    std::atomic<int> decode_agent_scope{0};  // 1: cluster hand-off through memory even when the XCD placement was observed
-    std::atomic<int> decode_mfma_hash{0};    // 1: query SimHash by the MFMA kernel in a launch of its own, then the decode
-    std::atomic<int> decode_split_hash{-1};  // -1 = auto, 0 = never, 1 = always (clusters on one XCD), 2 = split but nobody publishes (test)
-    std::atomic<int> decode_quad_hash{-1};   // one workgroup per head: -1 = auto, 0 = never, 1 = the heads of an XCD residue hash in quads on the matrix pipe
-    std::atomic<int> decode_direct{-1};      // -1 = auto, 0 = never, 1 = always (when R > 1) keep direct piece slots
-    std::atomic<int> attn_head_kernel{-1};   // -1 = auto, 0 = split-KV kernel, 1 = one workgroup per head
-    std::atomic<int> attn_gx{0};             // 0 = auto, else split-KV workgroups per head
-    std::atomic<int> attn_dense_grouped{1};  // full_attention: 1 = K/V read once per kv group, 0 = once per query head
-    std::atomic<int> decode_kn_payload{1};   // 1: use the key norms attached to the table entries (where attached), 0: one HBM access per token
-    std::atomic<int> host_zero_copy{1};      // MP_MEM_HOST calls: 1 = kernels work on pinned memory in place (the caller's, or the handle's mirror), 0 = staged copies
-    std::atomic<int> host_flag_wait{0};      // MP_MEM_HOST calls: 1 = wait for the stream by spinning on a word a one-thread kernel
-                                             // writes to pinned memory instead of hipStreamSynchronize (A/B, EXPERIMENTS.md R4-5)
-    // counters (read with mp_debug_get_option, reset with mp_debug_set_option(name, 0)): how the MP_MEM_HOST attention
-    // entry served its calls -- a fast path that silently stops hitting shows here (fallbacks must be observable)
-    std::atomic<int> build_rank_exact{0};    // 1: the table build ranks by match-any ballots always (A/B, tests); 0: by the LDS's lane order, verified
-    std::atomic<int> build_rank_fallbacks{0};// counter: builds redone with the exact ranking because a bucket run did not ascend
-    std::atomic<int> build_rank_inject{0};   // test hook: n > 0 = the next n table builds behave as if the fast ranking's check had failed
-    std::atomic<int> host_fast_hits{0};      // the rows batch_retrieve had just handed out were recognised: no index upload
-    std::atomic<int> host_fast_edited{0};    // pairing found, but a row differed from what was handed out: launch dropped, upload path
-    std::atomic<int> host_fast_unpaired{0};  // no pairing (other buffers, other counts, another handle in between): upload path
-    std::atomic<int> host_speculate{1};      // MP_MEM_HOST batch_retrieve enqueues the paired store's attention launch behind its own
-                                             // kernel when the last attention call came with a pinned query tensor (see mp_lsh::Spec)
-    std::atomic<int> host_spec_hits{0};      // counter: attention calls served by the launch the retrieve had issued
-    std::atomic<int> host_spec_misses{0};    // counter: such a launch existed but the call's arguments were not what it had assumed
-    std::atomic<int> host_flag_timeouts{0};  // counter: a completion word did not arrive within ~5 ms (the stream was synchronised instead)
-    // where a MP_MEM_HOST batch_retrieve spends its time, ns summed over the calls since the last reset (scripts/host_mode_times.py):
-    // up to the last launch, waiting for its completion word, copying counts and rows out + bookkeeping
-    std::atomic<int> host_ret_calls{0}, host_ret_ns_enqueue{0}, host_ret_ns_wait{0}, host_ret_ns_copy{0};
-    std::atomic<int> host_copy_prefetch{48}; // the copy of the handed-out rows asks for the NEXT row while it copies one: the whole row up to
-                                             // this many 64-byte lines, the first 8 lines of a longer one; 0 = off (A/B: R6-2)
-};
-static DebugOptions g_opt;
-
-static std::atomic<int>* debug_option(const char* name) {
-    if (!name) return nullptr;
-    if (!strcmp(name, "decode_two_launch")) return &g_opt.decode_two_launch;
-    if (!strcmp(name, "decode_cluster")) return &g_opt.decode_cluster;
-    if (!strcmp(name, "decode_agent_scope")) return &g_opt.decode_agent_scope;
-    if (!strcmp(name, "decode_direct")) return &g_opt.decode_direct;
-    if (!strcmp(name, "decode_split_hash")) return &g_opt.decode_split_hash;
-    if (!strcmp(name, "decode_quad_hash")) return &g_opt.decode_quad_hash;
-    if (!strcmp(name, "decode_mfma_hash")) return &g_opt.decode_mfma_hash;
-    if (!strcmp(name, "attn_head_kernel")) return &g_opt.attn_head_kernel;
-    if (!strcmp(name, "attn_gx")) return &g_opt.attn_gx;
-    if (!strcmp(name, "attn_dense_grouped")) return &g_opt.attn_dense_grouped;
-    if (!strcmp(name, "decode_kn_payload")) return &g_opt.decode_kn_payload;
-    if (!strcmp(name, "host_zero_copy")) return &g_opt.host_zero_copy;
-    if (!strcmp(name, "host_flag_wait")) return &g_opt.host_flag_wait;
-    if (!strcmp(name, "build_rank_exact")) return &g_opt.build_rank_exact;
-    if (!strcmp(name, "build_rank_fallbacks")) return &g_opt.build_rank_fallbacks;
-    if (!strcmp(name, "build_rank_inject")) return &g_opt.build_rank_inject;
-    if (!strcmp(name, "host_fast_hits")) return &g_opt.host_fast_hits;
-    if (!strcmp(name, "host_fast_edited")) return &g_opt.host_fast_edited;
-    if (!strcmp(name, "host_fast_unpaired")) return &g_opt.host_fast_unpaired;
-    if (!strcmp(name, "host_speculate")) return &g_opt.host_speculate;
-    if (!strcmp(name, "host_spec_hits")) return &g_opt.host_spec_hits;
-    if (!strcmp(name, "host_spec_misses")) return &g_opt.host_spec_misses;
-    if (!strcmp(name, "host_flag_timeouts")) return &g_opt.host_flag_timeouts;
-    if (!strcmp(name, "host_copy_prefetch")) return &g_opt.host_copy_prefetch;
-    if (!strcmp(name, "host_ret_calls")) return &g_opt.host_ret_calls;
-    if (!strcmp(name, "host_ret_ns_enqueue")) return &g_opt.host_ret_ns_enqueue;
-    if (!strcmp(name, "host_ret_ns_wait")) return &g_opt.host_ret_ns_wait;
-    if (!strcmp(name, "host_ret_ns_copy")) return &g_opt.host_ret_ns_copy;
-    return nullptr;
-}
-
-// ---- every handle remembers the device that was current when its state was allocated; entry points
-// switch to it for the duration of the call (allocations, launches and memsets then target the owning
-// device whatever the caller's current device is) and restore the caller's device on return
-struct DeviceGuard {
-    int prev = -1;
-    bool switched = false;
-    explicit DeviceGuard(int dev) {
-        if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (switched) (void)hipSetDevice(prev);
-    }
-    DeviceGuard(const DeviceGuard&) = delete;
-    DeviceGuard& operator=(const DeviceGuard&) = delete;
-};
-#define MP_ON_DEVICE(h) ::mp::DeviceGuard _device_guard((h) ? (h)->device : -1)
-
-static int current_device() {
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return -1;
-    return dev;
-}
-
-// ---- small RAII device buffer for staging host arguments
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-    template <class T>
-    T* as() { return reinterpret_cast<T*>(p); }
-};
-
-// Stage `bytes` of a caller buffer into HBM when it lives on the host; device buffers pass through.
-static int stage_in(const void* src, size_t bytes, int mem, DevBuf& buf, const void** out) {
-    if (mem == MP_MEM_DEVICE) {
-        *out = src;
-        return MP_OK;
-    }
-    MP_HIP_CHECK(buf.alloc(bytes));
-    MP_HIP_CHECK(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice));
-    *out = buf.p;
-    return MP_OK;
-}
-
-// Persistent staging of the host-buffer mode: a pinned host block and a device block of the same size, grown on
-// demand and kept by the handle (no hipMalloc / hipFree per call).
-struct Stage {
-    void* hp = nullptr;   // pinned host
-    void* hd = nullptr;   // the same block as the device sees it (kernels read / write it over PCIe)
-    void* dp = nullptr;   // device
-    size_t cap = 0;
-    // host_only: the block is a pinned MIRROR the kernels write over PCIe (hp / hd); no device twin is allocated
-    int reserve(size_t bytes, bool host_only = false) {
-        if (bytes <= cap && (host_only || dp != nullptr)) return MP_OK;
-        size_t want = cap ? cap : 4096;
-        while (want < bytes) want *= 2;
-        release();
-        MP_HIP_CHECK(hipHostMalloc(&hp, want, hipHostMallocMapped));
-        if (!host_only) MP_HIP_CHECK(hipMalloc(&dp, want));
-        if (hipHostGetDevicePointer(&hd, hp, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            hd = nullptr;                      // no alias: callers fall back to copies
-        }
-        cap = want;
-        return MP_OK;
-    }
-    void release() {
-        if (hp) (void)hipHostFree(hp);
-        if (dp) (void)hipFree(dp);
-        hp = dp = hd = nullptr;
-        cap = 0;
-    }
-};
-
-// Host-buffer mode: waiting for the stream.  hipStreamSynchronize costs ~10 us from the kernel's end to the caller's next
-// instruction; the `host_flag_wait` option instead has a one-thread kernel write a sequence number to a pinned word behind
-// the call's launches and spins on it (PCIe posted writes of one device arrive in order: what the launches wrote to pinned
-// memory is there when the word is).  Falls back to the synchronisation after 5 ms.
-struct HostFlag {
-    unsigned int* hp = nullptr;   // pinned word
-    unsigned int* hd = nullptr;   // as the device sees it
-    unsigned int seq = 0;
-    // arm: a one-thread kernel on `st` writes the next sequence number to the pinned word (0 = could not be armed);
-    // reached: spin until the word has got there (false after ~5 ms: the caller synchronises the stream instead).  A call may
-    // arm a word in the MIDDLE of what it enqueues and wait for that point only (capi.hip: the speculative attention launch).
-    unsigned int arm(hipStream_t st) {
-        if (hp == nullptr) {
-            void* p = nullptr;
-            if (hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess) {
-                hp = reinterpret_cast<unsigned int*>(p);
-                *hp = 0u;
-                void* d = nullptr;
-                if (hipHostGetDevicePointer(&d, p, 0) == hipSuccess) hd = reinterpret_cast<unsigned int*>(d);
-            }
-            if (hd == nullptr) (void)hipGetLastError();
-        }
-        if (hd == nullptr) return 0u;
-        if (++seq == 0u) ++seq;
-        if (launch_host_flag(hd, seq, st) != hipSuccess) {
-            (void)hipGetLastError();
-            return 0u;
-        }
-        return seq;
-    }
-    bool reached(unsigned int want) const {
-        if (want == 0u || hp == nullptr) return false;
-        volatile unsigned int* f = hp;
-        for (long it = 0; it < 5000000L; ++it) {          // ~5 ms
-            if ((int)(*f - want) >= 0) return true;       // (a later number has passed it)
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
-        return false;
-    }
-    int wait(hipStream_t st, bool spin) {
-        if (spin && reached(arm(st))) return MP_OK;
-        MP_HIP_CHECK(hipStreamSynchronize(st));
-        return MP_OK;
-    }
-    void release() {
-        if (hp) (void)hipHostFree(hp);
-        hp = hd = nullptr;
-    }
-};
-
-// Host-buffer mode without copies: the address at which a KERNEL can read / write a caller's host buffer in place.
-// The reference's callers hold pinned tensors (models/attnserver.py:59-66: hipHostMalloc through torch's pin_memory):
-// those are mapped already.  A PAGEABLE buffer (results_lsh_cpu and nnz, :59-60) is never touched by a kernel: the kernels
-// work on a pinned mirror owned by the handle and the host copies the live entries across.  (Rounds 2-3 could also
-// REGISTER a pageable buffer -- hipHostRegister, the opt-in `host_register` mode; the full GPU suite aborted twice inside
-// the ROCm runtime with it, and round 4's hunt -- scripts/experiments/stress_host_register.py: registrations that outlive,
-// or are outlived by, their buffers, heap-resident and really unmapped ones, 150 iterations each, under rocgdb -- reproduced
-// neither the aborts nor a wrong result.  A mode whose failure cannot be explained does not ship: removed, EXPERIMENTS.md
-// R4-6.)  nullptr = not mapped.
-struct HostMap {
-    const void* last_pageable = nullptr;   // the last pointer found to be plain pageable memory (negative results only
-                                           // are remembered: treating pinned memory as pageable is merely slower)
-    void* resolve(const void* ptr, size_t /*bytes*/) {
-        if (ptr == last_pageable) return nullptr;   // (the failing lookup below costs microseconds per call)
-        hipPointerAttribute_t a;
-        if (hipPointerGetAttributes(&a, ptr) == hipSuccess) {
-            if (a.type == hipMemoryTypeHost && a.devicePointer != nullptr) return a.devicePointer;
-            if (a.type != hipMemoryTypeUnregistered) return nullptr;   // device / managed memory passed as "host"
-        } else {
-            (void)hipGetLastError();                               // pageable memory: "invalid value" on older runtimes
-        }
-        last_pageable = ptr;
-        return nullptr;
-    }
-    void release() { last_pageable = nullptr; }
-};
-
-constexpr int FILL_BLOCKS = 1024;   // row blocks of mp_attn_fill_offload's column sums
-constexpr int MAX_CLUSTER = MP_CLUSTER_MAX;   // workgroups per query head of the one-launch decode, at most
-
-static int alloc_zero(void** p, size_t bytes) {
-    MP_HIP_CHECK(hipMalloc(p, bytes ? bytes : 1));
-    MP_HIP_CHECK(hipMemset(*p, 0, bytes));
-    return MP_OK;
-}
-
-}  // namespace mp
+#include "capi_launchers.h"
+#include "capi_support.h"
 
 using namespace mp;
 
-// =================================================================== handle state
-
-struct mp_simhash {
-    int device = -1;          // device of the planes (current device at mp_simhash_set_planes)
-    int D = 0, K = 0, L = 0, KLpad = 0;
-    uint16_t* Wt = nullptr;   // [KLpad][D]        plane-major  (MFMA B operand)
-    uint16_t* Wk = nullptr;   // [D/8][KLpad][8]   chunk-major  (hash fused into the retrieve)
-    float* wnorm = nullptr;   // [KLpad]
-    float* dbg_acc = nullptr; // optional debug sink (set by mp_simhash_debug_acc)
-};
-
-struct mp_lsh {
-    int device = -1;               // device of all state (current device at mp_lsh_alloc)
-    bool allocated = false;
-    int K = 0, L = 0, NB = 0, layers = 0, H = 0, Hkv = 0, B = 0, G = 0;
-    int64_t M = 0;
-    std::vector<int> idbits_of;    // per layer: 17 while every id of the layer's tables is < 2^17 (the bits above carry a
-                                   // token's key norm once packed), 0 once a fill brought a wider id (lsh_widen)
-    std::vector<std::vector<uint32_t>> att_ver;   // [layers][B]: version of the store's norms the rows of (layer, request) carry (0: none)
-    int* idbits_dev = nullptr;                    // [layers] idbits_of on the device, written in stream order
-    unsigned int* att_ver_dev = nullptr;          // [layers][B][Hkv] the same on the device, written in stream order:
-                                                  // what the decode kernel compares with the store's kn_ver_dev
-    int* pay_bad = nullptr;        // [layers][B][Hkv] device flags: a norm of the KV group could not be packed (decode reads them)
-    int R = 1;                     // token ranges per table row = workgroups per head of the decode kernel
-    int range_len = 0;             // tokens per range (multiple of 32)
-    std::vector<int32_t*> bounds;  // per layer [B*Hkv][L][NB][R+1]
-    std::vector<int32_t*> table;   // per layer [B*Hkv][L][M]
-    std::vector<int32_t*> slots;   // per layer [B*Hkv][L][NB][R][slot_words] direct piece slots, or empty (R = 1 / long pieces)
-    int slot_words = 32;           // words per slot: 32, 16 or 8 by the mean piece length (lsh_slot_log2)
-    int slot_log2 = 5;             // its log2: fixed at alloc, handed to the builder and the reader
-    unsigned long long* xw = nullptr;   // [BH][xwords] split hash: (launch sequence << 32 | 32 sign bits) (R > 1)
-    unsigned int* xseq = nullptr;  // [BH] split hash: sequence number of the next launch
-    int xwords = 0;
-    Stage small, big;              // host-buffer mode: (codes | nnz | offsets | row checksums) and the packed result rows
-    HostMap hostmap;               // host-buffer mode: caller buffers the kernels use in place
-    HostFlag hostflag;             // host-buffer mode: completion word (host_flag_wait)
-    // host-buffer mode: what the last MP_MEM_HOST batch_retrieve handed to its caller -- the caller's pointers, the counts
-    // and a position-weighted checksum of every row -- while `results` / `nnz` (HBM) still hold the same rows.  The
-    // attention entry of the paired store recognises the `ind` / `nnz` it is given by them and reads the HBM copy instead
-    // of uploading the rows it was just handed (models/attnserver.py:299-300 passes results_lsh_cpu straight on).
-    struct HostRetrieve {
-        bool valid = false;
-        const void* results = nullptr;
-        const void* nnz = nullptr;
-        std::vector<int32_t> nnzv;
-        std::vector<uint32_t> sums;        // [BH][2]: sum of row_mix(id + 1, position + 1), sum of (id + 1) (position + 1), mod 2^32
-        const int32_t* kept = nullptr;     // [BH][M] the handle's pinned mirror when the caller's rows are pageable: the rows as
-                                           // the kernel wrote them, compared EXACTLY (memcmp) with what the caller hands on;
-                                           // nullptr when the kernel wrote the caller's pinned rows directly (checksums then)
-    } host_ret;
-    // the HBM copy of the rows / counts a MP_MEM_HOST batch_retrieve hands out.  Buffers of their OWN (allocated at the
-    // first such call), not the decode path's step buffers `results` / `nnz`: an mp_decode_* launch -- eager, or replayed
-    // from a captured graph, which the host never sees -- rewrites those in stream order, and the attention entry would
-    // attend over the graph's rows while the caller's (unchanged) rows still pass the comparison.  Only the
-    // host-mode retrieve writes these, and it forgets the pairing first.
-    int32_t* hr_rows = nullptr;    // [BH][M]
-    int32_t* hr_nnz = nullptr;     // [BH]
-    // Speculation (round 6).  The reference's caller hands attention_wrapper the SAME pinned query / output / max_value_expsum
-    // tensors every step, and fills the query tensor BEFORE it calls batch_retrieve (models/attnserver.py:59-66, 273, 299-300).
-    // So when the paired store's last MP_MEM_HOST attention call came with a pinned query tensor, the next host-mode
-    // batch_retrieve enqueues that store's attention launch right behind its own kernel -- reading q from the remembered
-    // tensor, ||q|| from a row-norm kernel, the rows from hr_rows -- and the two calls cost ONE wait.  The attention call
-    // then only checks that it is the call the launch assumed (same store, layer, K, L, dtype, query pointer AND bytes,
-    // the caller's ||q|| within 2e-6 of the kernel's, rows untouched) and copies the outputs out of its pinned block;
-    // anything else: the launch's outputs are dropped and the call is served as before.
-    struct Spec {
-        mp_attn_t* attn = nullptr;         // the store whose last host-mode attention call paired with this handle's rows
-        const void* q_host = nullptr;      // its query tensor (pinned, mapped)
-        int q_dtype = 0, K = 0, L = 0;
-        bool launched = false;             // the last batch_retrieve issued the attention launch
-        int layer = -1;
-        unsigned long long attn_seq = 0;   // attn->host_seq when it did: another call on the store since then owns its pinned block
-        size_t q_bytes = 0;                // bytes of the query snapshot in the store's pinned block (AttnHostLayout::o_qsnap)
-        bool prepared = false;             // the query's copy + norms are enqueued (in front of the retrieve kernel)
-        unsigned int done_flag = 0;        // the store's completion word behind the launch (0: synchronise `stream` instead)
-        hipStream_t stream = nullptr;
-    } spec;
-    bool hr_refused = false;       // the copy does not fit the accelerator budget: host-mode retrieves take the staged path
-    int ret_users = 0;             // attention calls that are working on hr_rows / host_ret right now (under g_host_ret_mu)
-    int64_t accel_budget = -1;     // HBM the accelerator structures (direct slots, hr_rows) may take over all layers; < 0: a third of
-                                   // what is free when they are allocated (mp_lsh_alloc's rule)
-    int64_t accel_used = 0;        // ... and what they hold
-    int32_t* last_query = nullptr; // [BH][L] staging copy of host-side query codes
-    const int32_t* lastq = nullptr;// device codes of the last retrieve (for get_mask): last_query,
-                                   // `codes`, or the caller's own device buffer (valid until it changes)
-    int last_layer = -1;
-    bool last_lean = false;        // the last call was a decode without by-products: no codes to recompute the mask from
-    int* err = nullptr;            // device-side validation flag
-    // device-resident step buffers of the fused decode path
-    int32_t* codes = nullptr;      // [BH][L]
-    int32_t* results = nullptr;    // [BH][M]
-    int32_t* nnz = nullptr;        // [BH]
-    float* qnorm = nullptr;        // [BH]
-};
-
-struct mp_attn {
-    int device = -1;               // device of all state (current device at mp_attn_alloc)
-    bool allocated = false;
-    int layers = 0, H = 0, Hkv = 0, D = 0, B = 0, G = 0;
-    int64_t M = 0;
-    std::vector<uint16_t*> kv;     // per layer [B*Hkv][M][2][D]
-    std::vector<float*> kn;        // per layer [B*Hkv][M]
-    std::vector<std::vector<uint32_t>> kn_ver;   // [layers][B]: a process-wide unique number, renewed whenever a fill rewrites
-                                                 // the slot's norms
-    unsigned int* kn_ver_dev = nullptr;          // [layers][B][Hkv] the same on the device (written in stream order)
-    float* score = nullptr;        // [BH][M] logits -> probabilities on demand
-    float* part_o = nullptr;       // [max_slices][D]
-    float2* part_ml = nullptr;     // [max_slices]
-    float2* head_mz = nullptr;     // [BH] (max logit, Z) of the last call
-    int* head_cnt = nullptr;       // [BH] arrival tickets of the in-launch merge (zero between calls)
-    int* part_cnt = nullptr;       // [BH][MAX_CLUSTER] selected tokens of every cluster member in the last one-launch decode (owned
-                                   // here, not by the lsh handle: get_score compacts the score rows with it later)
-    int* err = nullptr;            // device-side validation flag (append past max_length)
-    double* colsum = nullptr;      // [FILL_BLOCKS][Hkv*D] scratch of mp_attn_fill_offload
-    Stage small, big;              // host-buffer mode: (q | qn | nnz | offsets | out | mve) and the packed index rows
-    HostMap hostmap;               // host-buffer mode: caller buffers the kernels use in place
-    HostFlag hostflag;             // host-buffer mode: completion word (host_flag_wait)
-    unsigned long long host_seq = 0;   // MP_MEM_HOST attention calls (and speculative launches) on this store: each owns the pinned block
-    float* spec_qn = nullptr;      // [BH] ||q|| of a speculative launch (device)
-    float* score_alt = nullptr;    // [BH][M], [BH]: where a speculative launch leaves its logits and (max, Z) -- the caller-visible
-    float2* head_mz_alt = nullptr; // state (get_score of the LAST attention call) changes hands only when the launch is accepted
-    std::vector<mp_lsh_t*> spec_owners;   // LSH handles whose spec.attn points here (cleared on destroy, under g_host_ret_mu)
-    int32_t* ind_rows = nullptr;   // host-buffer mode: [BH][M] device copy of `ind`
-    int32_t* last_nnz = nullptr;   // [BH] staging copy of host-side nnz
-    std::vector<int32_t> lastz_host;   // host-buffer fast path: the counts of the last call as the caller held them; get_score
-                                       // uploads them into last_nnz on demand (lastz == nullptr then) -- the lsh handle's device
-                                       // copy the kernel read does not outlive that handle's next call
-    const int32_t* lastz = nullptr;// device nnz of the last call (for get_score): last_nnz or the
-                                   // caller's own device buffer (valid until it changes)
-    int score_state = 0;           // 0 none, 1 logits, 2 probabilities
-    const int* seg_cnt = nullptr;  // score rows are in R segments (decode kernel, R > 1): per-member counts,
-    int seg_R = 1;                 // compacted on demand by mp_attn_get_score
-    int grid = 8;                  // workgroups per head of the partial kernel (grid.x)
-    bool head_kernel = false;      // one workgroup per head (attn_head_kernel) instead of split-KV
-    bool xcd_rr = false;           // block b -> XCD b % 8 observed on this device (xcd_round_robin_verified)
-    int cus = 256;
-};
-
-// the lsh handle whose last MP_MEM_HOST batch_retrieve is still described by its host_ret (nullptr: none); written
-// by that handle's calls, read by the attention entry.  Handles are not thread-safe (as the reference's objects);
-// the mutex only keeps a destroy on another thread from racing the lookup.
-static std::mutex g_host_ret_mu;
-static std::condition_variable g_host_ret_cv;
-static mp_lsh_t* g_host_ret_lsh = nullptr;
-// (waits until no attention call works on this handle's hr_rows any more: such a call holds a USE COUNT on the handle,
-// not the mutex, while its kernel runs -- calls on other handles, other GPUs, are not serialised behind it: ADVICE r05)
-static void host_ret_forget(mp_lsh_t* h) {
-    std::unique_lock<std::mutex> lock(g_host_ret_mu);
-    if (h) {
-        g_host_ret_cv.wait(lock, [h] { return h->ret_users == 0; });
-        h->host_ret.valid = false;
-    }
-    if (g_host_ret_lsh == h) g_host_ret_lsh = nullptr;
-}
-// checksum of the first n entries of a row, two u32 sums with wrap-around -- what the retrieve kernel leaves per row
-// (lsh.hip: rowsum): a non-linear mix of (entry, position) and the position-weighted linear sum.  32-bit lanes on
-// purpose: the loop vectorises (vpmulld); it runs while the attention kernel does.  Used only where the kernel wrote the
-// caller's PINNED rows (no kept copy to compare with); pageable rows are compared exactly with the handle's mirror.
-#if defined(__x86_64__)
-__attribute__((target("avx2")))
-static void host_row_sum_avx2(const int32_t* row, int64_t n, uint32_t* s1, uint32_t* s2) {
-    uint32_t a = 0u, b = 0u;
-    for (int64_t j = 0; j < n; ++j) {
-        const uint32_t v = (uint32_t)row[j] + 1u;
-        a += row_mix(v, (uint32_t)(j + 1));
-        b += v * (uint32_t)(j + 1);
-    }
-    *s1 = a;
-    *s2 = b;
-}
-#endif
-static void host_row_sum(const int32_t* row, int64_t n, uint32_t* s1, uint32_t* s2) {
-#if defined(__x86_64__)
-    static const bool avx2 = __builtin_cpu_supports("avx2");
-    if (avx2) return host_row_sum_avx2(row, n, s1, s2);
-#endif
-    uint32_t a = 0u, b = 0u;
-    for (int64_t j = 0; j < n; ++j) {
-        const uint32_t v = (uint32_t)row[j] + 1u;
-        a += row_mix(v, (uint32_t)(j + 1));
-        b += v * (uint32_t)(j + 1);
-    }
-    *s1 = a;
-    *s2 = b;
-}
+#include "capi_handles.h"
 
 extern "C" {
 
