@@ -27,5 +27,6 @@ timeout 300 python scripts/stress_cluster.py cfg4 40 contend lean 2>&1 | grep -v
   echo "=== cfg4 MP_LEAN=1"; MP_LEAN=1 timeout 300 python scripts/phase_spread.py cfg4 6 randn graph 30 2>&1 | grep -v amdgpu.ids; } > $out/${tag}_phase_spread_final.txt 2>&1
 echo "phase spread t=$(( $(date +%s) - t0 ))"
 python scripts/host_mode_times.py cfg1 2>&1 | grep -v amdgpu.ids > $out/${tag}_host_mode_times.txt; tail -12 $out/${tag}_host_mode_times.txt
+timeout 300 python scripts/key_hash_time.py build product 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_prefill_times.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2
 echo "done t=$(( $(date +%s) - t0 ))"
