@@ -359,7 +359,7 @@ __device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ 
 // order, which is token order.  That order is not architecturally promised, so it is VERIFIED: the write-out checks that
 // neighbouring entries of a bucket's run ascend and raises err bit 64 otherwise; the host then rebuilds the request with the
 // exact ranking (match-any ballots over the code's bits: ~75 vector instructions per token -- the kernel was bound by VALU
-// issue: 319 M wave-instructions per launch at cfg 1 = 0.52 ms of issue slots alone, profiles/r05_pmc_sq_insts_cfg1.md).
+// issue: 319 M wave-instructions per launch at cfg 1 = 0.52 ms of issue slots alone, profiles/archive/r05_pmc_sq_insts_cfg1.md).
 template <int TPL, bool PACK = false, bool FAST = false>   // tokens per lane and tile: T = TPL * blockDim.x
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsh_build_kernel(   // 16 waves per CU either way: 128 VGPRs
     const int16_t* __restrict__ codes,   // [Hkv*L][n] unsorted
@@ -1820,7 +1820,7 @@ __device__ __forceinline__ void lsh_head_body(
     // its mean; mean 32 ids at cfg 2 / 3), so ~4 % of the pieces are longer than 64 ids, almost every workgroup holds a
     // wave with such a piece, and the launch waits for the workgroup that paid the second dependent round trip.  Now both
     // chunks of all of a wave's pieces are requested before anything is applied: cfg 3 29.06 -> 28.43 us per layer, cfg 2
-    // 32.36 -> 31.71, cfg 2 on clustered keys 41.42 -> 40.70 (same box, alternating regions: profiles/r05_ab_stream_variants.txt).
+    // 32.36 -> 31.71, cfg 2 on clustered keys 41.42 -> 40.70 (same box, alternating regions: profiles/archive/r05_ab_stream_variants.txt).
     // The loads go through ONE buffer descriptor over the KV group's table rows: a lane past its piece gets an offset
     // beyond num_records, for which the hardware returns 0 WITHOUT a memory request -- the second-chunk loads of the 96 %
     // short pieces cost an instruction slot and no line (clamped addresses, the form used where a pointer is needed,
