@@ -308,6 +308,12 @@ int mp_debug_xcd_round_robin(void);
  *                        served as without the option.  0 = never
  *   "host_spec_hits" / "host_spec_misses"   COUNTERS: attention calls served by such a launch / launches whose assumptions the
  *                        call did not meet
+ *   "host_copy_prefetch" MP_MEM_HOST mp_lsh_batch_retrieve with pageable `results`: while a row is copied out of the handle's
+ *                        pinned mirror the NEXT row is prefetched -- whole where it is at most this many 64-byte lines (default
+ *                        48), its first 8 lines otherwise; 0 = no prefetch (A/B: EXPERIMENTS.md R6-2)
+ *   "host_ret_calls", "host_ret_ns_enqueue" / "_wait" / "_copy"   COUNTERS (reset by setting 0): zero-copy MP_MEM_HOST
+ *                        batch_retrieve calls, and the nanoseconds they spent up to their last launch, waiting for their
+ *                        completion word, copying counts and rows out (int: good for ~40 000 calls between resets)
  *   "simhash_exact_norm" 1 = the fused query hash normalises the row by the exact f64 sequence always (A/B, tests);
  *                        0 (default) = a fast f32 form with the exact sequence as its fallback: identical codes
  *   "decode_cluster"     0 = auto, else workgroups per query head of the one-launch decode (1 .. 32); read by mp_lsh_alloc

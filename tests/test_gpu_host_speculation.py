@@ -52,10 +52,10 @@ def _close(a, b):
 class Caller:
     """The tensors of models/attnserver.py:59-66, allocated once."""
 
-    def __init__(self, c, pin_results):
+    def __init__(self, c, pin_results, query_dtype=torch.bfloat16):
         BH, M, D, L = c["BH"], c["M"], c["D"], c["L"]
         self.codes = torch.zeros((BH, L), dtype=torch.int32).pin_memory()
-        self.query = torch.zeros((BH, D), dtype=torch.bfloat16).pin_memory()
+        self.query = torch.zeros((BH, D), dtype=query_dtype).pin_memory()
         self.results = torch.zeros((BH, M), dtype=torch.int32)
         self.nnz = torch.zeros((BH,), dtype=torch.int32)
         if pin_results:
@@ -187,3 +187,49 @@ def test_handles_destroyed_in_either_order(mp):
             del c["srv"]
             c["lsh"].batch_retrieve(0, caller.codes, caller.results, caller.nnz)     # no store to launch for any more
         torch.cuda.synchronize()
+
+
+def test_row_copy_prefetch_and_the_call_timers(mp):
+    """Round 6, second pass on the retrieve call (EXPERIMENTS.md R6-2): the copy of the handed-out rows into the caller's pageable
+    tensor prefetches the next row -- an option that changes nothing but time -- and the call's three phases are counted."""
+    import magicpig_amd._lib as L_
+
+    c = _setup(mp, layers=1)
+    caller = Caller(c, False)
+    q = bf16_t(c["qb"], "cuda")
+    codes, want_out, want_mve, want_nnz = _device_entry(c, 0, q)
+    default = L_.get_option("host_copy_prefetch")
+    assert default == 48
+    try:
+        rows = []
+        for lines in (0, 8, 48, 100000):
+            L_.set_option("host_copy_prefetch", lines)
+            for k in ("host_ret_calls", "host_ret_ns_enqueue", "host_ret_ns_wait", "host_ret_ns_copy"):
+                L_.set_option(k, 0)
+            caller.results.zero_()
+            out, mve, nnz = caller.layer(c, 0, q, codes)
+            assert torch.equal(nnz, want_nnz) and _close(out, want_out)
+            rows.append(caller.results.clone())
+            assert L_.get_option("host_ret_calls") == 1
+            assert all(L_.get_option("host_ret_ns_" + k) > 0 for k in ("enqueue", "wait", "copy"))
+        for r in rows[1:]:
+            assert torch.equal(r, rows[0])
+    finally:
+        L_.set_option("host_copy_prefetch", default)
+
+
+def test_f32_query_tensor_is_served_by_the_launch_ahead_too(mp):
+    """mp_attn_sparse takes f32 queries as well (MP_DTYPE_F32): the snapshot, the host-side norms and the launch follow the dtype."""
+    import magicpig_amd._lib as L_
+
+    c = _setup(mp, layers=1)
+    caller = Caller(c, False, query_dtype=torch.float32)
+    _counters(L_, reset=True)
+    for step in range(4):
+        q = bf16_t(np.roll(c["qb"], step, axis=0), "cuda")
+        codes, want_out, want_mve, want_nnz = _device_entry(c, 0, q)
+        out, mve, nnz = caller.layer(c, 0, q, codes)          # (query.copy_ widens the bf16 rows: the same values in f32)
+        assert torch.equal(nnz, want_nnz)
+        assert _close(out, want_out) and np.allclose(mve[1], want_mve[1], atol=1e-3)
+    hits, misses, fast = _counters(L_)
+    assert fast == 4 and hits == 3 and misses == 0
