@@ -1031,8 +1031,10 @@ int mp_attn_fill_offload(mp_attn_t* h, mp_simhash_t* s, int layer_id, int reques
     MP_HIP_CHECK(launch_key_centre_fill(key_cache, value_cache, num_sink, n, h->Hkv, h->D, h->M, h->colsum, nblk,
                                         avg_k, kv, knd, st));
     if (codes != nullptr)   // key SimHash straight from the store's (centred) K rows: row stride 2D, head stride M*2D
+        // (the rows' norms are in the store already -- kn: the bf16 rounding of the exact norm of the stored row -- so the
+        // kernel's guard band takes them from there instead of summing every row's squares again)
         MP_HIP_CHECK(launch_simhash_keys_strided(kv, h->M * 2 * h->D, 2 * h->D, s->Wt, s->wnorm, h->Hkv, n, s->D,
-                                                 s->K, s->L, codes, st));
+                                                 s->K, s->L, codes, knd, h->M, st));
     return MP_OK;
 }
 

@@ -60,7 +60,7 @@ hipError_t launch_attn_fill(const uint16_t*, const uint16_t*, const float*, int,
 hipError_t launch_key_centre_fill(const uint16_t*, const uint16_t*, int64_t, int64_t, int, int, int64_t, double*, int,
                                   uint16_t*, uint16_t*, float*, hipStream_t);
 hipError_t launch_simhash_keys_strided(const uint16_t*, int64_t, int64_t, const uint16_t*, const float*, int, int64_t,
-                                       int, int, int, int16_t*, hipStream_t);
+                                       int, int, int, int16_t*, const float*, int64_t, hipStream_t);
 hipError_t launch_ragged_offsets(const int32_t*, int, int64_t, int32_t*, hipStream_t);
 hipError_t launch_ragged_copy(bool, int32_t*, int32_t*, const int32_t*, int, int64_t, hipStream_t);
 hipError_t launch_merge_state(const uint16_t*, const float*, const uint16_t*, const float*, int,

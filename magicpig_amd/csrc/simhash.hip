@@ -258,7 +258,7 @@ constexpr int SK_MAX_SETS = 4;            // plane sets (32 planes each) per wav
 constexpr int SK_MAX_TABLES = 64;
 __host__ __device__ constexpr int sk_sets(int D) { return D <= 128 ? 4 : 2; }   // 128 VGPRs of plane fragments either way
 
-template <int D>
+template <int D, bool NORMS = false>     // NORMS: the rows' norms are given (the attention store's kn: bf16-rounded, within 2^-9)
 __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void simhash_keys_kernel(
     const uint16_t* __restrict__ x,       // bf16 (centred keys): row r of head h at x + h*head_stride + r*row_stride
     int64_t head_stride, int64_t row_stride,   // elements: n*D, D for keys [heads][n][D]; M*2D, 2D for the K|V store
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const float* __restrict__ wnorm,      // [KLpad]
     int64_t n, int K, int L, int tables_per_wg, int tiles_per_wg, int chunk_tiles, int wgs_x, int chunks,
     int heads, int groups,                    // persistent: `groups` groups of wgs_x workgroups per XCD walk the units
+    const float* __restrict__ rnorm, int64_t rnorm_stride,   // NORMS: row r of head h has norm rnorm[h * rnorm_stride + r]
     int16_t* __restrict__ codes,              // [heads][L][n]
     unsigned long long* __restrict__ stamp) {
     constexpr int KSTEPS = D / 16;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const int CROWS = chunk_tiles * SH_ROWS;
     __shared__ __attribute__((aligned(16))) uint16_t s_x[2][SH_ROWS * STRIDE];
     __shared__ float s_rn[2][SH_ROWS];
+    __shared__ __attribute__((aligned(16))) float s_rnall[NORMS ? SK_CH_MAX * SH_ROWS : 1];    // NORMS: the unit's row norms
     constexpr int BW = SK_WAVES * SETS + 1;       // words of the sign matrix per row: one per column tile + one of slack
     __shared__ uint32_t s_queue[SK_QCAP];
     __shared__ int s_qn;
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const int table0 = colgrp * tables_per_wg;
     const int col0 = table0 * K, KL = K * L;   // col0 is NOT tile aligned: Wt is row-per-plane, any start works
     const uint16_t* xh = x + (int64_t)(unit / chunks) * head_stride;          // the unit whose tiles are being LOADED
+    const float* rnh = NORMS ? rnorm + (int64_t)(unit / chunks) * rnorm_stride : nullptr;
     int64_t row_base = (int64_t)(unit % chunks) * CROWS;
     MP_STAMP(stamp, 40);
 
@@ -353,9 +356,13 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
         // a uniform base (the unit's first row) + a 32-bit element offset per lane: a unit is <= 1 024 rows of <= 512 elements
         const uint16_t* ubase = xh + row_base * row_stride;
         const int lim = (int)(last_row - row_base);                       // last row of the head, relative to the unit
+        // (the row of this thread inside a tile, recomputed per call behind an opaque move: hoisted out of the unit loop its
+        // variants -- + 16, + 32 per q and tile parity -- lived in registers across the whole tile loop and were spilled)
+        int rt = tid / CPR;
+        asm volatile("" : "+v"(rt));
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
-            int r = t * SH_ROWS + (tid / CPR) + q * (NTHR / CPR);
+            int r = t * SH_ROWS + rt + q * (NTHR / CPR);
             r = r < lim ? r : lim;
             const uint32_t off = (uint32_t)r * (uint32_t)row_stride + (uint32_t)((tid % CPR) * 8);
             sreg[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ubase + off));
@@ -366,6 +373,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
         for (int q = 0; q < QN; ++q) {
             const int row = (tid / CPR) + q * (NTHR / CPR);
             *reinterpret_cast<u32x4*>(&s_x[buf][row * STRIDE + (tid % CPR) * 8]) = sreg[q];
+            if constexpr (NORMS) continue;           // (the unit's norms are in s_rnall: below)
             float ss = 0.f;
             dot8_bf16_chain(ss, sreg[q], sreg[q]);        // sum of squares of the chunk's 8 elements
             dot_settle(ss);
@@ -459,7 +467,8 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     auto compute = [&](int t) {
         const int buf = t & 1;
         const uint16_t* brow = &s_x[buf][(lane & 31) * STRIDE + (lane >> 5) * 8];
-        const float rn = s_rn[buf][lane & 31];
+        // (NORMS: an upper bound of ||row|| -- the store's norm is the bf16 rounding of the exact one)
+        const float rn = NORMS ? s_rnall[t * SH_ROWS + (lane & 31)] * 1.005f : s_rn[buf][lane & 31];
         constexpr bool KEEP = KSTEPS <= 8;                 // head_dim 256: 64 registers of fragments do not fit next to the planes'
         bf16x8 xb[KEEP ? KSTEPS : 1];
         if constexpr (KEEP) {
@@ -503,8 +512,21 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     // prologue: tile 0 staged, tile 1 in registers.  Two register sets: the rows of tile t+2 are
     // requested while tile t is on the matrix pipe and written to LDS one phase later.
     u32x4 s0[QN], s1[QN];
+    // NORMS: the norms of a unit's rows (<= 1 024 floats) go from the store straight into LDS (buffer_load ... lds: no register
+    // holds them) -- requested with the unit's first two tiles, i.e. for the next unit in front of the current unit's flush,
+    // behind the tile loop's closing barrier (nobody reads the current unit's norms any more); the barrier in front of the
+    // unit's first tile waits for them (vmcnt) like for everything else.  Rows past the head's end read as 0 (out of range).
+    auto norms_load = [&]() {
+        const int64_t left = n - row_base;
+        const int rows = (int)(left < (int64_t)CROWS ? left : (int64_t)CROWS);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rnh + row_base), 0, rows * 4, 0x00020000);
+        for (int c = wave; c * WAVE < CROWS; c += SK_WAVES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (__attribute__((address_space(3))) void*)(s_rnall + c * WAVE), 4, lane * 4,
+                                                     c * WAVE * 4, 0, 0);
+    };
     tile_load(0, s0);
     tile_load(1, s1);
+    if constexpr (NORMS) norms_load();
     for (;;) {
     const uint16_t* const xcur = xh;                      // the unit being computed and flushed in this iteration
     const int64_t row_base_cur = row_base;
@@ -540,9 +562,11 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const bool more = unit < units;                       // uniform
     if (more) {
         xh = x + (int64_t)(unit / chunks) * head_stride;
+        if constexpr (NORMS) rnh = rnorm + (int64_t)(unit / chunks) * rnorm_stride;
         row_base = (int64_t)(unit % chunks) * CROWS;
         tile_load(0, s0);
         tile_load(1, s1);
+        if constexpr (NORMS) norms_load();
     }
 
     // exact pass over the queued candidates: one 16-lane group per candidate
@@ -741,7 +765,7 @@ static void keys_chunk_tiles(int64_t n, int wgs_x, int heads, int sets, int& chu
 // round of one head is filled by the next
 hipError_t launch_simhash_keys_strided(const uint16_t* keys, int64_t head_stride, int64_t row_stride,
                                        const uint16_t* Wt, const float* wnorm, int heads, int64_t n, int D, int K,
-                                       int L, int16_t* codes, hipStream_t st) {
+                                       int L, int16_t* codes, const float* rnorm, int64_t rnorm_stride, hipStream_t st) {
     int tp, tiles;
     const int sets = sk_sets(D);
     simhash_keys_geometry(K, sets, tp, tiles);
@@ -763,9 +787,14 @@ hipError_t launch_simhash_keys_strided(const uint16_t* keys, int64_t head_stride
     const size_t lds = (size_t)crows * (SK_WAVES * sets + 1) * sizeof(uint32_t);   // the chunk's sign matrix
 #define MP_SK_CASE(DD)                                                                              \
     if (D == DD) {                                                                                  \
+        if (rnorm != nullptr)                                                                       \
+            hipLaunchKernelGGL((simhash_keys_kernel<DD, true>), grid, block, lds, st, keys, head_stride, \
+                               row_stride, Wt, wnorm, n, K, L, tp, tiles, ch, wgs_x, (int)chunks, heads, \
+                               groups, rnorm, rnorm_stride, codes, g_stamp);                        \
+        else                                                                                        \
         hipLaunchKernelGGL((simhash_keys_kernel<DD>), grid, block, lds, st, keys, head_stride,      \
                            row_stride, Wt, wnorm, n, K, L, tp, tiles, ch, wgs_x, (int)chunks, heads, \
-                           groups, codes, g_stamp);                                                         \
+                           groups, (const float*)nullptr, (int64_t)0, codes, g_stamp);                                                         \
         return hipGetLastError();                                                                   \
     }
     MP_SK_CASE(128)
@@ -777,7 +806,7 @@ hipError_t launch_simhash_keys_strided(const uint16_t* keys, int64_t head_stride
 
 hipError_t launch_simhash_keys(const uint16_t* keys, const uint16_t* Wt, const float* wnorm,
                                int heads, int64_t n, int D, int K, int L, int16_t* codes, hipStream_t st) {
-    return launch_simhash_keys_strided(keys, n * D, D, Wt, wnorm, heads, n, D, K, L, codes, st);
+    return launch_simhash_keys_strided(keys, n * D, D, Wt, wnorm, heads, n, D, K, L, codes, nullptr, 0, st);
 }
 
 }  // namespace mp
