@@ -319,12 +319,40 @@ __device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ 
     __syncthreads();
     int* mine = s_cnt + (wave % nw) * NB;
     bool bad = false;
-#pragma unroll 4
-    for (int k = tid; k < n; k += blockDim.x) {
-        const int v = c[k];
+    auto count = [&](int v) {
         if (v < 0 || v >= NB) bad = true;
         else atomicAdd(&mine[v], 1);
+    };
+    // Round 6: the pass over the row's codes was a loop of 2-byte loads, four in flight per lane -- 48 dependent HBM round
+    // trips per row: 92 of the 233 us a workgroup spent on a row of cfg 1 (scripts/build_phases.py), 39 % of the kernel.  Now a
+    // lane takes EIGHT consecutive codes per 16-byte load (which code a lane counts does not matter to a histogram) and keeps
+    // four such loads in flight: 32 codes per lane and round trip.  The row's start is only 2-byte aligned (n is arbitrary):
+    // the few codes in front of the first 16-byte boundary and behind the last whole vector are counted one by one.
+    const int head_all = (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(c) & 15u)) & 15u) >> 1);
+    const int head = head_all < n ? head_all : n;
+    const int nvec = (n - head) >> 3;
+    const u32x4* cv = reinterpret_cast<const u32x4*>(c + head);
+    const int step = (int)blockDim.x;
+    for (int i0 = tid; i0 < nvec; i0 += 4 * step) {
+        u32x4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                       // unconditional (clamped): a load under a branch is waited for at the join
+            const int i = i0 + u * step;
+            q[u] = cv[i < nvec ? i : nvec - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * step < nvec) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    count((int)(int16_t)(q[u][w] & 0xffffu));
+                    count((int)(int16_t)(q[u][w] >> 16));
+                }
+            }
+        }
     }
+    for (int k = tid; k < head; k += step) count((int)c[k]);
+    for (int k = head + (nvec << 3) + tid; k < n; k += step) count((int)c[k]);
     (void)lane;
     if (bad) atomicOr(err, 1);
     __syncthreads();
@@ -363,6 +391,17 @@ __device__ __forceinline__ void build_row_histogram(const int16_t* __restrict__ 
 // neighbouring entries of a bucket's run ascend and raises err bit 64 otherwise; the host then rebuilds the request with the
 // exact ranking (match-any ballots over the code's bits: ~75 vector instructions per token -- the kernel was bound by VALU
 // issue: 319 M wave-instructions per launch at cfg 1 = 0.52 ms of issue slots alone, profiles/archive/r05_pmc_sq_insts_cfg1.md).
+// phase stamps of the table build (stamp build only: workgroup 0, thread 0, slots 50 .. 58 of the stamp buffer -- kernel start,
+// row histogram done, and for the row's THIRD tile: top, validated + zeroed, counted, scanned, ranked, written out; kernel end)
+#if MP_STAMPS
+__device__ unsigned long long* d_build_stamp = nullptr;
+#define MP_BSTAMP(slot)                                                                                   \
+    do {                                                                                                  \
+        if (d_build_stamp != nullptr && blockIdx.x == 0 && threadIdx.x == 0) d_build_stamp[slot] = wall_clock64(); \
+    } while (0)
+#else
+#define MP_BSTAMP(slot) do { } while (0)
+#endif
 template <int TPL, bool PACK = false, bool FAST = false>   // tokens per lane and tile: T = TPL * blockDim.x
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void lsh_build_kernel(   // 16 waves per CU either way: 128 VGPRs
     const int16_t* __restrict__ codes,   // [Hkv*L][n] unsorted
@@ -392,10 +431,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int64_t row = blockIdx.x;
     const int16_t* c = codes + row * n;
     int32_t* dst = table + row * M;
+    MP_BSTAMP(50);
     // (PACK: the whole-row histogram counts up to n per bucket -- 32-bit counters, nw / 2 sets in the nw * NB / 2 words)
     build_row_histogram(c, n, NB, s_cnt, s_tmp, bounds + row * NB * RS, RS, err,
                         [&](int i, int ex, int v) { s_gbase[i] = v > 0 ? ex : -1; },   // -1: a bucket without tokens (it
                         PACK ? nw / 2 : 0);                                             // never moves: every tile adds 0)
+    MP_BSTAMP(51);
     int* mine = s_cnt + wave * NB;                            // (not PACK)
     const int wbase = wave * NB;                              // PACK: this wave's counters are cnt16[wbase + v]
     auto count_add = [&](int v, int k) -> int {               // += k on this wave's counter of bucket v; returns the old value
@@ -432,7 +473,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const bool cuts = TPL < 32 && range_len > 0 && R > 1;     // uniform (the 32-codes-per-lane form, K = 12 / 13, has no
                                                               // register to spare: its sub-bounds stay with the search kernel)
     int t0 = 0;
+    int tile_no = 0;                                          // (stamp build)
     while (t0 < n) {
+        const bool st_tile = tile_no++ == 2;
+        if (st_tile) MP_BSTAMP(52);
         // the tile: [t0, tend), at most T tokens.  A range boundary inside it is taken in the tile's stride where it falls
         // between two waves' slices (cfg 1: range_len = 12 288 = 12 slices of 1 024): the cursor the scan hands the first
         // wave behind the boundary IS the bucket's sub-bound -- one store per bucket, no extra tile.  Elsewhere (cfg 4:
@@ -464,6 +508,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             vq[j] = (kk < tend && v >= 0 && v < NB) ? v : -1;
         }
         lds_barrier();
+        if (st_tile) MP_BSTAMP(53);
 #if MP_LB_WHATIF != 3               // (3: timing experiment only, wrong tables: no counting of the tile's tokens)
 #pragma unroll
         for (int j = 0; j < TPL; ++j)
@@ -473,6 +518,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if (tend < n) load_codes(tend, vnext);             // uniform; consumed by the next iteration
         }
         lds_barrier();
+        if (st_tile) MP_BSTAMP(54);
         // per-wave cursors inside the tile's sorted order; where the tile's run of a bucket goes
         int carry = 0;
         for (int base = 0; base < NB; base += blockDim.x) {
@@ -507,6 +553,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             carry += total;
         }
         lds_barrier();
+        if (st_tile) MP_BSTAMP(55);
         const int tile_count = carry;                   // valid tokens of the tile
 #if MP_LB_WHATIF == 4               // timing experiment only (wrong tables; with the write-out gone too: stale positions
                                     // would be written out of bounds): no ranking of the tile's tokens
@@ -540,6 +587,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             }
         }
         lds_barrier();
+        if (st_tile) MP_BSTAMP(56);
         // Written out by position, TPL entries per thread, in straight-line batches of 8 (round 5): all stage reads, then all
         // norm gathers, then all stores.  As a rolled loop (the trip count is tile_count / blockDim) every entry was a
         // dependent chain of its own -- LDS read -> L2 gather of the norm -> store -- and a tile paid TPL of them in turn.
@@ -611,6 +659,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
             for (int j = 0; j < TPL; ++j) vq[j] = vnext[j];
         }
+        if (st_tile) MP_BSTAMP(57);
         t0 = tend;
     }
     if (cuts) {   // boundaries at or behind the last token: the bucket's end (its final write position)
@@ -618,6 +667,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         for (int r = (n + range_len - 1) / range_len; r <= R - 1; ++r)
             if (r >= 1) dump_subbound(r);
     }
+    MP_BSTAMP(58);
 }
 
 // Direct variant for NB too large for the staged layout (K >= 14): the row is cut into one
@@ -2431,6 +2481,9 @@ hipError_t launch_lsh_build(const int16_t* codes, int rows, int64_t n, int NB, i
     const int RS = R + 1;
     if (build_staged_geometry(NB, n, R, R > 1 ? lsh_range_len(M, R) : 0, nw, tpl, lds, pack)) {
         const bool fast = pack && !exact_rank;                 // (the 32-codes-per-lane form keeps the exact ranking)
+#if MP_STAMPS
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_build_stamp), &g_stamp, sizeof(g_stamp), 0, hipMemcpyHostToDevice, st);
+#endif
 #define MP_BUILD_CASE(TPL, PK, FA)                                                                         \
         if (tpl == TPL && pack == PK && fast == FA)                                                        \
             hipLaunchKernelGGL((lsh_build_kernel<TPL, PK, FA>), dim3(rows), dim3(64 * nw), lds, st, codes, \
