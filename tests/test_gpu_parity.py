@@ -1529,3 +1529,26 @@ def test_cfg1_shaped_retrieve_sha(mp):
     assert torch.equal(nnz, nnz2)
     for h in range(B * H):
         assert torch.equal(results[h, :nz[h]], results2[h, :nz[h]])
+
+
+@pytest.mark.parametrize("n,shift", [(1, 0), (7, 1), (8, 0), (9, 3), (1023, 1), (4099, 5), (8193, 7)])
+def test_table_build_histogram_on_unaligned_and_odd_rows(mp, n, shift):
+    """Round 6 (EXPERIMENTS.md R6-8): the row histogram of the device table build reads eight codes per 16-byte load; a row
+    starts wherever (kv head, table) x n puts it -- any 2-byte boundary -- so the codes in front of the first 16-byte boundary
+    and behind the last whole vector are counted one by one.  Odd lengths, a code buffer that itself starts off a 16-byte
+    boundary, rows shorter than a vector: the tables must be those of torch.sort + fill."""
+    K, L, H, Hkv, B, M = 6, 5, 4, 2, 1, 8448
+    gen = torch.Generator().manual_seed(1000 + n)
+    codes_cpu = torch.randint(0, 1 << K, (Hkv, L, n), generator=gen, dtype=torch.int32).to(torch.int16)
+    flat = torch.zeros((Hkv * L * n + 8,), dtype=torch.int16, device="cuda")
+    view = flat[shift:shift + Hkv * L * n].view(Hkv, L, n)                 # contiguous, its first byte 2 * shift off the allocation
+    view.copy_(codes_cpu)
+    a, b = mp.LSH(), mp.LSH()
+    a.alloc(K, L, 1, H, Hkv, B, M)
+    b.alloc(K, L, 1, H, Hkv, B, M)
+    a.fastfill(0, 0, view)
+    sv, si = codes_cpu.cuda().sort(dim=-1, stable=True)
+    b.fill(0, 0, sv.contiguous(), si.int().contiguous())
+    ta, tb = a.get_tables(0), b.get_tables(0)
+    assert torch.equal(ta[0], tb[0])                                       # bounds (bucket starts / ends, sub-bounds)
+    assert torch.equal(ta[1][..., :n], tb[1][..., :n])                     # the table rows
