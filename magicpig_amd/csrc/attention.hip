@@ -629,12 +629,24 @@ __global__ __launch_bounds__(256) void key_colsum_kernel(const uint16_t* __restr
     const int64_t a = (int64_t)blockIdx.x * per, b = (a + per < n) ? a + per : n;
     for (int cb = threadIdx.x * 4; cb < cols; cb += blockDim.x * 4) {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int64_t t = a; t < b; ++t) {
-            const uint2 v = *reinterpret_cast<const uint2*>(key_cache + (t0 + t) * cols + cb);
-            acc[0] += (double)bf16_lo(v.x);
-            acc[1] += (double)bf16_hi(v.x);
-            acc[2] += (double)bf16_lo(v.y);
-            acc[3] += (double)bf16_hi(v.y);
+        // eight rows' loads in flight, added in row order (round 6: as a loop of one 8-byte load per iteration the block's ~96
+        // rows were 96 dependent round trips: 70 us per layer at cfg 1 for 200 MB; EXPERIMENTS.md R6-8)
+        for (int64_t t = a; t < b; t += 8) {
+            uint2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t tt = t + u < b ? t + u : b - 1;
+                v[u] = *reinterpret_cast<const uint2*>(key_cache + (t0 + tt) * cols + cb);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t + u < b) {
+                    acc[0] += (double)bf16_lo(v[u].x);
+                    acc[1] += (double)bf16_hi(v[u].x);
+                    acc[2] += (double)bf16_lo(v[u].y);
+                    acc[3] += (double)bf16_hi(v[u].y);
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) partial[(int64_t)blockIdx.x * cols + cb + i] = acc[i];
