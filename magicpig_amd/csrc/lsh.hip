@@ -110,9 +110,6 @@ constexpr int RT_GROUP = 12;               // buckets in flight per wave per rou
 // non-temporal (`nt`: no claim on the L2 the K / V rows and the hyperplanes live in).  Round 4, same instruction schedule with
 // and without the bit on these 121 loads: cfg 3 29.77 -> 29.13 us per layer, cfg 1 and cfg 4 within +-0.1 (EXPERIMENTS.md R4-15).
 #define MP_TLOAD(p) __builtin_nontemporal_load(p)
-#ifndef MP_LB_WHATIF
-#define MP_LB_WHATIF 0                     // 1, 3, 4: leave-one-out timing builds of lsh_build_kernel (EXPERIMENTS.md R6-8); never shipped
-#endif
 constexpr int RT_TAIL_CAP = 2048;          // pooled chunk descriptors for ids beyond 128 per bucket
 constexpr int RT_TAIL_UNROLL = 8;
 constexpr int CLUSTER_MAX = MP_CLUSTER_MAX; // workgroups per query head of the decode kernel, at most (common.h)
@@ -509,11 +506,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         }
         lds_barrier();
         if (st_tile) MP_BSTAMP(53);
-#if MP_LB_WHATIF != 3               // (3: timing experiment only, wrong tables: no counting of the tile's tokens)
 #pragma unroll
         for (int j = 0; j < TPL; ++j)
             if (vq[j] >= 0) (void)count_add(vq[j], 1);
-#endif
         if constexpr (PREFETCH) {
             if (tend < n) load_codes(tend, vnext);             // uniform; consumed by the next iteration
         }
@@ -555,10 +550,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         lds_barrier();
         if (st_tile) MP_BSTAMP(55);
         const int tile_count = carry;                   // valid tokens of the tile
-#if MP_LB_WHATIF == 4               // timing experiment only (wrong tables; with the write-out gone too: stale positions
-                                    // would be written out of bounds): no ranking of the tile's tokens
-        if (tile_count < 0)
-#endif
         if constexpr (FAST) {
 #pragma unroll
             for (int j = 0; j < TPL; ++j) {
@@ -605,9 +596,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             }
             if (refused) atomicOr(bad + row / L, 1);
         } else {
-#if MP_LB_WHATIF == 1 || MP_LB_WHATIF == 4   // timing experiment only (wrong tables): no write-out of the tile
-            if (tile_count < 0)
-#endif
             {
             constexpr int OB = TPL >= 16 ? 4 : 8;                // entries per batch (TPL is 8 or 16; 16 keeps two sets of codes in registers)
             const float* knr = kn ? kn + (row / L) * M : nullptr;    // a tile's 8 192 norms: 32 KB, read once per table row

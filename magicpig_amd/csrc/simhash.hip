@@ -245,12 +245,6 @@ __global__ __launch_bounds__(1024) void simhash_query_kernel(
 // bit matrix [32 * chunk_tiles rows][tiles + 1 words], from which the K-bit codes are cut at the end and stored as long
 // runs of every [L][n] row; guard-band candidates are queued and resolved together at the end (exact f64 dot product,
 // one 16-lane group per candidate), patching the bit matrix before the codes are cut out.
-#ifndef MP_SK_CAND_MASK
-#define MP_SK_CAND_MASK 1                 // guard-band candidates queued as one 16-bit mask per (row, column tile, half-wave)
-#endif
-#ifndef MP_SK_WHATIF
-#define MP_SK_WHATIF 0                    // 1 .. 4: timing experiments on the key kernel (EXPERIMENTS.md R6-7); wrong codes, never shipped
-#endif
 constexpr int SK_CH_MAX = 32;             // 32-row tiles per workgroup, at most (keys_chunk_tiles picks; LDS caps it)
 constexpr int SK_QCAP = 1024;             // deferred exact-sign candidates per workgroup
 constexpr int SK_WAVES = 4;               // waves per workgroup; two workgroups per CU = two waves per SIMD
@@ -415,20 +409,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
         // read every plane's own band from LDS inside the loop (16 dependent LDS round trips, ~2 500 cycles per
         // execution, half a tile's time on average).  Which of a lane's 16 planes belong to this workgroup at all
         // (the last tile's tail, Wt's zero padding) is a per-lane bit mask made once, `mine`.
-#if MP_SK_WHATIF == 1          // timing experiment only (wrong codes): no lane ever holds a guard-band candidate
-        const float thr = -1.f;
-#else
         const float thr = wcoarse[st] * rn;
-#endif
         if (amin <= thr) {
             const int64_t gr = row_base + (int64_t)t * SH_ROWS + (lane & 31);
-            // plane offset of accumulator i inside the workgroup's span: pb + (i & 3) + 8 (i >> 2).  Opaque to the
-            // optimiser on purpose: as a loop invariant it hoisted all 16 SETS sums out of the tile loop -- 64
-            // registers, spilled to scratch
-            int pb = ctile * 32 + 4 * (lane >> 5);
-            asm volatile("" : "+v"(pb));
             const uint32_t ok = gr < n ? mine[st] : 0u;
-#if MP_SK_CAND_MASK
             // ONE queue entry per (row, column tile, half-wave) with the 16 accumulators' candidate bits: straight-line
             // compares, one LDS atomic and one store per lane that holds any -- the per-candidate form below ran 16 divergent
             // branches with an atomic each, in a path that some wave of the workgroup takes in nine tiles of ten, in front of
@@ -443,19 +427,6 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
                     s_queue[slot] = ((uint32_t)(t * SH_ROWS + (lane & 31)) << 21) | ((uint32_t)ctile << 17) |
                                     ((uint32_t)(lane >> 5) << 16) | cm;
             }
-            (void)pb;
-#else
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                // guard-band candidate: queue (chunk row, plane offset) for the exact pass at the end
-                if (((ok >> i) & 1u) && fabsf(acc[i]) <= thr) {
-                    const int slot = atomicAdd(&s_qn, 1);
-                    if (slot < SK_QCAP)
-                        s_queue[slot] = ((uint32_t)(t * SH_ROWS + (lane & 31)) << 16) |
-                                        (uint32_t)(pb + (i & 3) + 8 * (i >> 2));
-                }
-            }
-#endif
         }
     };
     // MFMA + signs of tile t (LDS half t & 1).  C' = W X^T: lane l holds, for row (l & 31) of the tile, the 16 planes
@@ -484,18 +455,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
                 for (int kk = 0; kk < KSTEPS; ++kk) {
                     const bf16x8 xk = KEEP ? xb[KEEP ? kk : 0] : *reinterpret_cast<const bf16x8*>(brow + kk * 16);
-#if MP_SK_WHATIF == 4              // timing experiment only (wrong codes): everything but the matrix instructions
-                    if (kk == 0) acc[st & 1][0] = (float)xk[0] + (float)bfrag[st][kk][0];
-#else
                     acc[st & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag[st][kk], xk, acc[st & 1], 0, 0, 0);
-#endif
                 }
             }
-#if MP_SK_WHATIF == 2              // timing experiment only (wrong codes): matrix work without the sign / guard-band epilogue
-            if (st > 0) { asm volatile("" :: "v"(acc[(st - 1) & 1])); }
-#else
             if (st > 0) epilogue(acc[(st - 1) & 1], st - 1, t, rn);
-#endif
             if (st > 0 && st < SETS) {
 #pragma unroll
                 for (int kk = 0; kk < KSTEPS; ++kk) {
@@ -537,17 +500,12 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     tile_store(0, s0);
     __syncthreads();                                      // ... and past its cut, which read the sign matrix
     MP_STAMP(stamp, 41);
-#if MP_SK_WHATIF == 3              // timing experiment only (racy): no barrier between the tiles
-#define MP_SK_TILE_BARRIER() do { } while (0)
-#else
-#define MP_SK_TILE_BARRIER() lds_barrier()
-#endif
 #define MP_SK_PHASE(T, LOADSET, STORESET)                                  \
     if ((T) < nt) {                                                        \
         tile_load((T) + 2, LOADSET);                                       \
         compute(T);                                                        \
         tile_store(((T) + 1) & 1, STORESET);                               \
-        MP_SK_TILE_BARRIER();                                              \
+        lds_barrier();                                                     \
     }
     for (int t = 0; t < nt; t += 2) {
         MP_SK_PHASE(t, s0, s1)
@@ -575,16 +533,11 @@ __global__ __launch_bounds__(64 * SK_WAVES) __attribute__((amdgpu_waves_per_eu(2
     for (int e = tid >> 4; e < nq; e += nthr >> 4) {
         const uint32_t ent = s_queue[e];
         const int l16 = tid & 15;
-#if MP_SK_CAND_MASK
         const int crow = ent >> 21;
         const int pbase = (int)((ent >> 17) & 15u) * 32 + 4 * (int)((ent >> 16) & 1u);
         for (uint32_t cm = ent & 0xffffu; cm; cm &= cm - 1u) {           // (uniform over the entry's 16 lanes)
         const int i = __builtin_ctz(cm);
         const int coff = pbase + (i & 3) + 8 * (i >> 2);
-#else
-        const int crow = ent >> 16, coff = ent & 0xffffu;
-        {
-#endif
         double part = 0.0;
         for (int d8 = l16; d8 < CPR; d8 += 16) {
             const u32x4 a = *reinterpret_cast<const u32x4*>(xcur + (row_base_cur + crow) * row_stride + d8 * 8);
