@@ -1,12 +1,12 @@
 """Markdown table of a round's committed bench lines (profiles/<tag>_bench_<cfg>[_clustered].json), kernel stats
 (profiles/<tag>_kernel_stats_*.md) and PMC traffic (profiles/hbm_traffic_latest.json): the rows of DESIGN.md section 5.
-usage: python scripts/summarise_round.py r04"""
+usage: python scripts/summarise_round.py r06"""
 import json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(ROOT, "profiles")
-rows = [("cfg0", ""), ("cfg1", ""), ("cfg1", "_clustered"), ("cfg2", ""), ("cfg2", "_clustered"), ("cfg3", ""), ("cfg4", "")]
+rows = [("cfg0", ""), ("cfg1", ""), ("cfg1", "_byproducts"), ("cfg1", "_clustered"), ("cfg2", ""), ("cfg2", "_clustered"), ("cfg3", ""), ("cfg4", "")]
 print("| config | tokens/s | us / launch: HIP events; rocprofv3 avg (step / layers) | algorithmic MB | GB/s (of 8 TB/s) | PMC MB (x) | R | nnz / head | CPU reference tokens/s (retrieve + attention us) | host mode us / layer |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 for cfg, suf in rows:
